@@ -1,0 +1,66 @@
+"""ctypes loader for libawq_hip.so (the C ABI declared in include/awq_hip.h).
+
+There is deliberately no fallback: if the shared library is missing, or a tensor is not on a
+HIP device, the call raises.  The CPU oracle under oracle/ is test infrastructure and is never
+imported from this package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libawq_hip.so")
+
+_lib = None
+
+c_void_p, c_int, c_int64, c_size_t, c_uint32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                  ctypes.c_size_t, ctypes.c_uint32)
+
+# name -> (restype, argtypes); must list every symbol include/awq_hip.h declares
+# (tests/test_boundary.py cross-checks this table against the header and the .so).
+SIGNATURES = {
+    "awq_hip_abi_version": (c_int, []),
+    "awq_hip_error_string": (ctypes.c_char_p, [c_int]),
+    "awq_hip_last_kernel": (ctypes.c_char_p, []),
+    "awq_unpack_int4": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "awq_dequantize_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "awq_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "awq_gemm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                 c_int64, c_int64, c_void_p, c_size_t, c_uint32, c_void_p]),
+}
+
+
+class AwqHipError(RuntimeError):
+    pass
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  torch is imported first so that the HIP runtime
+    already mapped by torch (same SONAME libamdhip64.so.7) is the one our kernels register with."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (side effect: maps torch's libamdhip64 before ours resolves it)
+
+        if not os.path.exists(LIB_PATH):
+            raise AwqHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python autoawq_amd/csrc/build.py` (or __graft_entry__.build()). "
+                "autoawq_amd has no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        if h.awq_hip_abi_version() != 1:
+            raise AwqHipError("libawq_hip.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().awq_hip_error_string(rc).decode()
+        raise AwqHipError(f"{what}: {msg} (code {rc})")

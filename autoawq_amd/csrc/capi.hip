@@ -1,0 +1,118 @@
+// capi.hip -- the extern "C" surface of libawq_hip.so (declared in include/awq_hip.h).
+// Validation + kernel selection only; kernels live in the other translation units.
+#include "awq_internal.h"
+
+namespace {
+thread_local const char* g_last_kernel = "none";
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_gemm_layout(int64_t K, int64_t N, int64_t g) {
+    // awq/modules/linear/gemm.py:132-133
+    if (K < 0 || N < 0 || g <= 0) return AWQ_ERR_BAD_SHAPE;
+    if (N % 8 != 0) return AWQ_ERR_BAD_SHAPE;
+    if (K % g != 0) return AWQ_ERR_BAD_SHAPE;
+    if (K > INT32_MAX || N > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    return AWQ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int awq_hip_abi_version(void) { return AWQ_HIP_ABI_VERSION; }
+
+const char* awq_hip_error_string(int code) {
+    switch (code) {
+        case AWQ_OK: return "ok";
+        case AWQ_ERR_BAD_SHAPE: return "bad shape (need N % 8 == 0, K % group_size == 0)";
+        case AWQ_ERR_BAD_ALIGNMENT: return "pointer not 16-byte aligned";
+        case AWQ_ERR_UNSUPPORTED: return "no kernel for this shape/variant";
+        case AWQ_ERR_WORKSPACE: return "workspace missing or too small";
+        case AWQ_ERR_LAUNCH: return "HIP launch error";
+        case AWQ_ERR_NULL: return "required pointer is NULL";
+        default: return "unknown error";
+    }
+}
+
+const char* awq_hip_last_kernel(void) { return g_last_kernel; }
+
+int awq_unpack_int4(const int32_t* q, uint8_t* out, int64_t rows, int64_t words, void* stream) {
+    if (rows < 0 || words < 0) return AWQ_ERR_BAD_SHAPE;
+    if (rows * words == 0) return AWQ_OK;
+    if (!q || !out) return AWQ_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(out) & 7u) || (reinterpret_cast<uintptr_t>(q) & 3u)) return AWQ_ERR_BAD_ALIGNMENT;
+    return awq_launch_unpack(q, out, rows, words, static_cast<hipStream_t>(stream));
+}
+
+int awq_dequantize_weights(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out,
+                           int64_t K, int64_t N, int64_t group_size, void* stream) {
+    int rc = check_gemm_layout(K, N, group_size);
+    if (rc) return rc;
+    if (K * N == 0) return AWQ_OK;
+    if (!qweight || !scales || !qzeros || !out) return AWQ_ERR_NULL;
+    if (!aligned16(scales) || !aligned16(out)) return AWQ_ERR_BAD_ALIGNMENT;
+    return awq_launch_dequant(qweight, scales, qzeros, out, K, N, group_size, static_cast<hipStream_t>(stream));
+}
+
+size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size) {
+    (void)group_size;
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    // counters + the largest split-K slab set any variant may use: S <= ceil(K/32) slabs of
+    // [min(M,64), N] fp32, capped at 64 slabs.
+    int64_t s = (K + 31) / 32;
+    if (s > 64) s = 64;
+    int64_t m = M < 64 ? M : 64;
+    return (size_t)AWQ_WS_COUNTER_BYTES + (size_t)(s * m * N) * sizeof(float);
+}
+
+int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                     const uint16_t* bias, uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size,
+                     void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+    int rc = check_gemm_layout(K, N, group_size);
+    if (rc) return rc;
+    if (M < 0 || M > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    if (M == 0 || N == 0) return AWQ_OK;
+    if (!x || !qweight || !scales || !qzeros || !y) return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales) || !aligned16(qzeros) || !aligned16(y))
+        return AWQ_ERR_BAD_ALIGNMENT;
+    if (workspace && !aligned16(workspace)) return AWQ_ERR_BAD_ALIGNMENT;
+
+    AwqGemmArgs a;
+    a.x = x; a.qweight = qweight; a.scales = scales; a.qzeros = qzeros; a.bias = bias; a.y = y;
+    a.M = (int)M; a.K = (int)K; a.N = (int)N; a.g = (int)group_size;
+    a.stream = static_cast<hipStream_t>(stream);
+    a.counters = nullptr; a.partial = nullptr; a.partial_floats = 0;
+    if (workspace && workspace_bytes > AWQ_WS_COUNTER_BYTES) {
+        a.counters = static_cast<int*>(workspace);
+        a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + AWQ_WS_COUNTER_BYTES);
+        a.partial_floats = (workspace_bytes - AWQ_WS_COUNTER_BYTES) / sizeof(float);
+    }
+
+    unsigned kern = AWQ_GEMM_FLAG_KERNEL(flags);
+    int nlog = (int)AWQ_GEMM_FLAG_NLOG(flags);
+    int splitk = (int)AWQ_GEMM_FLAG_SPLITK(flags);
+    const bool two_pass = (flags & AWQ_GEMM_FLAG_TWO_PASS) != 0;
+    const bool nt = (flags & AWQ_GEMM_FLAG_NO_NT) == 0;
+    const bool fast_shape = (N % 32 == 0) && (group_size % 8 == 0) && (K % 8 == 0);
+
+    if (kern == AWQ_GEMM_KERNEL_AUTO) {
+        if (!fast_shape) kern = AWQ_GEMM_KERNEL_NAIVE;
+        else if (M <= 4) kern = AWQ_GEMM_KERNEL_VALU;
+        else kern = AWQ_GEMM_KERNEL_NAIVE;
+    }
+    switch (kern) {
+        case AWQ_GEMM_KERNEL_NAIVE:
+            g_last_kernel = "naive";
+            return awq_launch_gemm_naive(a);
+        case AWQ_GEMM_KERNEL_VALU: {
+            if (nlog == 0) nlog = 3;
+            if (splitk == 0) splitk = awq_gemv_valu_default_split(a.K, a.N, nlog);
+            g_last_kernel = "gemv_valu";
+            return awq_launch_gemv_valu(a, nlog, splitk, two_pass, nt);
+        }
+        default:
+            return AWQ_ERR_UNSUPPORTED;
+    }
+}
+
+}  // extern "C"

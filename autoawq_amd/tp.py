@@ -1,0 +1,92 @@
+"""Tensor-parallel sharding of GEMM-layout WQLinear buffers (new component: the reference has no
+distributed code at all -- SURVEY.md 2.3 / 8e; the oracle for it is the unsharded result).
+
+Legal split axes follow from how the reference itself concatenates packed tensors
+(awq/utils/fused_utils.py:87-96):
+  * column-parallel (qkv, gate/up): slice output columns at multiples of 8 -- qweight[:, n0/8:n1/8],
+    qzeros[:, n0/8:n1/8], scales[:, n0:n1], bias[n0:n1]; no communication;
+  * row-parallel (o_proj, down_proj): slice input rows at multiples of group_size --
+    qweight[k0:k1], qzeros[k0/g:k1/g], scales[k0/g:k1/g]; partial sums need ONE all-reduce;
+    bias is added once (rank 0).
+Shards only need to be group aligned, not equal: Llama-2-7B down_proj has 86 groups, so TP=8 is
+6 ranks x 11 groups + 2 ranks x 10 groups, with the matching uneven column split of gate/up.
+One process per GPU; the all-reduce is torch.distributed (backend "nccl" = RCCL over xGMI).
+"""
+import torch
+import torch.nn as nn
+
+from .modules.linear.gemm import WQLinear_GEMM
+
+
+def split_even_units(total_units, world):
+    """Contiguous split of `total_units` indivisible units over `world` ranks, sizes differ by <= 1.
+    Returns [(start, count)] per rank."""
+    base, rem = divmod(total_units, world)
+    out, start = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < rem else 0)
+        out.append((start, cnt))
+        start += cnt
+    return out
+
+
+def column_shard(qweight, qzeros, scales, bias, n0, n1):
+    assert n0 % 8 == 0 and n1 % 8 == 0, "column shards must be multiples of 8 output columns"
+    return (qweight[:, n0 // 8:n1 // 8].contiguous(), qzeros[:, n0 // 8:n1 // 8].contiguous(),
+            scales[:, n0:n1].contiguous(), None if bias is None else bias[n0:n1].contiguous())
+
+
+def row_shard(qweight, qzeros, scales, k0, k1, group_size):
+    assert k0 % group_size == 0 and k1 % group_size == 0, "row shards must be whole groups"
+    g0, g1 = k0 // group_size, k1 // group_size
+    return qweight[k0:k1].contiguous(), qzeros[g0:g1].contiguous(), scales[g0:g1].contiguous()
+
+
+def _module_from(qweight, qzeros, scales, bias, group_size):
+    K, N = qweight.shape[0], qweight.shape[1] * 8
+    m = WQLinear_GEMM(4, group_size, K, N, bias is not None, qweight.device)
+    m.qweight, m.qzeros, m.scales = qweight, qzeros, scales
+    if bias is not None:
+        m.bias = bias
+    return m
+
+
+class ColumnParallelWQLinear(nn.Module):
+    """Holds this rank's output-column slice; forward returns the local slice (no collective)."""
+
+    def __init__(self, full: WQLinear_GEMM, rank, world, unit=8, bounds=None):
+        super().__init__()
+        N = full.out_features
+        if bounds is None:
+            assert N % unit == 0
+            s, c = split_even_units(N // unit, world)[rank]
+            bounds = (s * unit, (s + c) * unit)
+        self.bounds = bounds
+        self.shard = _module_from(*column_shard(full.qweight, full.qzeros, full.scales, full.bias, *bounds),
+                                  full.group_size)
+
+    def forward(self, x):
+        return self.shard(x)
+
+
+class RowParallelWQLinear(nn.Module):
+    """Holds this rank's input-row slice (whole groups); forward all-reduces the partial sums."""
+
+    def __init__(self, full: WQLinear_GEMM, rank, world, bounds=None, group=None):
+        super().__init__()
+        g = full.group_size
+        if bounds is None:
+            s, c = split_even_units(full.in_features // g, world)[rank]
+            bounds = (s * g, (s + c) * g)
+        self.bounds = bounds
+        self.rank, self.world, self.group = rank, world, group
+        qw, qz, sc = row_shard(full.qweight, full.qzeros, full.scales, bounds[0], bounds[1], g)
+        self.shard = _module_from(qw, qz, sc, full.bias if rank == 0 else None, g)
+
+    def forward(self, x_local):
+        y = self.shard(x_local)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(y, group=self.group)
+        return y

@@ -1,0 +1,32 @@
+"""Host-side (torch, any device) packers for the AWQ int4 buffers.
+
+Vectorised replacements for the Python column loops of the reference packers
+(awq/modules/linear/gemm.py:196-249, gemv.py:110-153); they produce bit-identical buffers
+(pinned by tests/test_modules_cpu.py against reference-packed fixtures).  These run once,
+offline, at quantisation time -- they are host logic, not the hot path.
+"""
+import torch
+
+# nibble i of a GEMM-layout word holds logical column ORDER[i] (awq/modules/linear/gemm.py:222)
+AWQ_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)
+
+
+def pack_rows_int4(values, order=AWQ_ORDER):
+    """values [R, C] integer tensor with entries 0..15, C % 8 == 0 -> int32 [R, C/8]; nibble i of
+    word c holds values[:, 8c + order[i]]."""
+    R, C = values.shape
+    v = values.to(torch.int32).reshape(R, C // 8, 8)
+    out = torch.zeros((R, C // 8), dtype=torch.int32, device=values.device)
+    for i, o in enumerate(order):
+        out |= v[:, :, o] << (4 * i)  # int32 wraps exactly like the reference's `|= col << shift`
+    return out
+
+
+def quantize_int_weights_kn(weight_nk, scales_gn, zeros_gn, group_size):
+    """Integer weights [K, N] = round((W^T + z*s) / s) with the dtype promotion of
+    awq/modules/linear/gemm.py:196-203 (fp16 scales, z*s in the dtype the caller passed)."""
+    scale_zeros = zeros_gn * scales_gn
+    s_half = scales_gn.clone().half()
+    wt = weight_nk.t()
+    num = wt + scale_zeros.repeat_interleave(group_size, dim=0)
+    return torch.round(num / s_half.repeat_interleave(group_size, dim=0)).to(torch.int)

@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tok/s @bs=1 + GEMV HBM GB/s on synthetic Llama-2-7B-shape AWQ int4 g128.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 launched by
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A "step" = one decode token through every int4 Linear of the model (the hot path): per layer
+qkv (fused, 4096->12288), o (4096->4096), gate+up (fused, 4096->22016), down (11008->4096), 32
+layers, batch 1, distinct random packed weights per layer (3.37 GB working set >> the 256 MiB
+Infinity Cache), captured in ONE hipGraph and replayed.  Inputs are resident in HBM before the
+timed region.  N > 1: the same model tensor-parallel over N GPUs (column-split qkv / gate+up,
+row-split o / down with one RCCL all-reduce each) -- strong scaling.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured-achievable copy is 6290
+HIDDEN, INTER, LAYERS, GROUP = 4096, 11008, 32, 128
+
+
+def algorithmic_bytes(K, N, M, g, bias=False):
+    """packed weights + zeros + scales read once, x read once, y written once."""
+    return K * N // 2 + (K // g) * (N // 8) * 4 + (K // g) * N * 2 + M * K * 2 + M * N * 2 + (N * 2 if bias else 0)
+
+
+def rand_packed(K, N, g, dev, gen):
+    lim = 0x7FFFFFFF
+    qw = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, device=dev, generator=gen)
+    qz = torch.randint(-lim - 1, lim, (K // g, N // 8), dtype=torch.int32, device=dev, generator=gen)
+    sc = (torch.rand((K // g, N), device=dev, generator=gen) * 0.02 + 0.005).half()
+    return qw, qz, sc
+
+
+def build_model(dev, rank, world, layers, seed=1234):
+    """Per-rank shard shapes: column split of qkv / gate+up, whole-group row split of o / down."""
+    from autoawq_amd.tp import split_even_units
+
+    gen = torch.Generator(device=dev).manual_seed(seed + rank)
+    # o_proj rows / qkv columns: split the 32 heads (128 columns each)
+    hs, hc = split_even_units(HIDDEN // 128, world)[rank]
+    # down rows: split the 86 groups; gate/up columns follow the same bounds
+    gs, gc = split_even_units(INTER // GROUP, world)[rank]
+    shapes = [("qkv", HIDDEN, 3 * hc * 128, False), ("o", hc * 128, HIDDEN, True),
+              ("gate_up", HIDDEN, 2 * gc * GROUP, False), ("down", gc * GROUP, HIDDEN, True)]
+    model = []
+    for _ in range(layers):
+        layer = []
+        for name, K, N, reduce_after in shapes:
+            qw, qz, sc = rand_packed(K, N, GROUP, dev, gen)
+            x = torch.randn((1, K), device=dev, generator=gen).half()
+            layer.append(dict(name=name, K=K, N=N, qw=qw, qz=qz, sc=sc, x=x, reduce=reduce_after and world > 1))
+        model.append(layer)
+    return model, shapes
+
+
+def run_step(model, outs, ops, dist):
+    i = 0
+    for layer in model:
+        for lin in layer:
+            y = ops.gemm_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"])
+            if lin["reduce"]:
+                dist.all_reduce(y)
+            outs[i] = y
+            i += 1
+
+
+def cpu_baseline(layers_total):
+    """AutoAWQ's own CPU path (dequantize_gemm + fp16 matmul, awq/modules/linear/gemm.py:71-79)
+    restated in torch (oracle/awq_oracle.py, kind="port"), timed on this host's cores on a bounded
+    sample: the 4 Linears of ONE layer, median of 3 after one warm-up."""
+    from oracle import awq_oracle
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    gen = torch.Generator().manual_seed(7)
+    lins = []
+    for K, N in [(HIDDEN, 3 * HIDDEN), (HIDDEN, HIDDEN), (HIDDEN, 2 * INTER), (INTER, HIDDEN)]:
+        qw, qz, sc = rand_packed(K, N, GROUP, "cpu", gen)
+        lins.append((torch.randn((1, K), generator=gen).half(), qw, qz, sc))
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        for x, qw, qz, sc in lins:
+            awq_oracle.torch_linear_gemm(x, qw, qz, sc, GROUP)
+        dt = time.perf_counter() - t0
+        if it:
+            times.append(dt)
+    layer_s = statistics.median(times)
+    return {"value": 1.0 / (layer_s * layers_total), "unit": "tok/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"4 Linears of 1 of {layers_total} layers, median of 3 ({layer_s:.2f} s/layer); "
+                                       "torch-CPU restatement of dequantize_gemm + fp16 matmul"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--layers", type=int, default=LAYERS, help="debug only; the metric is quoted at 32")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or (a.gpus == 1 and world == 1), f"--gpus {a.gpus} but WORLD_SIZE {world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from autoawq_amd import _lib, ops
+
+    _lib.lib()
+    model, shapes = build_model(dev, rank, world, a.layers)
+    nl = sum(len(l) for l in model)
+    outs = [None] * nl
+    bytes_step = sum(algorithmic_bytes(l["K"], l["N"], 1, GROUP) for layer in model for l in layer)
+
+    stream = torch.cuda.Stream(device=dev)
+    graph, used_graph = None, False
+    with torch.cuda.stream(stream):
+        for _ in range(max(a.warmup, 3) if a.no_graph else 3):
+            run_step(model, outs, ops, dist)
+        stream.synchronize()
+        if not a.no_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    run_step(model, outs, ops, dist)
+                used_graph = True
+            except Exception as e:  # e.g. collective not capturable: fall back to eager launches
+                if rank == 0:
+                    print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+                graph = None
+        step = graph.replay if graph is not None else (lambda: run_step(model, outs, ops, dist))
+        for _ in range(a.warmup):
+            step()
+        stream.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(a.steps):
+            step()
+        e1.record(stream)
+        e1.synchronize()
+        torch.cuda.synchronize()
+        ms_total = e0.elapsed_time(e1)
+    if dist is not None:
+        t = torch.tensor([ms_total], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_total = float(t.item())
+        tb = torch.tensor([float(bytes_step)], device=dev)
+        dist.all_reduce(tb)
+        bytes_all = float(tb.item())
+        dist.barrier()
+    else:
+        bytes_all = float(bytes_step)
+    ms_step = ms_total / a.steps
+
+    if rank == 0:
+        tok_s = 1000.0 / ms_step
+        launches = nl
+        # dominant kernel = the fused int4 GEMV; the timed region holds nothing but its launches
+        # (N=1), so its average launch duration (incl. inter-kernel gap) = step time / launches.
+        achieved = (bytes_step / launches) / (ms_step * 1e-3 / launches) / 1e9  # this rank's GB/s
+        out = {
+            "metric": "decode tok/s @bs=1 (int4 linears), 7B AWQ-int4 g128", "value": tok_s, "unit": "tok/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "int4 weights x fp16 activations, fp32 accumulate", "data": "synthetic",
+            "config": {"workload": "Llama-2-7B-shape AWQ int4 g128, GEMV bs=1 decode: 32 layers x "
+                                   "{qkv 4096->12288, o 4096->4096, gate+up 4096->22016, down 11008->4096}",
+                       "layers": a.layers, "launches_per_step": launches, "hipgraph": used_graph,
+                       "parallelism": f"tp{world}" if world > 1 else "single",
+                       "algorithmic_bytes_per_step_all_ranks": bytes_all, "kernel": ops.last_kernel()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": bytes_step / launches, "avg_launch_us": ms_step * 1e3 / launches,
+                         "note": "achieved = algorithmic bytes / event-timed step; includes inter-kernel gaps"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.layers)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

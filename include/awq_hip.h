@@ -1,0 +1,96 @@
+/*
+ * awq_hip.h -- C ABI of libawq_hip.so, the MI355X (gfx950) AWQ int4 weight-only matmul library.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one function of
+ * the pybind11 extension modules `awq_ext` / `awq_v2_ext` that the reference calls but does not
+ * ship (they live in the un-vendored `autoawq-kernels` package, reference setup.py:53).  The
+ * reference call site each one serves is cited next to it (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; fp16 travels as uint16_t bit patterns; no torch types.
+ *   - every pointer is a DEVICE pointer owned by the caller, including outputs and workspaces;
+ *     the library never allocates, frees or synchronises (hipGraph-capturable).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - return value: AWQ_OK (0) or a negative AWQ_ERR_* code; awq_hip_error_string() names it.
+ *   - stateless and re-entrant; layout facts asserted by the reference modules are re-checked
+ *     (N % 8 == 0, K % group == 0 -- awq/modules/linear/gemm.py:132-133).
+ *   - workspaces: *_workspace_bytes() gives the size.  The first AWQ_WS_COUNTER_BYTES of a GEMM
+ *     workspace hold split-K arrival counters and MUST be zero before the first call; every call
+ *     leaves them zero again.
+ */
+#ifndef AWQ_HIP_H
+#define AWQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AWQ_HIP_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define AWQ_EXPORT __attribute__((visibility("default")))
+#else
+#define AWQ_EXPORT
+#endif
+
+enum {
+    AWQ_OK = 0,
+    AWQ_ERR_BAD_SHAPE = -1,     /* N % 8, K % group, group % 8 ... violated */
+    AWQ_ERR_BAD_ALIGNMENT = -2, /* a pointer is not 16-byte aligned */
+    AWQ_ERR_UNSUPPORTED = -3,   /* valid AWQ tensor, but no kernel for it yet */
+    AWQ_ERR_WORKSPACE = -4,     /* workspace too small / NULL where one is required */
+    AWQ_ERR_LAUNCH = -5,        /* hipGetLastError() != hipSuccess after the launch */
+    AWQ_ERR_NULL = -6           /* a required pointer is NULL */
+};
+
+#define AWQ_WS_COUNTER_BYTES 16384 /* 4096 int32 split-K tickets at the head of a GEMM workspace */
+
+AWQ_EXPORT int awq_hip_abi_version(void);
+AWQ_EXPORT const char* awq_hip_error_string(int code);
+/* Name of the kernel variant the last awq_gemm_forward() call on this thread dispatched to
+ * (diagnostics / tests; static string). */
+AWQ_EXPORT const char* awq_hip_last_kernel(void);
+
+/* ---- GEMM layout: qweight [K, N/8] i32, qzeros [K/g, N/8] i32, scales [K/g, N] f16 ------- */
+
+/* Integer unpack only: out[r, 8c+j] = nibble of q[r, c] holding logical column 8c+j (0..15).
+ * Reference: unpack_awq + reverse_awq_order + `& 0xF`, awq/utils/packing_utils.py:8-43,94-95. */
+AWQ_EXPORT int awq_unpack_int4(const int32_t* q, uint8_t* out, int64_t rows, int64_t words, void* stream);
+
+/* Replaces awq_ext.dequantize_weights_cuda(qweight, scales, qzeros, split_k_iters, thx, thy, dbg)
+ * (awq/modules/linear/gemm.py:51-53 forward, :100-102 backward; tests/test_dequantization.py:41-49).
+ * out [K, N] fp16 = (w - z) * s, bit-identical to dequantize_gemm (packing_utils.py:87-102). */
+AWQ_EXPORT int awq_dequantize_weights(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                           uint16_t* out, int64_t K, int64_t N, int64_t group_size, void* stream);
+
+/* Replaces awq_ext.gemm_forward_cuda(x2d, qweight, scales, qzeros, split_k_iters)
+ * (awq/modules/linear/gemm.py:56-58; awq/modules/fused/mlp.py:41,49-62).
+ * y [M, N] fp16 = x [M, K] fp16 @ dequant(qweight) (+ bias [N] fp16 if bias != NULL), fp32
+ * accumulation, one rounding of the result.  Any M >= 0.  `workspace` may be NULL only if
+ * awq_gemm_workspace_bytes() returned 0 for the shape.  `flags` = 0 selects the tuned kernel;
+ * AWQ_GEMM_FLAG_* force a variant (tests / tuning sweeps). */
+AWQ_EXPORT size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size);
+AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
+                     const int32_t* qzeros, const uint16_t* bias, uint16_t* y, int64_t M, int64_t K,
+                     int64_t N, int64_t group_size, void* workspace, size_t workspace_bytes,
+                     uint32_t flags, void* stream);
+
+/* flags for awq_gemm_forward: bits 0-3 kernel family, bits 4-7 column-lane log2, bits 8-15 split-K */
+#define AWQ_GEMM_KERNEL_AUTO 0u
+#define AWQ_GEMM_KERNEL_NAIVE 1u  /* one thread per output, reference-order loop (checker) */
+#define AWQ_GEMM_KERNEL_VALU 2u   /* wave64 streaming GEMV, fp16 dequant + fp32 FMA, M <= 4 */
+#define AWQ_GEMM_KERNEL_SKINNY 3u /* MFMA 16x16x32 skinny GEMM, M <= 16 per pass */
+#define AWQ_GEMM_KERNEL_TILED 4u  /* LDS-tiled MFMA GEMM with fused dequant, large M */
+#define AWQ_GEMM_FLAG_KERNEL(f) ((f)&0xFu)
+#define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto */
+#define AWQ_GEMM_FLAG_SPLITK(f) (((f) >> 8) & 0xFFu) /* 0 = auto */
+#define AWQ_GEMM_FLAG_TWO_PASS (1u << 16) /* split-K reduce in a second kernel instead of in-launch */
+#define AWQ_GEMM_FLAG_NO_NT (1u << 17)    /* plain (temporal) weight loads */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWQ_HIP_H */

@@ -1,0 +1,111 @@
+"""CPU-side checks of the drop-in boundary: C ABI symbols, module surface, packers, and the rule
+that the product never touches the oracle.  No GPU needed (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "awq_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(awq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_and_library_exports_same_symbols():
+    from autoawq_amd import _lib
+
+    if not _lib.available():
+        import __graft_entry__
+
+        __graft_entry__.build()
+    names = _header_functions()
+    assert names, "no functions parsed from include/awq_hip.h"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(h, n), f"libawq_hip.so does not export {n}"
+    L = _lib.lib()
+    assert L.awq_hip_abi_version() == 1
+    assert L.awq_hip_error_string(-1).decode().startswith("bad shape")
+    # pure host-side validation paths (no kernel is launched for these)
+    assert L.awq_gemm_forward(None, None, None, None, None, None, 1, 128, 12, 128, None, 0, 0, None) == -1  # N % 8
+    assert L.awq_gemm_forward(None, None, None, None, None, None, 1, 100, 16, 64, None, 0, 0, None) == -1   # K % g
+    assert L.awq_gemm_forward(None, None, None, None, None, None, 0, 128, 16, 128, None, 0, 0, None) == 0   # M == 0
+    assert L.awq_gemm_forward(None, None, None, None, None, None, 1, 128, 16, 128, None, 0, 0, None) == -6  # NULL
+    assert L.awq_gemm_workspace_bytes(1, 4096, 4096, 128) > 16384
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under autoawq_amd/ may reference it."""
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "autoawq_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle|awq_oracle|libawq_oracle", txt, re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_wqlinear_gemm_surface_matches_reference_checkpoint_layout():
+    from autoawq_amd import WQLinear_GEMM
+
+    g = golden("packed_K512_N64_g128")
+    m = WQLinear_GEMM(4, 128, 512, 64, True, "cpu")
+    sd = m.state_dict()
+    assert list(sd.keys()) == ["qweight", "qzeros", "scales", "bias"]
+    assert tuple(sd["qweight"].shape) == g["gemm_qweight"].shape and sd["qweight"].dtype == torch.int32
+    assert tuple(sd["qzeros"].shape) == g["gemm_qzeros"].shape and sd["qzeros"].dtype == torch.int32
+    assert tuple(sd["scales"].shape) == g["gemm_scales"].shape and sd["scales"].dtype == torch.float16
+    assert list(dict(m.named_parameters())) == []  # buffers, not Parameters
+    assert "in_features=512, out_features=64, bias=True, w_bit=4, group_size=128" in repr(m)
+    assert WQLinear_GEMM(4, -1, 256, 64, False, "cpu").group_size == 256  # gemm.py:128
+    assert WQLinear_GEMM(4, 128, 256, 64, False, "cpu").bias is None
+    with pytest.raises(NotImplementedError):
+        WQLinear_GEMM(3, 128, 256, 64, False, "cpu")
+    with pytest.raises(AssertionError):
+        WQLinear_GEMM(4, 128, 200, 64, False, "cpu")
+    # state-dict round trip with reference-produced buffers
+    m.load_state_dict({"qweight": torch.from_numpy(g["gemm_qweight"]), "qzeros": torch.from_numpy(g["gemm_qzeros"]),
+                       "scales": torch.from_numpy(g["gemm_scales"]), "bias": torch.from_numpy(g["bias"])})
+    assert np.array_equal(m.qweight.numpy(), g["gemm_qweight"])
+
+
+@pytest.mark.parametrize("name", ["packed_K512_N64_g128", "packed_K256_N32_g64", "packed_K128_N32_g32"])
+def test_from_linear_packs_bit_identically_to_reference(name):
+    """Vectorised packer == reference Python-loop packer (awq/modules/linear/gemm.py:171-251)."""
+    from autoawq_amd import WQLinear_GEMM
+
+    g = golden(name)
+    gs = int(g["group_size"])
+    K, N = g["w_int"].shape
+    lin = torch.nn.Linear(K, N, bias=True).half()
+    lin.weight.data = torch.from_numpy(g["lin_weight"])
+    lin.bias.data = torch.from_numpy(g["bias"])
+    scales = torch.from_numpy(g["gemm_scales"])                      # [G, N] fp16
+    zeros = torch.from_numpy(g["z_int"].astype(np.float32))          # [G, N]
+    m = WQLinear_GEMM.from_linear(lin, 4, gs, False, scales, zeros)
+    assert np.array_equal(m.qweight.numpy(), g["gemm_qweight"])
+    assert np.array_equal(m.qzeros.numpy(), g["gemm_qzeros"])
+    assert np.array_equal(m.scales.numpy().view(np.uint16), g["gemm_scales"].view(np.uint16))
+    assert np.array_equal(m.bias.detach().numpy(), g["bias"])
+    empty = WQLinear_GEMM.from_linear(lin, 4, gs, init_only=True)
+    assert int(empty.qweight.abs().sum()) == 0
+
+
+def test_cpu_tensors_fail_loudly():
+    from autoawq_amd import WQLinear_GEMM
+    from autoawq_amd._lib import AwqHipError
+
+    m = WQLinear_GEMM(4, 128, 256, 64, False, "cpu")
+    with pytest.raises(AwqHipError):
+        m(torch.randn(1, 1, 256))
+    # empty batch never reaches a kernel (gemm.py:44-45)
+    out = m(torch.randn(0, 5, 256))
+    assert out.shape == (0, 5, 64) and out.dtype == torch.float32
