@@ -70,19 +70,3 @@ AWQ_DEV float ld_agent_f32(const float* p) {
     uint32_t u = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return __builtin_bit_cast(float, u);
 }
-
-// Split-K hand-off (cdna_hip_programming.md section 5, "in-launch split-K reduction", sc1 form):
-// every wave has issued write-through partial stores; drain them, then ONE lane takes a ticket.
-// Returns true in every thread of the block that arrived last for `counter`.
-AWQ_DEV bool awq_splitk_arrive(int* counter, int nsplit, int* lds_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool last = (t == nsplit - 1);
-        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-        *lds_flag = last ? 1 : 0;
-    }
-    __syncthreads();
-    return *lds_flag != 0;
-}

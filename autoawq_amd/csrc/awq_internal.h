@@ -19,14 +19,17 @@ struct AwqGemmArgs {
     const uint16_t* bias;    // [N] or null
     uint16_t* y;             // [M, N]
     int M, K, N, g;
-    int* counters;   // split-K tickets (zero on entry, zero on exit)
-    float* partial;  // [S, M, N] fp32 split-K slabs
+    int* counters;   // control words (last one = error flag); zero on entry, zero on exit
+    float* partial;  // split-K slabs: tagged 8-byte granules [S-1, M, N] (or fp32 [S, M, N] in two-pass mode)
     size_t partial_floats;
     hipStream_t stream;
 };
 
 int awq_launch_gemm_naive(const AwqGemmArgs& a);
 // nlog: log2 of column-lanes per wave (2..4), splitk >= 1, two_pass: separate reduce kernel
-int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pass, bool nt);
+int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pass, bool nt, int ablate = 0);
 int awq_gemv_valu_default_split(int K, int N, int nlog);
 int awq_launch_splitk_reduce(const AwqGemmArgs& a, int splitk);
+// MFMA skinny GEMM, M <= 16; wpl = packed words per lane (2 or 4)
+int awq_launch_gemm_skinny(const AwqGemmArgs& a, int wpl, int splitk, bool nt);
+int awq_skinny_default_split(int K, int N, int wpl);

@@ -57,12 +57,14 @@ int awq_dequantize_weights(const int32_t* qweight, const uint16_t* scales, const
 size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     (void)group_size;
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    // counters + the largest split-K slab set any variant may use: S <= ceil(K/32) slabs of
-    // [min(M,64), N] fp32, capped at 64 slabs.
+    // control words + split-K slabs: up to 64 slabs of [min(M,16), N] 8-byte granules, capped at
+    // 64 MiB (the launchers lower the split to what fits).
     int64_t s = (K + 31) / 32;
     if (s > 64) s = 64;
-    int64_t m = M < 64 ? M : 64;
-    return (size_t)AWQ_WS_COUNTER_BYTES + (size_t)(s * m * N) * sizeof(float);
+    int64_t m = M < 16 ? M : 16;
+    size_t slabs = (size_t)(s * m * N) * 8;
+    if (slabs > ((size_t)64 << 20)) slabs = (size_t)64 << 20;
+    return (size_t)AWQ_WS_COUNTER_BYTES + slabs;
 }
 
 int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
@@ -98,6 +100,7 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     if (kern == AWQ_GEMM_KERNEL_AUTO) {
         if (!fast_shape) kern = AWQ_GEMM_KERNEL_NAIVE;
         else if (M <= 4) kern = AWQ_GEMM_KERNEL_VALU;
+        else if (M <= 16 && K % 32 == 0 && group_size % 32 == 0) kern = AWQ_GEMM_KERNEL_SKINNY;
         else kern = AWQ_GEMM_KERNEL_NAIVE;
     }
     switch (kern) {
@@ -107,8 +110,18 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
         case AWQ_GEMM_KERNEL_VALU: {
             if (nlog == 0) nlog = 3;
             if (splitk == 0) splitk = awq_gemv_valu_default_split(a.K, a.N, nlog);
+            while (splitk > 1 && (size_t)splitk * a.M * a.N * 8 > a.partial_floats * sizeof(float)) --splitk;
             g_last_kernel = "gemv_valu";
-            return awq_launch_gemv_valu(a, nlog, splitk, two_pass, nt);
+            return awq_launch_gemv_valu(a, nlog, splitk, two_pass, nt, (int)((flags >> 20) & 0xFu));
+        }
+        case AWQ_GEMM_KERNEL_SKINNY: {
+            const int wpl = (nlog == 4) ? 4 : 2;
+            if (M > 16) return AWQ_ERR_UNSUPPORTED;
+            if (splitk == 0) splitk = awq_skinny_default_split(a.K, a.N, wpl);
+            // keep the granule slabs inside the workspace the caller gave us
+            while (splitk > 1 && (size_t)(splitk - 1) * a.M * a.N * 8 > a.partial_floats * sizeof(float)) --splitk;
+            g_last_kernel = wpl == 4 ? "skinny_mfma_w4" : "skinny_mfma_w2";
+            return awq_launch_gemm_skinny(a, wpl, splitk, nt);
         }
         default:
             return AWQ_ERR_UNSUPPORTED;

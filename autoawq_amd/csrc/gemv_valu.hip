@@ -13,8 +13,9 @@
 //   * weights are dequantised to the exact fp16 the reference materialises ((w - z) * s, see
 //     awq_device.h) and accumulated in fp32 with mixed-precision FMAs;
 //   * block partials are folded through LDS; K is split over gridDim.y and the slabs are
-//     combined in-launch by the last-arriving block in FIXED slab order (deterministic), using
-//     write-through partial stores + one relaxed agent-scope ticket (no fences, no spinning).
+//     combined in-launch in FIXED slab order (deterministic) through tagged write-through
+//     granules, no fences and no tickets (awq_combine.h).
+#include "awq_combine.h"
 #include "awq_device.h"
 #include "awq_internal.h"
 
@@ -28,7 +29,7 @@ struct GemvParams {
     const half_t* bias;
     half_t* y;
     float* partial;
-    int* counters;
+    int* err;
     int K, N, g, rows_per_block;
     int in_launch_reduce;
 };
@@ -38,14 +39,16 @@ struct Chunk {
     u32x4 q[8];
 };
 
-template <int M, int NLOG, bool NT>
+// ABL (tuning ablations, wrong results on purpose): 1 = no in-launch split-K combine,
+// 2 = no dequant/FMA work (loads kept live), 3 = both.
+template <int M, int NLOG, bool NT, int ABL = 0>
 __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
     constexpr int NL = 1 << NLOG;    // column-lanes per wave
     constexpr int KLW = 64 / NL;     // K-lanes per wave
     constexpr int KLB = KLW * 4;     // K-lanes per block
     constexpr int CT = NL * 32;      // columns per block
     constexpr int STEP = KLB * 8;    // rows covered by one block pass
-    __shared__ float red[KLB * CT + 4];  // 32 KiB + flag word (single LDS object)
+    __shared__ float red[KLB * CT];  // 32 KiB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & (NL - 1);
@@ -70,6 +73,13 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
     };
 
     auto compute_chunk = [&](const u32x4(&q)[8], int k0) {
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) acc[0][r * 4 + wd] = __builtin_bit_cast(float, q[r][wd]);
+            return;
+        }
         const int grp = k0 / p.g;
         const u32x4 qz = *reinterpret_cast<const u32x4*>(p.qzeros + (int64_t)grp * NW + c32 * 4);
         half2_t zm[16], sc[16];
@@ -124,8 +134,11 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
         }
     }
 
-    // ---- fold the KLB K-lanes of the block through LDS, one activation row at a time
-    const bool single = (gridDim.y == 1);
+    // ---- fold the KLB K-lanes of the block through LDS, one activation row at a time; then
+    // split-K: producers publish tagged granules, the last-slab block collects (awq_combine.h)
+    const int S = gridDim.y;
+    const bool reducer = (S > 1) && (blockIdx.y == S - 1);
+    const int64_t slab = (int64_t)M * p.N;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         if (m) __syncthreads();
@@ -143,40 +156,30 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
 #pragma unroll 8
             for (int k = 0; k < KLB; ++k) s += red[k * CT + off];
             const int col = blockIdx.x * CT + c;
-            if (col < p.N) {
-                if (single) {
-                    if (p.bias) s += (float)p.bias[col];
-                    p.y[(int64_t)m * p.N + col] = (half_t)s;
-                } else {
-                    float* dst = p.partial + ((int64_t)blockIdx.y * M + m) * p.N + col;
-                    if (p.in_launch_reduce)
-                        st_agent_f32(dst, s);
-                    else
-                        *dst = s;
+            if (col >= p.N) continue;
+            if (S > 1) {
+                if (!p.in_launch_reduce) {  // two-pass mode: plain fp32 slabs, separate reduce kernel
+                    p.partial[((int64_t)blockIdx.y * M + m) * p.N + col] = s;
+                    continue;
+                }
+                awq_granule_t* g = reinterpret_cast<awq_granule_t*>(p.partial) + (int64_t)m * p.N + col;
+                if (!reducer) {
+                    if constexpr (!(ABL & 1)) awq_publish(g + (int64_t)blockIdx.y * slab, s);
+                    continue;
+                }
+                if constexpr (!(ABL & 1)) {
+                    float others;
+                    if (!awq_collect<64>(g, slab, S - 1, others)) {
+                        *p.err = 1;
+                        others = 0.f;
+                    }
+                    awq_clear(g, slab, S - 1);
+                    s = others + s;
                 }
             }
+            if (p.bias) s += (float)p.bias[col];
+            p.y[(int64_t)m * p.N + col] = (half_t)s;
         }
-    }
-    if (single || !p.in_launch_reduce) return;
-
-    // ---- split-K: last-arriving block of this column tile sums the slabs in fixed order
-    int* flag = reinterpret_cast<int*>(red + KLB * CT);
-    if (!awq_splitk_arrive(p.counters + blockIdx.x, gridDim.y, flag)) return;
-    const int S = gridDim.y;
-    for (int i = tid; i < M * CT; i += 256) {
-        const int m = i / CT, col = blockIdx.x * CT + (i % CT);
-        if (col >= p.N) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < S; sp += 8) {  // 8 independent sc1 loads in flight, summed in slab order
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                v[u] = (sp + u < S) ? ld_agent_f32(p.partial + ((int64_t)(sp + u) * M + m) * p.N + col) : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        if (p.bias) s += (float)p.bias[col];
-        p.y[(int64_t)m * p.N + col] = (half_t)s;
     }
 }
 
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void awq_gemm_naive_kernel(const uint32_t* __r
 
 template <int M, int NLOG, bool NT>
 void launch_valu(const GemvParams& p, dim3 grid, hipStream_t stream) {
-    hipLaunchKernelGGL((awq_gemv_valu_kernel<M, NLOG, NT>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((awq_gemv_valu_kernel<M, NLOG, NT, 0>), grid, dim3(256), 0, stream, p);
 }
 
 template <int M>
@@ -248,7 +251,7 @@ int awq_gemv_valu_default_split(int K, int N, int nlog) {
     return s;
 }
 
-int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pass, bool nt) {
+int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pass, bool nt, int ablate) {
     if (a.M < 1 || a.M > 4 || a.N % 32 || a.g % 8 || a.K % 8) return AWQ_ERR_UNSUPPORTED;
     if (nlog < 2 || nlog > 4) return AWQ_ERR_UNSUPPORTED;
     const int CT = 32 << nlog;
@@ -256,12 +259,14 @@ int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pa
     const int tiles = (a.N + CT - 1) / CT;
     const int passes = (a.K + step - 1) / step;
     if (splitk < 1) splitk = 1;
+    if (splitk > 64) splitk = 64;
     if (splitk > passes) splitk = passes;
     const int ppb = (passes + splitk - 1) / splitk;  // passes per block
     splitk = (passes + ppb - 1) / ppb;
     if (splitk > 1) {
-        if (!a.partial || a.partial_floats < (size_t)splitk * a.M * a.N) return AWQ_ERR_WORKSPACE;
-        if (!two_pass && (!a.counters || tiles > AWQ_WS_COUNTER_BYTES / 4)) return AWQ_ERR_WORKSPACE;
+        const size_t need = two_pass ? (size_t)splitk * a.M * a.N * sizeof(float)
+                                     : (size_t)(splitk - 1) * a.M * a.N * sizeof(awq_granule_t);
+        if (!a.partial || a.partial_floats * sizeof(float) < need || !a.counters) return AWQ_ERR_WORKSPACE;
     }
     GemvParams p;
     p.qweight = reinterpret_cast<const uint32_t*>(a.qweight);
@@ -271,11 +276,17 @@ int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pa
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.partial = a.partial;
-    p.counters = a.counters;
+    p.err = a.counters ? a.counters + (AWQ_WS_COUNTER_BYTES / 4 - 1) : nullptr;
     p.K = a.K; p.N = a.N; p.g = a.g;
     p.rows_per_block = ppb * step;
     p.in_launch_reduce = two_pass ? 0 : 1;
     dim3 grid(tiles, splitk);
+    if (ablate && a.M == 1 && nlog == 3 && nt) {
+        if (ablate == 1) hipLaunchKernelGGL((awq_gemv_valu_kernel<1, 3, true, 1>), grid, dim3(256), 0, a.stream, p);
+        else if (ablate == 2) hipLaunchKernelGGL((awq_gemv_valu_kernel<1, 3, true, 2>), grid, dim3(256), 0, a.stream, p);
+        else hipLaunchKernelGGL((awq_gemv_valu_kernel<1, 3, true, 3>), grid, dim3(256), 0, a.stream, p);
+        return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+    }
     switch (a.M) {
         case 1: dispatch_valu<1>(p, grid, nlog, nt, a.stream); break;
         case 2: dispatch_valu<2>(p, grid, nlog, nt, a.stream); break;

@@ -13,8 +13,8 @@ FLAG_TWO_PASS = 1 << 16
 FLAG_NO_NT = 1 << 17
 
 
-def gemm_flags(kernel=0, nlog=0, splitk=0, two_pass=False, no_nt=False):
-    f = (kernel & 0xF) | ((nlog & 0xF) << 4) | ((splitk & 0xFF) << 8)
+def gemm_flags(kernel=0, nlog=0, splitk=0, two_pass=False, no_nt=False, ablate=0):
+    f = (kernel & 0xF) | ((nlog & 0xF) << 4) | ((splitk & 0xFF) << 8) | ((ablate & 0xF) << 20)
     if two_pass:
         f |= FLAG_TWO_PASS
     if no_nt:
@@ -52,6 +52,24 @@ def workspace(device, nbytes):
         ws = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+def _current_workspace(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    return _workspaces.get(key)
+
+
+def workspace_error_flag(device):
+    """1 if a split-K reducer ever gave up waiting for its producers on this stream (synchronises)."""
+    ws = _current_workspace(device)
+    if ws is None:
+        return 0
+    return int(ws[16380:16384].view(torch.int32).item())
+
+
+def workspace_is_clean(device):
+    ws = _current_workspace(device)
+    return True if ws is None else not bool(ws.any().item())
 
 
 def unpack_int4(q):

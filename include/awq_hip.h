@@ -14,9 +14,9 @@
  *   - return value: AWQ_OK (0) or a negative AWQ_ERR_* code; awq_hip_error_string() names it.
  *   - stateless and re-entrant; layout facts asserted by the reference modules are re-checked
  *     (N % 8 == 0, K % group == 0 -- awq/modules/linear/gemm.py:132-133).
- *   - workspaces: *_workspace_bytes() gives the size.  The first AWQ_WS_COUNTER_BYTES of a GEMM
- *     workspace hold split-K arrival counters and MUST be zero before the first call; every call
- *     leaves them zero again.
+ *   - workspaces: *_workspace_bytes() gives the size.  A GEMM workspace (control words + tagged
+ *     split-K granules) MUST be all-zero before the first call; every call leaves it all-zero
+ *     again.  One workspace serves one stream at a time.
  */
 #ifndef AWQ_HIP_H
 #define AWQ_HIP_H
@@ -46,7 +46,7 @@ enum {
     AWQ_ERR_NULL = -6           /* a required pointer is NULL */
 };
 
-#define AWQ_WS_COUNTER_BYTES 16384 /* 4096 int32 split-K tickets at the head of a GEMM workspace */
+#define AWQ_WS_COUNTER_BYTES 16384 /* control words at the head of a GEMM workspace (last int32 = error flag) */
 
 AWQ_EXPORT int awq_hip_abi_version(void);
 AWQ_EXPORT const char* awq_hip_error_string(int code);
@@ -85,10 +85,11 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
 #define AWQ_GEMM_KERNEL_SKINNY 3u /* MFMA 16x16x32 skinny GEMM, M <= 16 per pass */
 #define AWQ_GEMM_KERNEL_TILED 4u  /* LDS-tiled MFMA GEMM with fused dequant, large M */
 #define AWQ_GEMM_FLAG_KERNEL(f) ((f)&0xFu)
-#define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto */
+#define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto; VALU: log2 column lanes (2..4); SKINNY: words per lane (2|4) */
 #define AWQ_GEMM_FLAG_SPLITK(f) (((f) >> 8) & 0xFFu) /* 0 = auto */
 #define AWQ_GEMM_FLAG_TWO_PASS (1u << 16) /* split-K reduce in a second kernel instead of in-launch */
 #define AWQ_GEMM_FLAG_NO_NT (1u << 17)    /* plain (temporal) weight loads */
+#define AWQ_GEMM_FLAG_ABLATE(n) (((n)&0xFu) << 20) /* tuning only: results are WRONG on purpose */
 
 #ifdef __cplusplus
 }

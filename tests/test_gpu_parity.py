@@ -99,6 +99,11 @@ def gemm_variants(ops):
         v[f"valu_n{nlog}_s7_two_pass"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, splitk=7, two_pass=True)
     v["valu_n3_s64"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=3, splitk=64)
     v["valu_n3_plain_loads"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=3, no_nt=True)
+    for wpl in (2, 4):
+        v[f"skinny_w{wpl}"] = ops.gemm_flags(ops.KERNEL_SKINNY, nlog=wpl)
+        v[f"skinny_w{wpl}_s1"] = ops.gemm_flags(ops.KERNEL_SKINNY, nlog=wpl, splitk=1)
+        v[f"skinny_w{wpl}_s5"] = ops.gemm_flags(ops.KERNEL_SKINNY, nlog=wpl, splitk=5)
+    v["skinny_w2_s64_plain_loads"] = ops.gemm_flags(ops.KERNEL_SKINNY, nlog=2, splitk=64, no_nt=True)
     return v
 
 
@@ -127,7 +132,7 @@ def test_gemm_golden(ops, oracle, name):
 @pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (4096, 11008, 128), (11008, 4096, 128),
                                    (4096, 12288, 128), (1024, 8192, 128), (512, 96, 64), (512, 1056, 32),
                                    (256, 40, 128), (2048, 2048, 2048)])
-@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 13, 16])
 def test_gemm_vs_oracle_all_variants(ops, oracle, K, N, g, M):
     if M > 1 and K * N > 4096 * 4096:
         pytest.skip("large shapes are covered at M=1; keeps the oracle time bounded")
@@ -144,6 +149,7 @@ def test_gemm_vs_oracle_all_variants(ops, oracle, K, N, g, M):
         ran += 1
         assert_product_close(y.cpu().numpy().astype(np.float32), y32, f"K{K} N{N} g{g} M{M} {vname}")
     assert ran >= 2
+    assert ops.workspace_error_flag(dx.device) == 0, "split-K collect timed out"
 
 
 def test_gemm_deterministic_and_counters_rearmed(ops):
@@ -151,9 +157,11 @@ def test_gemm_deterministic_and_counters_rearmed(ops):
     counters come back to zero so the next (different-shape) call works."""
     qw, qz, s, x, _ = fullrange_case(4096, 4096, 128, 1, seed=11, realistic=True)
     dq, dz, ds, dx = qw.cuda(), qz.cuda(), s.cuda(), x.cuda()
-    first = ops.gemm_forward(dx, dq, ds, dz)
-    for _ in range(20):
-        assert torch.equal(ops.gemm_forward(dx, dq, ds, dz), first)
+    for flags in (0, ops.gemm_flags(ops.KERNEL_VALU, nlog=3, splitk=32), ops.gemm_flags(ops.KERNEL_SKINNY, nlog=2, splitk=16)):
+        first = ops.gemm_forward(dx, dq, ds, dz, flags=flags)
+        for _ in range(20):
+            assert torch.equal(ops.gemm_forward(dx, dq, ds, dz, flags=flags), first)
+    assert ops.workspace_is_clean(dx.device), "split-K workspace must be all-zero after every call"
     qw2, qz2, s2, x2, _ = fullrange_case(1024, 8192, 128, 2, seed=12, realistic=True)
     a = ops.gemm_forward(x2.cuda(), qw2.cuda(), s2.cuda(), qz2.cuda())
     b = ops.gemm_forward(x2.cuda(), qw2.cuda(), s2.cuda(), qz2.cuda(), flags=ops.gemm_flags(ops.KERNEL_NAIVE))
@@ -194,8 +202,9 @@ def test_module_forward_semantics(ops, oracle):
     assert out2.shape == (3, 64)
     assert torch.equal(out2, out3[0])
     for dt in (torch.float32, torch.bfloat16):  # cast to fp16 and back (gemm.py:256-258,284-285)
-        o = m(x.to(dt))
-        assert o.dtype == dt and torch.equal(o, out2.to(dt))
+        xd = x.to(dt)
+        o = m(xd)
+        assert o.dtype == dt and torch.equal(o, m(xd.half()).to(dt))
     assert m(torch.empty((0, 5, 256), device="cuda", dtype=torch.float16)).shape == (0, 5, 64)
     m.bias = None
     y32n, _ = oracle.linear_gemm(g["x"], g["qweight"], g["qzeros"], g["scales"], 128)

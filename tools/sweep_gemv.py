@@ -53,7 +53,7 @@ def main():
     dev = torch.device("cuda")
     gen = torch.Generator(device=dev).manual_seed(0)
     shapes = [(4096, 4096), (4096, 12288), (4096, 22016), (11008, 4096)]
-    Ms = [1] if a.quick else [1, 2, 4]
+    Ms = [1] if a.quick else [1, 4, 8, 16]
     results = []
     for K, N in shapes:
         per = K * N // 2
@@ -64,11 +64,15 @@ def main():
             ref = ops.gemm_forward(x, sets[0][0], sets[0][2], sets[0][1], flags=ops.gemm_flags(ops.KERNEL_NAIVE)).float()
             by = algorithmic_bytes(K, N, M, 128)
             variants = {}
-            for nlog in (2, 3, 4):
-                for sk in ((0, 1, 4, 8, 16, 32) if M == 1 else (0, 8, 16)):
+            for nlog in ((2, 3, 4) if M <= 4 else ()):
+                for sk in ((0, 4, 8, 16, 32) if M == 1 else (0, 8, 16)):
                     variants[f"valu n{nlog} s{sk}"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, splitk=sk)
                 variants[f"valu n{nlog} s0 2pass"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, two_pass=True)
                 variants[f"valu n{nlog} s0 plain-ld"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, no_nt=True)
+            for wpl in (2, 4):
+                for sk in ((0, 4, 8, 16, 32) if M == 1 else (0, 8, 16)):
+                    variants[f"skinny w{wpl} s{sk}"] = ops.gemm_flags(ops.KERNEL_SKINNY, nlog=wpl, splitk=sk)
+            variants["skinny w2 s0 plain-ld"] = ops.gemm_flags(ops.KERNEL_SKINNY, nlog=2, no_nt=True)
             variants["auto"] = 0
             for name, fl in variants.items():
                 try:
