@@ -31,5 +31,5 @@ int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pa
 int awq_gemv_valu_default_split(int K, int N, int nlog);
 int awq_launch_splitk_reduce(const AwqGemmArgs& a, int splitk);
 // MFMA skinny GEMM, M <= 16; wpl = packed words per lane (2 or 4)
-int awq_launch_gemm_skinny(const AwqGemmArgs& a, int wpl, int splitk, bool nt);
+int awq_launch_gemm_skinny(const AwqGemmArgs& a, int wpl, int splitk, bool nt, void* trace = nullptr);
 int awq_skinny_default_split(int K, int N, int wpl);

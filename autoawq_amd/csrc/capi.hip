@@ -4,6 +4,7 @@
 
 namespace {
 thread_local const char* g_last_kernel = "none";
+void* g_trace = nullptr;  // diagnostics only (awq_hip_set_trace_buffer)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -35,6 +36,8 @@ const char* awq_hip_error_string(int code) {
 }
 
 const char* awq_hip_last_kernel(void) { return g_last_kernel; }
+
+void awq_hip_set_trace_buffer(void* device_buffer) { g_trace = device_buffer; }
 
 int awq_unpack_int4(const int32_t* q, uint8_t* out, int64_t rows, int64_t words, void* stream) {
     if (rows < 0 || words < 0) return AWQ_ERR_BAD_SHAPE;
@@ -100,7 +103,8 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     if (kern == AWQ_GEMM_KERNEL_AUTO) {
         if (!fast_shape) kern = AWQ_GEMM_KERNEL_NAIVE;
         else if (M <= 4) kern = AWQ_GEMM_KERNEL_VALU;
-        else if (M <= 16 && K % 32 == 0 && group_size % 32 == 0) kern = AWQ_GEMM_KERNEL_SKINNY;
+        else if (M <= 16 && K % 32 == 0 && (group_size % 128 == 0 || group_size == 64 || group_size == 32))
+            kern = AWQ_GEMM_KERNEL_SKINNY;
         else kern = AWQ_GEMM_KERNEL_NAIVE;
     }
     switch (kern) {
@@ -121,7 +125,7 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
             // keep the granule slabs inside the workspace the caller gave us
             while (splitk > 1 && (size_t)(splitk - 1) * a.M * a.N * 8 > a.partial_floats * sizeof(float)) --splitk;
             g_last_kernel = wpl == 4 ? "skinny_mfma_w4" : "skinny_mfma_w2";
-            return awq_launch_gemm_skinny(a, wpl, splitk, nt);
+            return awq_launch_gemm_skinny(a, wpl, splitk, nt, (flags & (1u << 24)) ? g_trace : nullptr);
         }
         default:
             return AWQ_ERR_UNSUPPORTED;

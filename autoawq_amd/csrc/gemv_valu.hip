@@ -34,11 +34,6 @@ struct GemvParams {
     int in_launch_reduce;
 };
 
-template <int M>
-struct Chunk {
-    u32x4 q[8];
-};
-
 // ABL (tuning ablations, wrong results on purpose): 1 = no in-launch split-K combine,
 // 2 = no dequant/FMA work (loads kept live), 3 = both.
 template <int M, int NLOG, bool NT, int ABL = 0>
@@ -65,42 +60,60 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
 #pragma unroll
         for (int c = 0; c < 32; ++c) acc[m][c] = 0.f;
 
-    const uint32_t* wcol = p.qweight + (int64_t)c32 * 4;
+    // Buffer loads through wave-uniform descriptors: one 32-bit lane offset + scalar row offsets.
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    const uint32_t row_bytes = (uint32_t)NW * 4u;
+    const rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.qweight), 0, (uint32_t)p.K * row_bytes, 0x00020000);
+    const rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.qzeros), 0, (uint32_t)(p.K / p.g) * row_bytes, 0x00020000);
+    const rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.scales), 0, (uint32_t)(p.K / p.g) * (uint32_t)p.N * 2u, 0x00020000);
+    const uint32_t wvoff = (uint32_t)c32 * 16u;
 
-    auto load_chunk = [&](u32x4(&q)[8], int k0) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) q[r] = ld16<NT>(wcol + (int64_t)(k0 + r) * NW);
+    struct ChunkBuf {
+        u32x4 q[8];
+        u32x4 qz;
+        u32x4 sc[4];
+        u32x4 xv[M];
     };
 
-    auto compute_chunk = [&](const u32x4(&q)[8], int k0) {
+    // A chunk's weights, zeros, scales and activations are all requested together, one chunk
+    // ahead of their use (vmcnt retires in order: a load issued at its point of use would drag
+    // the whole prefetched stream into its wait).
+    auto load_chunk = [&](ChunkBuf& b, int k0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            b.q[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wvoff + (uint32_t)(k0 + r) * row_bytes, 0, NT ? 2 : 0));
+        const uint32_t grp = (uint32_t)(k0 / p.g);
+        b.qz = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(zres, wvoff + grp * row_bytes, 0, 0));
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd)
+            b.sc[wd] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sres, (uint32_t)c32 * 64u + 16u * wd + grp * (uint32_t)p.N * 2u, 0, 0));
+#pragma unroll
+        for (int m = 0; m < M; ++m) b.xv[m] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)m * p.K + k0);
+    };
+
+    auto compute_chunk = [&](const ChunkBuf& b) {
         if constexpr (ABL & 2) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
 #pragma unroll
-                for (int wd = 0; wd < 4; ++wd) acc[0][r * 4 + wd] = __builtin_bit_cast(float, q[r][wd]);
+                for (int wd = 0; wd < 4; ++wd) acc[0][r * 4 + wd] = __builtin_bit_cast(float, b.q[r][wd]);
             return;
         }
-        const int grp = k0 / p.g;
-        const u32x4 qz = *reinterpret_cast<const u32x4*>(p.qzeros + (int64_t)grp * NW + c32 * 4);
         half2_t zm[16], sc[16];
 #pragma unroll
         for (int wd = 0; wd < 4; ++wd) {
-            zm[wd * 4 + 0] = u2h2(awq_pair_magic<0>(qz[wd]));
-            zm[wd * 4 + 1] = u2h2(awq_pair_magic<1>(qz[wd]));
-            zm[wd * 4 + 2] = u2h2(awq_pair_magic<2>(qz[wd]));
-            zm[wd * 4 + 3] = u2h2(awq_pair_magic<3>(qz[wd]));
-            const u32x4 sv = *reinterpret_cast<const u32x4*>(p.scales + (int64_t)grp * p.N + c32 * 32 + wd * 8);
+            zm[wd * 4 + 0] = u2h2(awq_pair_magic<0>(b.qz[wd]));
+            zm[wd * 4 + 1] = u2h2(awq_pair_magic<1>(b.qz[wd]));
+            zm[wd * 4 + 2] = u2h2(awq_pair_magic<2>(b.qz[wd]));
+            zm[wd * 4 + 3] = u2h2(awq_pair_magic<3>(b.qz[wd]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc[wd * 4 + j] = u2h2(sv[j]);
+            for (int j = 0; j < 4; ++j) sc[wd * 4 + j] = u2h2(b.sc[wd][j]);
         }
-        half8_t xv[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) xv[m] = *reinterpret_cast<const half8_t*>(p.x + (int64_t)m * p.K + k0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
 #pragma unroll
             for (int wd = 0; wd < 4; ++wd) {
-                const uint32_t w = q[r][wd];
+                const uint32_t w = b.q[r][wd];
                 half2_t d[4];
                 d[0] = awq_dq_pair<0>(w, zm[wd * 4 + 0], sc[wd * 4 + 0]);
                 d[1] = awq_dq_pair<1>(w, zm[wd * 4 + 1], sc[wd * 4 + 1]);
@@ -108,7 +121,8 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
                 d[3] = awq_dq_pair<3>(w, zm[wd * 4 + 3], sc[wd * 4 + 3]);
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const float xk = (float)xv[m][r];
+                    const half2_t xp = u2h2(b.xv[m][r >> 1]);
+                    const float xk = (float)xp[r & 1];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         acc[m][wd * 8 + 2 * j] = __builtin_fmaf((float)d[j][0], xk, acc[m][wd * 8 + 2 * j]);
@@ -121,16 +135,16 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
 
     if (active) {
         int k0 = kbeg + kl * 8;
-        u32x4 qa[8], qb[8];
-        if (k0 < kend) load_chunk(qa, k0);
+        ChunkBuf ba, bb;
+        if (k0 < kend) load_chunk(ba, k0);
         while (k0 < kend) {
             int k1 = k0 + STEP;
-            if (k1 < kend) load_chunk(qb, k1);
-            compute_chunk(qa, k0);
+            if (k1 < kend) load_chunk(bb, k1);
+            compute_chunk(ba);
             if (k1 >= kend) break;
             k0 = k1 + STEP;
-            if (k0 < kend) load_chunk(qa, k0);
-            compute_chunk(qb, k1);
+            if (k0 < kend) load_chunk(ba, k0);
+            compute_chunk(bb);
         }
     }
 

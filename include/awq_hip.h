@@ -54,6 +54,10 @@ AWQ_EXPORT const char* awq_hip_error_string(int code);
  * (diagnostics / tests; static string). */
 AWQ_EXPORT const char* awq_hip_last_kernel(void);
 
+/* Diagnostics: device buffer that kernels launched with flag bit 24 fill with per-wave phase
+ * timestamps (8 x uint64 per wave, 100 MHz).  Not part of the compute path. */
+AWQ_EXPORT void awq_hip_set_trace_buffer(void* device_buffer);
+
 /* ---- GEMM layout: qweight [K, N/8] i32, qzeros [K/g, N/8] i32, scales [K/g, N] f16 ------- */
 
 /* Integer unpack only: out[r, 8c+j] = nibble of q[r, c] holding logical column 8c+j (0..15).

@@ -14,7 +14,7 @@ from conftest import ROOT, golden
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "awq_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(awq_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(awq_[a-z0-9_]+)\s*\(", src)))  # every declared function
 
 
 def test_header_declares_and_library_exports_same_symbols():
