@@ -21,7 +21,6 @@ SIGNATURES = {
     "awq_hip_abi_version": (c_int, []),
     "awq_hip_error_string": (ctypes.c_char_p, [c_int]),
     "awq_hip_last_kernel": (ctypes.c_char_p, []),
-    "awq_hip_set_trace_buffer": (None, [c_void_p]),
     "awq_unpack_int4": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "awq_dequantize_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "awq_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),

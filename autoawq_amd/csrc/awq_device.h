@@ -26,16 +26,25 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 AWQ_DEV half2_t u2h2(uint32_t v) { return __builtin_bit_cast(half2_t, v); }
 AWQ_DEV uint32_t h22u(half2_t v) { return __builtin_bit_cast(uint32_t, v); }
 
-// half2(1024 + column 2J, 1024 + column 2J+1) of one packed word
-// (a & mask) | magic in ONE VALU op.  gfx950 VOP3 takes no literals and hipcc splits the
-// expression into v_and_b32 + v_or_b32 with two literals; pinning the mask in an SGPR and the
-// magic in a VGPR gives v_and_or_b32 (constant-bus limit 1).
+// (a & mask) | magic in ONE VALU op.  gfx950 VOP3 takes no literals, so with literal constants
+// hipcc emits v_and_b32 + v_or_b32.  Passing the constants through an empty asm makes them opaque
+// register values (mask in an SGPR, magic in a VGPR: constant-bus limit 1) and instruction
+// selection then picks v_and_or_b32 itself.  The operation is NOT written in inline asm: hipcc
+// pads no hazards for an asm statement's outputs (VALU write -> MFMA source needs wait states,
+// cdna_hip_programming.md 5.7), and a decoded word feeds an MFMA right away.
+AWQ_DEV uint32_t opaque_sgpr(uint32_t c) {
+    asm("" : "+s"(c));
+    return c;
+}
+AWQ_DEV uint32_t opaque_vgpr(uint32_t c) {
+    asm("" : "+v"(c));
+    return c;
+}
 AWQ_DEV uint32_t and_or(uint32_t a, uint32_t mask, uint32_t magic) {
-    uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(magic));
-    return r;
+    return (a & opaque_sgpr(mask)) | opaque_vgpr(magic);
 }
 
+// half2(1024 + column 2J, 1024 + column 2J+1) of one packed word
 template <int J>
 AWQ_DEV uint32_t awq_pair_magic(uint32_t q) {
     if constexpr (J == 0)

@@ -19,17 +19,18 @@ struct AwqGemmArgs {
     const uint16_t* bias;    // [N] or null
     uint16_t* y;             // [M, N]
     int M, K, N, g;
-    int* counters;   // control words (last one = error flag); zero on entry, zero on exit
-    float* partial;  // split-K slabs: tagged 8-byte granules [S-1, M, N] (or fp32 [S, M, N] in two-pass mode)
+    int* counters;   // split-K ticket words, one per column tile: zero on entry, zero on exit
+    float* partial;  // split-K fp32 slabs (scratch: no invariant between calls)
     size_t partial_floats;
     hipStream_t stream;
 };
 
 int awq_launch_gemm_naive(const AwqGemmArgs& a);
-// nlog: log2 of column-lanes per wave (2..4), splitk >= 1, two_pass: separate reduce kernel
-int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pass, bool nt, int ablate = 0);
+// Reference-order-numerics GEMV (M <= 4).  nlog: log2 of column-lanes per wave (2..4), splitk >= 1.
+int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool nt);
 int awq_gemv_valu_default_split(int K, int N, int nlog);
 int awq_launch_splitk_reduce(const AwqGemmArgs& a, int splitk);
-// MFMA skinny GEMM, M <= 16; wpl = packed words per lane (2 or 4)
-int awq_launch_gemm_skinny(const AwqGemmArgs& a, int wpl, int splitk, bool nt, void* trace = nullptr);
-int awq_skinny_default_split(int K, int N, int wpl);
+// MFMA decode GEMV / skinny GEMM, M <= 16.  wpl: packed words per lane (2|4, 0 = auto);
+// nwaves: waves per block (4|8, 0 = auto); splitk 0 = auto.
+bool awq_gemv_mfma_supports(int M, int K, int N, int g, int wpl);
+int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int splitk, bool two_pass, bool nt);

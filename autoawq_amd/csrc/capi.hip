@@ -4,7 +4,6 @@
 
 namespace {
 thread_local const char* g_last_kernel = "none";
-void* g_trace = nullptr;  // diagnostics only (awq_hip_set_trace_buffer)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -37,8 +36,6 @@ const char* awq_hip_error_string(int code) {
 
 const char* awq_hip_last_kernel(void) { return g_last_kernel; }
 
-void awq_hip_set_trace_buffer(void* device_buffer) { g_trace = device_buffer; }
-
 int awq_unpack_int4(const int32_t* q, uint8_t* out, int64_t rows, int64_t words, void* stream) {
     if (rows < 0 || words < 0) return AWQ_ERR_BAD_SHAPE;
     if (rows * words == 0) return AWQ_OK;
@@ -59,13 +56,12 @@ int awq_dequantize_weights(const int32_t* qweight, const uint16_t* scales, const
 
 size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     (void)group_size;
+    (void)K;
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    // control words + split-K slabs: up to 64 slabs of [min(M,16), N] 8-byte granules, capped at
-    // 64 MiB (the launchers lower the split to what fits).
-    int64_t s = (K + 31) / 32;
-    if (s > 64) s = 64;
+    // ticket words + split-K slabs: up to 64 slabs of [min(M,16), N rounded up to a 512-column
+    // tile] fp32, capped at 64 MiB (the launchers lower the split to what fits).
     int64_t m = M < 16 ? M : 16;
-    size_t slabs = (size_t)(s * m * N) * 8;
+    size_t slabs = (size_t)(64 * m * (N + 512)) * 4;
     if (slabs > ((size_t)64 << 20)) slabs = (size_t)64 << 20;
     return (size_t)AWQ_WS_COUNTER_BYTES + slabs;
 }
@@ -96,15 +92,13 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     unsigned kern = AWQ_GEMM_FLAG_KERNEL(flags);
     int nlog = (int)AWQ_GEMM_FLAG_NLOG(flags);
     int splitk = (int)AWQ_GEMM_FLAG_SPLITK(flags);
+    const int waves = (int)AWQ_GEMM_FLAG_WAVES(flags);
     const bool two_pass = (flags & AWQ_GEMM_FLAG_TWO_PASS) != 0;
     const bool nt = (flags & AWQ_GEMM_FLAG_NO_NT) == 0;
-    const bool fast_shape = (N % 32 == 0) && (group_size % 8 == 0) && (K % 8 == 0);
+    if ((int64_t)K * N / 2 >= ((int64_t)1 << 31)) return AWQ_ERR_UNSUPPORTED;  // 32-bit buffer offsets
 
     if (kern == AWQ_GEMM_KERNEL_AUTO) {
-        if (!fast_shape) kern = AWQ_GEMM_KERNEL_NAIVE;
-        else if (M <= 4) kern = AWQ_GEMM_KERNEL_VALU;
-        else if (M <= 16 && K % 32 == 0 && (group_size % 128 == 0 || group_size == 64 || group_size == 32))
-            kern = AWQ_GEMM_KERNEL_SKINNY;
+        if (M <= 16 && awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2)) kern = AWQ_GEMM_KERNEL_MFMA_GEMV;
         else kern = AWQ_GEMM_KERNEL_NAIVE;
     }
     switch (kern) {
@@ -114,18 +108,14 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
         case AWQ_GEMM_KERNEL_VALU: {
             if (nlog == 0) nlog = 3;
             if (splitk == 0) splitk = awq_gemv_valu_default_split(a.K, a.N, nlog);
-            while (splitk > 1 && (size_t)splitk * a.M * a.N * 8 > a.partial_floats * sizeof(float)) --splitk;
+            while (splitk > 1 && (size_t)splitk * a.M * a.N * 4 > a.partial_floats * sizeof(float)) --splitk;
             g_last_kernel = "gemv_valu";
-            return awq_launch_gemv_valu(a, nlog, splitk, two_pass, nt, (int)((flags >> 20) & 0xFu));
+            return awq_launch_gemv_valu(a, nlog, splitk, nt);
         }
-        case AWQ_GEMM_KERNEL_SKINNY: {
-            const int wpl = (nlog == 4) ? 4 : 2;
+        case AWQ_GEMM_KERNEL_MFMA_GEMV: {
             if (M > 16) return AWQ_ERR_UNSUPPORTED;
-            if (splitk == 0) splitk = awq_skinny_default_split(a.K, a.N, wpl);
-            // keep the granule slabs inside the workspace the caller gave us
-            while (splitk > 1 && (size_t)(splitk - 1) * a.M * a.N * 8 > a.partial_floats * sizeof(float)) --splitk;
-            g_last_kernel = wpl == 4 ? "skinny_mfma_w4" : "skinny_mfma_w2";
-            return awq_launch_gemm_skinny(a, wpl, splitk, nt, (flags & (1u << 24)) ? g_trace : nullptr);
+            g_last_kernel = "gemv_mfma";
+            return awq_launch_gemv_mfma(a, nlog, waves, splitk, two_pass, nt);
         }
         default:
             return AWQ_ERR_UNSUPPORTED;

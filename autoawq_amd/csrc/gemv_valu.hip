@@ -12,10 +12,10 @@
 //     g % 8 == 0), prefetching the next chunk's weights before it computes the current one;
 //   * weights are dequantised to the exact fp16 the reference materialises ((w - z) * s, see
 //     awq_device.h) and accumulated in fp32 with mixed-precision FMAs;
-//   * block partials are folded through LDS; K is split over gridDim.y and the slabs are
-//     combined in-launch in FIXED slab order (deterministic) through tagged write-through
-//     granules, no fences and no tickets (awq_combine.h).
-#include "awq_combine.h"
+//   * block partials are folded through LDS; K is split over gridDim.y, slabs are plain fp32
+//     stores and a second kernel sums them in FIXED slab order (deterministic).
+// This is the reference-order-numerics variant (weights rounded to fp16 exactly as
+// dequantize_gemm does); the default decode kernel is gemv_mfma.hip.
 #include "awq_device.h"
 #include "awq_internal.h"
 
@@ -29,14 +29,10 @@ struct GemvParams {
     const half_t* bias;
     half_t* y;
     float* partial;
-    int* err;
     int K, N, g, rows_per_block;
-    int in_launch_reduce;
 };
 
-// ABL (tuning ablations, wrong results on purpose): 1 = no in-launch split-K combine,
-// 2 = no dequant/FMA work (loads kept live), 3 = both.
-template <int M, int NLOG, bool NT, int ABL = 0>
+template <int M, int NLOG, bool NT>
 __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
     constexpr int NL = 1 << NLOG;    // column-lanes per wave
     constexpr int KLW = 64 / NL;     // K-lanes per wave
@@ -92,13 +88,6 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
     };
 
     auto compute_chunk = [&](const ChunkBuf& b) {
-        if constexpr (ABL & 2) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-#pragma unroll
-                for (int wd = 0; wd < 4; ++wd) acc[0][r * 4 + wd] = __builtin_bit_cast(float, b.q[r][wd]);
-            return;
-        }
         half2_t zm[16], sc[16];
 #pragma unroll
         for (int wd = 0; wd < 4; ++wd) {
@@ -148,11 +137,8 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
         }
     }
 
-    // ---- fold the KLB K-lanes of the block through LDS, one activation row at a time; then
-    // split-K: producers publish tagged granules, the last-slab block collects (awq_combine.h)
+    // ---- fold the KLB K-lanes of the block through LDS, one activation row at a time
     const int S = gridDim.y;
-    const bool reducer = (S > 1) && (blockIdx.y == S - 1);
-    const int64_t slab = (int64_t)M * p.N;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         if (m) __syncthreads();
@@ -171,25 +157,9 @@ __global__ __launch_bounds__(256) void awq_gemv_valu_kernel(GemvParams p) {
             for (int k = 0; k < KLB; ++k) s += red[k * CT + off];
             const int col = blockIdx.x * CT + c;
             if (col >= p.N) continue;
-            if (S > 1) {
-                if (!p.in_launch_reduce) {  // two-pass mode: plain fp32 slabs, separate reduce kernel
-                    p.partial[((int64_t)blockIdx.y * M + m) * p.N + col] = s;
-                    continue;
-                }
-                awq_granule_t* g = reinterpret_cast<awq_granule_t*>(p.partial) + (int64_t)m * p.N + col;
-                if (!reducer) {
-                    if constexpr (!(ABL & 1)) awq_publish(g + (int64_t)blockIdx.y * slab, s);
-                    continue;
-                }
-                if constexpr (!(ABL & 1)) {
-                    float others;
-                    if (!awq_collect<64>(g, slab, S - 1, others)) {
-                        *p.err = 1;
-                        others = 0.f;
-                    }
-                    awq_clear(g, slab, S - 1);
-                    s = others + s;
-                }
+            if (S > 1) {  // plain fp32 slabs [S][M][N]; awq_splitk_reduce_kernel sums them in slab order
+                p.partial[((int64_t)blockIdx.y * M + m) * p.N + col] = s;
+                continue;
             }
             if (p.bias) s += (float)p.bias[col];
             p.y[(int64_t)m * p.N + col] = (half_t)s;
@@ -204,7 +174,14 @@ __global__ __launch_bounds__(256) void awq_splitk_reduce_kernel(const float* __r
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= MN) return;
     float s = 0.f;
-    for (int sp = 0; sp < S; ++sp) s += partial[(int64_t)sp * MN + i];
+    for (int sp0 = 0; sp0 < S; sp0 += 8) {  // 8 independent loads in flight, summed in slab order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(sp0 + u < S ? sp0 + u : S - 1) * MN + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (sp0 + u < S) s += v[u];
+    }
     if (bias) s += (float)bias[i % N];
     y[i] = (half_t)s;
 }
@@ -235,7 +212,7 @@ __global__ __launch_bounds__(256) void awq_gemm_naive_kernel(const uint32_t* __r
 
 template <int M, int NLOG, bool NT>
 void launch_valu(const GemvParams& p, dim3 grid, hipStream_t stream) {
-    hipLaunchKernelGGL((awq_gemv_valu_kernel<M, NLOG, NT, 0>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((awq_gemv_valu_kernel<M, NLOG, NT>), grid, dim3(256), 0, stream, p);
 }
 
 template <int M>
@@ -265,7 +242,7 @@ int awq_gemv_valu_default_split(int K, int N, int nlog) {
     return s;
 }
 
-int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pass, bool nt, int ablate) {
+int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool nt) {
     if (a.M < 1 || a.M > 4 || a.N % 32 || a.g % 8 || a.K % 8) return AWQ_ERR_UNSUPPORTED;
     if (nlog < 2 || nlog > 4) return AWQ_ERR_UNSUPPORTED;
     const int CT = 32 << nlog;
@@ -278,9 +255,8 @@ int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pa
     const int ppb = (passes + splitk - 1) / splitk;  // passes per block
     splitk = (passes + ppb - 1) / ppb;
     if (splitk > 1) {
-        const size_t need = two_pass ? (size_t)splitk * a.M * a.N * sizeof(float)
-                                     : (size_t)(splitk - 1) * a.M * a.N * sizeof(awq_granule_t);
-        if (!a.partial || a.partial_floats * sizeof(float) < need || !a.counters) return AWQ_ERR_WORKSPACE;
+        const size_t need = (size_t)splitk * a.M * a.N * sizeof(float);
+        if (!a.partial || a.partial_floats * sizeof(float) < need) return AWQ_ERR_WORKSPACE;
     }
     GemvParams p;
     p.qweight = reinterpret_cast<const uint32_t*>(a.qweight);
@@ -290,17 +266,9 @@ int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pa
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.partial = a.partial;
-    p.err = a.counters ? a.counters + (AWQ_WS_COUNTER_BYTES / 4 - 1) : nullptr;
     p.K = a.K; p.N = a.N; p.g = a.g;
     p.rows_per_block = ppb * step;
-    p.in_launch_reduce = two_pass ? 0 : 1;
     dim3 grid(tiles, splitk);
-    if (ablate && a.M == 1 && nlog == 3 && nt) {
-        if (ablate == 1) hipLaunchKernelGGL((awq_gemv_valu_kernel<1, 3, true, 1>), grid, dim3(256), 0, a.stream, p);
-        else if (ablate == 2) hipLaunchKernelGGL((awq_gemv_valu_kernel<1, 3, true, 2>), grid, dim3(256), 0, a.stream, p);
-        else hipLaunchKernelGGL((awq_gemv_valu_kernel<1, 3, true, 3>), grid, dim3(256), 0, a.stream, p);
-        return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
-    }
     switch (a.M) {
         case 1: dispatch_valu<1>(p, grid, nlog, nt, a.stream); break;
         case 2: dispatch_valu<2>(p, grid, nlog, nt, a.stream); break;
@@ -308,7 +276,7 @@ int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool two_pa
         default: dispatch_valu<4>(p, grid, nlog, nt, a.stream); break;
     }
     if (hipGetLastError() != hipSuccess) return AWQ_ERR_LAUNCH;
-    if (splitk > 1 && two_pass) return awq_launch_splitk_reduce(a, splitk);
+    if (splitk > 1) return awq_launch_splitk_reduce(a, splitk);
     return AWQ_OK;
 }
 

@@ -8,13 +8,14 @@ import torch
 from . import _lib
 
 # kernel-selection flags (mirror include/awq_hip.h)
-KERNEL_AUTO, KERNEL_NAIVE, KERNEL_VALU, KERNEL_SKINNY, KERNEL_TILED = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_NAIVE, KERNEL_VALU, KERNEL_MFMA_GEMV, KERNEL_TILED = 0, 1, 2, 3, 4
 FLAG_TWO_PASS = 1 << 16
 FLAG_NO_NT = 1 << 17
 
 
-def gemm_flags(kernel=0, nlog=0, splitk=0, two_pass=False, no_nt=False, ablate=0):
-    f = (kernel & 0xF) | ((nlog & 0xF) << 4) | ((splitk & 0xFF) << 8) | ((ablate & 0xF) << 20)
+def gemm_flags(kernel=0, nlog=0, splitk=0, two_pass=False, no_nt=False, waves=0):
+    """nlog: VALU -> log2 column lanes (2..4); MFMA_GEMV -> packed words per lane (2|4)."""
+    f = (kernel & 0xF) | ((nlog & 0xF) << 4) | ((splitk & 0xFF) << 8) | ((waves & 0xF) << 24)
     if two_pass:
         f |= FLAG_TWO_PASS
     if no_nt:
@@ -59,17 +60,10 @@ def _current_workspace(device):
     return _workspaces.get(key)
 
 
-def workspace_error_flag(device):
-    """1 if a split-K reducer ever gave up waiting for its producers on this stream (synchronises)."""
-    ws = _current_workspace(device)
-    if ws is None:
-        return 0
-    return int(ws[16380:16384].view(torch.int32).item())
-
-
 def workspace_is_clean(device):
+    """True when every split-K ticket word is back to zero (the invariant each call must restore)."""
     ws = _current_workspace(device)
-    return True if ws is None else not bool(ws.any().item())
+    return True if ws is None else not bool(ws[:16384].any().item())
 
 
 def unpack_int4(q):

@@ -14,9 +14,9 @@
  *   - return value: AWQ_OK (0) or a negative AWQ_ERR_* code; awq_hip_error_string() names it.
  *   - stateless and re-entrant; layout facts asserted by the reference modules are re-checked
  *     (N % 8 == 0, K % group == 0 -- awq/modules/linear/gemm.py:132-133).
- *   - workspaces: *_workspace_bytes() gives the size.  A GEMM workspace (control words + tagged
- *     split-K granules) MUST be all-zero before the first call; every call leaves it all-zero
- *     again.  One workspace serves one stream at a time.
+ *   - workspaces: *_workspace_bytes() gives the size.  The first AWQ_WS_COUNTER_BYTES of a GEMM
+ *     workspace hold split-K ticket words: they MUST be zero before the first call and every
+ *     call leaves them zero again; the rest is scratch.  One workspace serves one stream at a time.
  */
 #ifndef AWQ_HIP_H
 #define AWQ_HIP_H
@@ -46,17 +46,13 @@ enum {
     AWQ_ERR_NULL = -6           /* a required pointer is NULL */
 };
 
-#define AWQ_WS_COUNTER_BYTES 16384 /* control words at the head of a GEMM workspace (last int32 = error flag) */
+#define AWQ_WS_COUNTER_BYTES 16384 /* split-K ticket words at the head of a GEMM workspace */
 
 AWQ_EXPORT int awq_hip_abi_version(void);
 AWQ_EXPORT const char* awq_hip_error_string(int code);
 /* Name of the kernel variant the last awq_gemm_forward() call on this thread dispatched to
  * (diagnostics / tests; static string). */
 AWQ_EXPORT const char* awq_hip_last_kernel(void);
-
-/* Diagnostics: device buffer that kernels launched with flag bit 24 fill with per-wave phase
- * timestamps (8 x uint64 per wave, 100 MHz).  Not part of the compute path. */
-AWQ_EXPORT void awq_hip_set_trace_buffer(void* device_buffer);
 
 /* ---- GEMM layout: qweight [K, N/8] i32, qzeros [K/g, N/8] i32, scales [K/g, N] f16 ------- */
 
@@ -82,18 +78,18 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
                      int64_t N, int64_t group_size, void* workspace, size_t workspace_bytes,
                      uint32_t flags, void* stream);
 
-/* flags for awq_gemm_forward: bits 0-3 kernel family, bits 4-7 column-lane log2, bits 8-15 split-K */
+/* flags for awq_gemm_forward: bits 0-3 kernel family, bits 4-7 lane geometry, bits 8-15 split-K */
 #define AWQ_GEMM_KERNEL_AUTO 0u
-#define AWQ_GEMM_KERNEL_NAIVE 1u  /* one thread per output, reference-order loop (checker) */
-#define AWQ_GEMM_KERNEL_VALU 2u   /* wave64 streaming GEMV, fp16 dequant + fp32 FMA, M <= 4 */
-#define AWQ_GEMM_KERNEL_SKINNY 3u /* MFMA 16x16x32 skinny GEMM, M <= 16 per pass */
-#define AWQ_GEMM_KERNEL_TILED 4u  /* LDS-tiled MFMA GEMM with fused dequant, large M */
+#define AWQ_GEMM_KERNEL_NAIVE 1u     /* one thread per output, reference-order loop (checker / odd shapes) */
+#define AWQ_GEMM_KERNEL_VALU 2u      /* wave64 VALU GEMV, reference-order fp16 dequant + fp32 FMA, M <= 4 */
+#define AWQ_GEMM_KERNEL_MFMA_GEMV 3u /* MFMA 16x16x32 streaming GEMV / skinny GEMM, M <= 16 */
+#define AWQ_GEMM_KERNEL_TILED 4u     /* LDS-tiled MFMA GEMM with fused dequant, large M */
 #define AWQ_GEMM_FLAG_KERNEL(f) ((f)&0xFu)
-#define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto; VALU: log2 column lanes (2..4); SKINNY: words per lane (2|4) */
+#define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto; VALU: log2 column lanes (2..4); MFMA_GEMV: words per lane (2|4) */
 #define AWQ_GEMM_FLAG_SPLITK(f) (((f) >> 8) & 0xFFu) /* 0 = auto */
-#define AWQ_GEMM_FLAG_TWO_PASS (1u << 16) /* split-K reduce in a second kernel instead of in-launch */
+#define AWQ_GEMM_FLAG_TWO_PASS (1u << 16) /* MFMA_GEMV: split-K reduce in a second kernel instead of in-launch */
 #define AWQ_GEMM_FLAG_NO_NT (1u << 17)    /* plain (temporal) weight loads */
-#define AWQ_GEMM_FLAG_ABLATE(n) (((n)&0xFu) << 20) /* tuning only: results are WRONG on purpose */
+#define AWQ_GEMM_FLAG_WAVES(f) (((f) >> 24) & 0xFu) /* MFMA_GEMV: waves per block (4|8), 0 = auto */
 
 #ifdef __cplusplus
 }

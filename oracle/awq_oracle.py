@@ -132,6 +132,35 @@ def linear_gemm(x, qweight, qzeros, scales, g, bias=None):
     return y32, y16
 
 
+def linear_gemm_exact(x, qweight, qzeros, scales, g, bias=None, chunk=2048):
+    """Exact-arithmetic product (float64): y = x @ ((w - z) * s) with NO fp16 rounding of the
+    dequantised weight.  The reference rounds W to fp16 first (packing_utils.py:98-100); a kernel
+    that applies the scale after the integer dot product lands between the two.  Checker only."""
+    x = _c(x, np.float16).astype(np.float64)
+    w = unpack_gemm(qweight).astype(np.int16)
+    z = unpack_gemm(qzeros).astype(np.int16)
+    sc = _c(scales, np.float16).astype(np.float32)
+    K, N = w.shape
+    y = np.empty((x.shape[0], N), np.float64)
+    for n0 in range(0, N, chunk):
+        n1 = min(N, n0 + chunk)
+        d = (w[:, n0:n1] - np.repeat(z[:, n0:n1], g, axis=0)).astype(np.float32)
+        W = d * np.repeat(sc[:, n0:n1], g, axis=0)  # exact in fp32: 5-bit x 11-bit significands
+        y[:, n0:n1] = x @ W.astype(np.float64)
+    if bias is not None:
+        y += _c(bias, np.float16).astype(np.float64)[None, :]
+    return y
+
+
+def weight_rounding_sigma(x, W):
+    """Std-dev bound of the product noise caused by the reference's own fp16 rounding of W:
+    each W[k,n] carries an error <= ulp/2, ulp <= 2^-10 |W| (uniform: sigma = ulp/sqrt(12)), so
+    sigma_y[m,n] <= 2^-10/sqrt(12) * sqrt(sum_k x[m,k]^2 W[k,n]^2)."""
+    x2 = _c(x, np.float16).astype(np.float64) ** 2
+    W2 = np.asarray(W, np.float32).astype(np.float64) ** 2
+    return (2.0 ** -10 / np.sqrt(12.0)) * np.sqrt(x2 @ W2)
+
+
 def silu_and_mul(gate_up):
     gate_up = _c(gate_up, np.float16)
     d = gate_up.shape[-1] // 2

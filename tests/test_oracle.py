@@ -129,3 +129,26 @@ def test_silu_and_mul(oracle):
     g32, u32 = gu[..., :32].astype(np.float32), gu[..., 32:].astype(np.float32)
     want = (g32 / (1 + np.exp(-g32)) * u32).astype(np.float16)
     assert np.abs(out.astype(np.float32) - want.astype(np.float32)).max() <= 2e-3
+
+
+def test_exact_product_and_weight_rounding_sigma(oracle):
+    """linear_gemm_exact (no fp16 rounding of W) and the fp16-W oracle differ by the reference's own
+    weight-rounding noise, bounded by weight_rounding_sigma (used by the GPU parity tests)."""
+    g = golden("fullrange_K256_N64_g128")
+    y32, _ = oracle.linear_gemm(g["x"], g["qweight"], g["qzeros"], g["scales"], 128, g["bias"])
+    yex = oracle.linear_gemm_exact(g["x"], g["qweight"], g["qzeros"], g["scales"], 128, g["bias"])
+    sig = oracle.weight_rounding_sigma(g["x"], g["W"])
+    assert yex.shape == y32.shape and sig.shape == y32.shape
+    d = np.abs(yex - y32.astype(np.float64))
+    assert (d <= 6 * sig + 1e-6 * np.abs(yex) + 1e-9).all()
+    assert d.max() > 0  # the two oracles are genuinely different arithmetic
+    # with power-of-two scales and small integers W is exactly representable: both oracles agree
+    K, N = 128, 16
+    rng = np.random.default_rng(0)
+    qw = rng.integers(-2**31, 2**31 - 1, (K, N // 8), dtype=np.int64).astype(np.int32)
+    qz = rng.integers(-2**31, 2**31 - 1, (1, N // 8), dtype=np.int64).astype(np.int32)
+    s = np.full((1, N), 0.5, np.float16)
+    x = rng.integers(-4, 5, (2, K)).astype(np.float16)
+    a, _ = oracle.linear_gemm(x, qw, qz, s, 128)
+    b = oracle.linear_gemm_exact(x, qw, qz, s, 128)
+    assert np.array_equal(a.astype(np.float64), b)

@@ -48,6 +48,7 @@ def time_variant(sets, x, flags, reps=6):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--valu", action="store_true")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep_gemv.json"))
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -64,15 +65,17 @@ def main():
             ref = ops.gemm_forward(x, sets[0][0], sets[0][2], sets[0][1], flags=ops.gemm_flags(ops.KERNEL_NAIVE)).float()
             by = algorithmic_bytes(K, N, M, 128)
             variants = {}
-            for nlog in ((2, 3, 4) if M <= 4 else ()):
-                for sk in ((0, 4, 8, 16, 32) if M == 1 else (0, 8, 16)):
-                    variants[f"valu n{nlog} s{sk}"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, splitk=sk)
-                variants[f"valu n{nlog} s0 2pass"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, two_pass=True)
-                variants[f"valu n{nlog} s0 plain-ld"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, no_nt=True)
+            if a.valu and M <= 4:
+                for nlog in (2, 3):
+                    for sk in (0, 8, 16):
+                        variants[f"valu n{nlog} s{sk}"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, splitk=sk)
             for wpl in (2, 4):
-                for sk in ((0, 4, 8, 16, 32) if M == 1 else (0, 8, 16)):
-                    variants[f"skinny w{wpl} s{sk}"] = ops.gemm_flags(ops.KERNEL_SKINNY, nlog=wpl, splitk=sk)
-            variants["skinny w2 s0 plain-ld"] = ops.gemm_flags(ops.KERNEL_SKINNY, nlog=2, no_nt=True)
+                for wv in (2, 4, 8):
+                    for sk in ((0, 2, 4, 8, 16, 32) if M == 1 else (0, 8)):
+                        variants[f"mfma w{wpl} v{wv} s{sk}"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=sk, waves=wv)
+                variants[f"mfma w{wpl} v4 s0 2pass"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, two_pass=True)
+                variants[f"mfma w{wpl} v4 s1"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=1)
+            variants["mfma w2 v4 s0 plain-ld"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, no_nt=True)
             variants["auto"] = 0
             for name, fl in variants.items():
                 try:
