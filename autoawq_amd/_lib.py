@@ -24,6 +24,7 @@ SIGNATURES = {
     "awq_unpack_int4": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "awq_dequantize_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "awq_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "awq_gemm_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
     "awq_gemm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_void_p, c_size_t, c_uint32, c_void_p]),
 }

@@ -19,8 +19,10 @@ struct AwqGemmArgs {
     const uint16_t* bias;    // [N] or null
     uint16_t* y;             // [M, N]
     int M, K, N, g;
-    int* counters;   // split-K ticket words, one per column tile: zero on entry, zero on exit
-    float* partial;  // split-K fp32 slabs (scratch: no invariant between calls)
+    int* counters;   // control words (word 0 = error flag), zero on entry
+    float* exchange;  // in-launch split-K exchange region: all-ones sentinel on entry AND on exit
+    size_t exchange_bytes;
+    float* partial;  // scratch fp32 slabs for the two-pass reducers (no invariant between calls)
     size_t partial_floats;
     hipStream_t stream;
 };
@@ -30,7 +32,7 @@ int awq_launch_gemm_naive(const AwqGemmArgs& a);
 int awq_launch_gemv_valu(const AwqGemmArgs& a, int nlog, int splitk, bool nt);
 int awq_gemv_valu_default_split(int K, int N, int nlog);
 int awq_launch_splitk_reduce(const AwqGemmArgs& a, int splitk);
-// MFMA decode GEMV / skinny GEMM, M <= 16.  wpl: packed words per lane (2|4, 0 = auto);
-// nwaves: waves per block (4|8, 0 = auto); splitk 0 = auto.
+// MFMA decode GEMV / skinny GEMM, M <= 16.  wpl: packed words per lane (2|4); nwaves: waves per
+// block (2|4|8); unit: 16-row sets per wave iteration (2|4|8); splitk: K slices.  0 = auto each.
 bool awq_gemv_mfma_supports(int M, int K, int N, int g, int wpl);
-int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int splitk, bool two_pass, bool nt);
+int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, int splitk, bool two_pass);

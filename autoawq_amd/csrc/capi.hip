@@ -54,16 +54,31 @@ int awq_dequantize_weights(const int32_t* qweight, const uint16_t* scales, const
     return awq_launch_dequant(qweight, scales, qzeros, out, K, N, group_size, static_cast<hipStream_t>(stream));
 }
 
+namespace {
+// workspace = [control AWQ_WS_COUNTER_BYTES][exchange region E][scratch region E]
+size_t region_bytes(int64_t M, int64_t N) {
+    const int64_t m = M < 16 ? M : 16;
+    size_t e = (size_t)(64 * m * (N + 512)) * 4;  // up to 64 slabs of [min(M,16), N rounded up to a tile]
+    if (e > ((size_t)32 << 20)) e = (size_t)32 << 20;  // the launchers lower the split to what fits
+    return (e + 255) & ~(size_t)255;
+}
+}  // namespace
+
 size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     (void)group_size;
-    (void)K;
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    // ticket words + split-K slabs: up to 64 slabs of [min(M,16), N rounded up to a 512-column
-    // tile] fp32, capped at 64 MiB (the launchers lower the split to what fits).
-    int64_t m = M < 16 ? M : 16;
-    size_t slabs = (size_t)(64 * m * (N + 512)) * 4;
-    if (slabs > ((size_t)64 << 20)) slabs = (size_t)64 << 20;
-    return (size_t)AWQ_WS_COUNTER_BYTES + slabs;
+    return (size_t)AWQ_WS_COUNTER_BYTES + 2 * region_bytes(M, N);
+}
+
+int awq_gemm_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace) return AWQ_ERR_NULL;
+    if (workspace_bytes < AWQ_WS_COUNTER_BYTES) return AWQ_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(workspace, 0, AWQ_WS_COUNTER_BYTES, st) != hipSuccess) return AWQ_ERR_LAUNCH;
+    if (workspace_bytes > AWQ_WS_COUNTER_BYTES &&
+        hipMemsetAsync(static_cast<char*>(workspace) + AWQ_WS_COUNTER_BYTES, 0xFF, workspace_bytes - AWQ_WS_COUNTER_BYTES, st) != hipSuccess)
+        return AWQ_ERR_LAUNCH;
+    return AWQ_OK;
 }
 
 int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
@@ -82,11 +97,14 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     a.x = x; a.qweight = qweight; a.scales = scales; a.qzeros = qzeros; a.bias = bias; a.y = y;
     a.M = (int)M; a.K = (int)K; a.N = (int)N; a.g = (int)group_size;
     a.stream = static_cast<hipStream_t>(stream);
-    a.counters = nullptr; a.partial = nullptr; a.partial_floats = 0;
-    if (workspace && workspace_bytes > AWQ_WS_COUNTER_BYTES) {
+    a.counters = nullptr; a.partial = nullptr; a.partial_floats = 0; a.exchange = nullptr; a.exchange_bytes = 0;
+    if (workspace && workspace_bytes > AWQ_WS_COUNTER_BYTES + 512) {
+        const size_t half = ((workspace_bytes - AWQ_WS_COUNTER_BYTES) / 2) & ~(size_t)255;
         a.counters = static_cast<int*>(workspace);
-        a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + AWQ_WS_COUNTER_BYTES);
-        a.partial_floats = (workspace_bytes - AWQ_WS_COUNTER_BYTES) / sizeof(float);
+        a.exchange = reinterpret_cast<float*>(static_cast<char*>(workspace) + AWQ_WS_COUNTER_BYTES);
+        a.exchange_bytes = half;
+        a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + AWQ_WS_COUNTER_BYTES + half);
+        a.partial_floats = half / sizeof(float);
     }
 
     unsigned kern = AWQ_GEMM_FLAG_KERNEL(flags);
@@ -98,8 +116,14 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     if ((int64_t)K * N / 2 >= ((int64_t)1 << 31)) return AWQ_ERR_UNSUPPORTED;  // 32-bit buffer offsets
 
     if (kern == AWQ_GEMM_KERNEL_AUTO) {
-        if (M <= 16 && awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2)) kern = AWQ_GEMM_KERNEL_MFMA_GEMV;
-        else kern = AWQ_GEMM_KERNEL_NAIVE;
+        if (M <= 16 && awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2)) {
+            rc = awq_launch_gemv_mfma(a, 0, 0, 0, 0, false);
+            if (rc != AWQ_ERR_UNSUPPORTED) {
+                g_last_kernel = "gemv_mfma";
+                return rc;
+            }
+        }
+        kern = AWQ_GEMM_KERNEL_NAIVE;  // odd shapes, M > 16 until the tiled GEMM takes them
     }
     switch (kern) {
         case AWQ_GEMM_KERNEL_NAIVE:
@@ -115,7 +139,7 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
         case AWQ_GEMM_KERNEL_MFMA_GEMV: {
             if (M > 16) return AWQ_ERR_UNSUPPORTED;
             g_last_kernel = "gemv_mfma";
-            return awq_launch_gemv_mfma(a, nlog, waves, splitk, two_pass, nt);
+            return awq_launch_gemv_mfma(a, nlog, waves, (int)AWQ_GEMM_FLAG_UNIT(flags), splitk, two_pass);
         }
         default:
             return AWQ_ERR_UNSUPPORTED;

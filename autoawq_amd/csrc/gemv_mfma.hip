@@ -32,10 +32,11 @@
 //   2-4 co-resident waves of a SIMD overlap each other's memory and MFMA phases), then FOLDS
 //   group folds.
 //   The NWAVES waves of a block take consecutive row ranges of one column tile and are folded
-//   through LDS; K is further split over S blocks per tile.  Slabs are combined in-launch:
-//   write-through 16-byte slab stores, drain, one relaxed ticket; the last arriver sums the slabs
-//   in slab order (bitwise reproducible), writes fp16 and re-arms the ticket
-//   (cdna_hip_programming.md section 5, split-K recipe with sc1 slabs).
+//   through LDS; K is further split over S blocks per tile and combined in-launch in ONE fabric
+//   hop through self-validating write-through slabs (see the combine code): producers store and
+//   exit, the block of the last K slice polls, sums in slice order (bitwise reproducible), writes
+//   fp16 and re-arms.  (A drain + ticket + last-arriver design measured three serial fabric round
+//   trips, ~3 us, per call: profiles/ notes.)
 #include "awq_device.h"
 #include "awq_internal.h"
 
@@ -48,11 +49,13 @@ struct GemvMfmaParams {
     const half_t* x;
     const half_t* bias;
     half_t* y;
-    float* slabs;       // [S][tiles][M][CW] fp32 (in-launch) or [S][M][N] (two-pass)
-    unsigned* tickets;  // [tiles], zero on entry, zero on exit
+    float* slabs;    // in-launch exchange region [S-1][tiles][M][CW] fp32: all-ones sentinel on entry and on exit
+    float* scratch;  // two-pass mode: plain fp32 slabs [S][M][N]
+    int* err;        // set to 1 if a reducer gave up waiting
     int M, K, N, g;
     int tiles, S;
-    int iters_per_block;  // loop iterations (SETS sets each) per K slice
+    int rows_per_block;  // K slice per block: a whole number of 16*UNIT-row units
+    int ng_max;          // groups a slice can touch (sizes the LDS staging area)
     int two_pass;
 };
 
@@ -93,10 +96,23 @@ AWQ_DEV float4_t mfma16(u32x4v a, u32x4v b, float4_t c) {
 
 constexpr uint32_t OOB = 0x80000000u;  // lane offset beyond every descriptor: returns 0, no traffic
 
+// Phase timestamps for tools/trace_gemv.py (debug build only: -DAWQ_GEMV_TRACE)
+#ifdef AWQ_GEMV_TRACE
+__device__ unsigned long long* g_awq_trace = nullptr;
+#define AWQ_STAMP(slot)                                                                                  \
+    do {                                                                                                 \
+        if (g_awq_trace && lane == 0)                                                                    \
+            g_awq_trace[((size_t)blockIdx.x * NWAVES + wave) * 16 + (slot)] = wall_clock64();             \
+    } while (0)
+#else
+#define AWQ_STAMP(slot) do { } while (0)
+#endif
+
 // SEL: selector-row A (M <= 8, one MFMA per B fragment); !SEL: M <= 16, two MFMAs.
-// NREG: live D registers per lane (2 when M == 1, else 4).  SETS: 16-row sets per loop iteration
-// (8 or 4); FOLDS: group folds per iteration (SETS*16/FOLDS rows each: a divisor of g, <= 128).
-template <int WPL, int NWAVES, bool SEL, int NREG, int SETS, int FOLDS, bool NT>
+// NREG: live D registers per lane (2 when M == 1, else 4).  UNIT: 16-row sets a wave streams per
+// loop iteration (4*UNIT loads per lane in flight); FOLDS: group folds per unit (UNIT*16/FOLDS
+// rows each: a divisor of g, <= 128).
+template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool NT>
 __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaParams p) {
     typedef typename Words<WPL>::T WV;
     constexpr int CPL = 8 * WPL;         // columns per lane
@@ -105,7 +121,11 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     constexpr int NACC = 4 * WPL;        // (word, J) pairs per lane
     constexpr int NA = SEL ? 1 : 2;      // accumulators per pair
     constexpr int AUXW = NT ? 2 : 0;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [NWAVES][M][CWP]
+    constexpr int NTHR = NWAVES * 64;
+    constexpr int SPF = UNIT / FOLDS;    // sets per fold
+    // dynamic LDS: [xs: (M+1) x RS fp16][zq: ng x CW/8 u32][zsc: ng x CW fp16] during the K loop,
+    // re-used as red[NWAVES][M][CWP] fp32 afterwards
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,15 +134,50 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     const int NW = p.N >> 3;
     const int colw = (tile * 16 + j) * WPL;  // first packed word of this lane
     const bool active = colw < NW;
+    const int M = p.M;
+    AWQ_STAMP(0);
 
-    // this wave's loop iterations [ws, we), in units of SETS sets
-    const int nsets = p.K >> 4;
-    const int niter = (nsets + SETS - 1) / SETS;
-    const int bs = slice * p.iters_per_block;
-    const int be = min(niter, bs + p.iters_per_block);
-    const int per_wave = (be - bs + NWAVES - 1) / NWAVES;
-    const int ws = min(be, bs + wave * per_wave);
-    const int we = min(be, ws + per_wave);
+    // K slice of this block: rows [r0, r1), a whole number of units
+    const int r0 = slice * p.rows_per_block;
+    const int r1 = min(p.K, r0 + p.rows_per_block);
+    const int RS = p.rows_per_block;             // LDS row pitch of xs (multiple of 16*UNIT)
+    const int g0 = r0 / p.g;                     // first group of the slice
+    const int ng = (r1 - 1) / p.g - g0 + 1;      // groups touched by the slice
+    half_t* xs = reinterpret_cast<half_t*>(smem);
+    uint32_t* zq = reinterpret_cast<uint32_t*>(smem + (size_t)(M + 1) * RS * 2);
+    half_t* zsc = reinterpret_cast<half_t*>(reinterpret_cast<unsigned char*>(zq) + (size_t)p.ng_max * (CW / 2));
+
+    const uint32_t row_bytes = (uint32_t)NW * 4u;
+    const rsrc_t wres = mk_rsrc(p.qweight, (uint32_t)p.K * row_bytes);
+
+    // ---- stage this block's activations, zeros and scales in LDS (block-cooperative, 16-byte
+    // chunks): the K loop then uses the vector-memory path for packed weights ONLY.
+    {
+        const int xchunks = RS >> 3;  // 16-byte chunks per activation row
+        for (int c = tid; c < (M + 1) * xchunks; c += NTHR) {
+            const int m = c / xchunks, cc = c % xchunks;
+            const int row = r0 + 8 * cc;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < M && row < r1) v = *reinterpret_cast<const u32x4*>(p.x + (int64_t)m * p.K + row);
+            *reinterpret_cast<u32x4*>(xs + (size_t)m * RS + 8 * cc) = v;
+        }
+        constexpr int QC = CW / 32;  // 16-byte chunks of packed zeros per group row of the tile
+        for (int c = tid; c < ng * QC; c += NTHR) {
+            const int gl = c / QC, cc = c % QC;
+            const int w0 = tile * (CW / 8) + 4 * cc;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (w0 < NW) v = *reinterpret_cast<const u32x4*>(p.qzeros + (int64_t)(g0 + gl) * NW + w0);  // N % 32 == 0
+            *reinterpret_cast<u32x4*>(zq + gl * (CW / 8) + 4 * cc) = v;
+        }
+        constexpr int SC = CW / 8;  // 16-byte chunks of scales per group row of the tile
+        for (int c = tid; c < ng * SC; c += NTHR) {
+            const int gl = c / SC, cc = c % SC;
+            const int col = tile * CW + 8 * cc;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (col < p.N) v = *reinterpret_cast<const u32x4*>(p.scales + (int64_t)(g0 + gl) * p.N + col);
+            *reinterpret_cast<u32x4*>(zsc + gl * CW + 8 * cc) = v;
+        }
+    }
 
     float yv[NACC][NA][NREG];
 #pragma unroll
@@ -132,53 +187,42 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
 #pragma unroll
             for (int r = 0; r < NREG; ++r) yv[c][a][r] = 0.f;
 
-    if (ws < we) {
-        const uint32_t row_bytes = (uint32_t)NW * 4u;
-        const uint32_t ngroups = (uint32_t)(p.K / p.g);
-        const rsrc_t wres = mk_rsrc(p.qweight, (uint32_t)p.K * row_bytes);
-        const rsrc_t zres = mk_rsrc(p.qzeros, ngroups * row_bytes);
-        const rsrc_t sres = mk_rsrc(p.scales, ngroups * (uint32_t)p.N * 2u);
-        const rsrc_t xres = mk_rsrc(p.x, (uint32_t)p.M * (uint32_t)p.K * 2u);
+    {
         const uint32_t wvoff = active ? (uint32_t)colw * 4u + (uint32_t)(4 * kb) * row_bytes : OOB;
-        const uint32_t zvoff = active ? (uint32_t)colw * 4u : OOB;
-        const uint32_t svoff = active ? (uint32_t)colw * 16u : OOB;
-        // A row of this lane: SEL -> batch row j >> 1, column parity j & 1; else batch row j
-        const int arow = SEL ? (j >> 1) : j;
-        const uint32_t xvoff = (arow < p.M) ? ((uint32_t)arow * (uint32_t)p.K + 4u * kb) * 2u : OOB;
+        // A row of this lane: SEL -> batch row j >> 1, column parity j & 1; else batch row j.
+        // Lanes whose A row is >= M read the all-zero row M of xs.
+        const int arow = min(SEL ? (j >> 1) : j, M);
+        const half_t* xlane = xs + (size_t)arow * RS + 4 * kb;
         const uint32_t sel_lo = (j & 1) ? 0x01000C0Cu : 0x0C0C0100u;  // low half of a dword -> slot (j & 1)
         const uint32_t sel_hi = (j & 1) ? 0x03020C0Cu : 0x0C0C0302u;  // high half
         const u32x4v ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
-        constexpr int SPF = SETS / FOLDS;  // sets per fold
+        const int nunits = (r1 - r0) / (16 * UNIT);
+        bool staged = false;
+        AWQ_STAMP(7);
 
-        for (int it = ws; it < we; ++it) {
-            // ---- request the whole iteration: weights, activations, zeros/scales of its groups
-            WV q[SETS][4];
-            u32x2 xq[SETS];
-            WV qz[FOLDS];
-            u32x4 sc[FOLDS][WPL];
-            const uint32_t uset = (uint32_t)__builtin_amdgcn_readfirstlane(it) * SETS;
+        for (int u = wave; u < nunits; u += NWAVES) {
+            // ---- request the unit's packed weights: 4*UNIT independent loads per lane
+            WV q[UNIT][4];
+            const uint32_t urow = (uint32_t)__builtin_amdgcn_readfirstlane(r0 + u * 16 * UNIT);
+            uint32_t soff = urow * row_bytes;
 #pragma unroll
-            for (int t = 0; t < SETS; ++t) {
-                const bool valid = (int)(uset + t) < nsets;  // only the K tail can be short
-                const uint32_t srow = (uset + t) * 16u * row_bytes;
-                const uint32_t wv = valid ? wvoff : OOB;
+            for (int t = 0; t < UNIT; ++t) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) q[t][r] = ld_words<WPL, AUXW>(wres, wv, srow + (uint32_t)r * row_bytes);
-                xq[t] = __builtin_bit_cast(
-                    u32x2, __builtin_amdgcn_raw_buffer_load_b64(xres, valid ? xvoff : OOB, (uset + t) * 32u, 0));
+                for (int r = 0; r < 4; ++r) {
+                    q[t][r] = ld_words<WPL, AUXW>(wres, wvoff, soff);
+                    soff += row_bytes;
+                }
+                soff += 12u * row_bytes;
             }
-#pragma unroll
-            for (int f = 0; f < FOLDS; ++f) {
-                uint32_t grp = ((uset + SPF * f) * 16u) / (uint32_t)p.g;
-                grp = grp < ngroups ? grp : ngroups - 1;
-                qz[f] = ld_words<WPL, 0>(zres, zvoff, grp * row_bytes);
-#pragma unroll
-                for (int wd = 0; wd < WPL; ++wd) sc[f][wd] = __builtin_bit_cast(
-                    u32x4, __builtin_amdgcn_raw_buffer_load_b128(sres, svoff + 16u * wd, grp * (uint32_t)p.N * 2u, 0));
+            __builtin_amdgcn_sched_barrier(0);  // all requests are issued before anything is consumed
+            if (u == wave) AWQ_STAMP(1);
+            if (!staged) {  // first unit: the staging stores above must be visible block-wide
+                __syncthreads();
+                staged = true;
             }
-            __builtin_amdgcn_sched_barrier(0);  // every request above is issued before anything is consumed
 
             // ---- consume
+            const int lrow = (int)urow - r0;  // slice-local first row of the unit
 #pragma unroll
             for (int f = 0; f < FOLDS; ++f) {
                 float4_t acc[NACC][NA];
@@ -189,7 +233,8 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                     for (int a = 0; a < NA; ++a) acc[c][a] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = f * SPF; t < (f + 1) * SPF; ++t) {
-                    const uint32_t x01 = xq[t][0], x23 = xq[t][1];
+                    const u32x2 xq = *reinterpret_cast<const u32x2*>(xlane + lrow + 16 * t);
+                    const uint32_t x01 = xq[0], x23 = xq[1];
                     u32x4v a0, a1;
                     if constexpr (SEL) {
                         a0 = u32x4v{__builtin_amdgcn_perm(0u, x01, sel_lo), __builtin_amdgcn_perm(0u, x01, sel_hi),
@@ -216,11 +261,13 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
 #undef AWQ_MMA_J
                     }
                 }
-                // y += s * (acc - (16 + z) * sx) over the rows of this fold (one group, <= 128 rows)
+                // y += s * (acc - (16 + z) * sx) over the rows of this fold (inside one group)
+                const int gl = ((int)urow + 16 * SPF * f) / p.g - g0;
+                const WV qzv = *reinterpret_cast<const WV*>(zq + gl * (CW / 8) + j * WPL);
 #pragma unroll
                 for (int wd = 0; wd < WPL; ++wd) {
-                    const u32x4 sv = sc[f][wd];
-                    const uint32_t zw = qz[f][wd];
+                    const u32x4 sv = *reinterpret_cast<const u32x4*>(zsc + gl * CW + j * CPL + 8 * wd);
+                    const uint32_t zw = qzv[wd];
                     const uint32_t zp[4] = {pair16<0>(zw), pair16<1>(zw), pair16<2>(zw), pair16<3>(zw)};
 #pragma unroll
                     for (int J = 0; J < 4; ++J) {
@@ -237,11 +284,15 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                     }
                 }
             }
+            if (u == wave) AWQ_STAMP(8);
         }
+        if (!staged) __syncthreads();  // waves without a unit still meet the staging barrier
     }
+    __syncthreads();  // every wave is done with xs / zq / zsc: the LDS becomes red[]
+    float* red = reinterpret_cast<float*>(smem);
 
+    AWQ_STAMP(2);
     // ---- fold the waves of the block through LDS: red[wave][m][col]
-    const int M = p.M;
     {
         float* mine = red + wave * M * CWP;
 #pragma unroll
@@ -258,6 +309,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                 }
     }
     __syncthreads();
+    AWQ_STAMP(3);
 
     const int quads = M * (CW / 4);  // float4 groups of the block's [M][CW] partial tile
     const int col0 = tile * CW;
@@ -292,41 +344,68 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         for (int qd = tid; qd < quads; qd += NWAVES * 64) {
             const int m = qd / (CW / 4), col = col0 + (qd % (CW / 4)) * 4;
             if (col < p.N)
-                *reinterpret_cast<float4_t*>(p.slabs + ((int64_t)slice * M + m) * p.N + col) = block_sum4(qd);
+                *reinterpret_cast<float4_t*>(p.scratch + ((int64_t)slice * M + m) * p.N + col) = block_sum4(qd);
         }
         return;
     }
 
-    // ---- in-launch combine: write-through slab, drain, ticket; last arriver reduces
+    // ---- in-launch combine, ONE fabric hop: self-validating slabs.
+    // The exchange region is kept filled with a sentinel (all bits set, a NaN no arithmetic here
+    // produces).  A producer block stores its fp32 partial tile with 16-byte write-through stores
+    // and exits: no drain, no flag, no ticket -- every aligned 4-byte word is its own "ready"
+    // signal, so torn 16-byte stores are harmless.  The block of the LAST K slice of a tile is its
+    // reducer: it polls the other slices' words with agent-scope (sc1) loads until none is the
+    // sentinel, adds them in slice order (bitwise reproducible), adds its own partial last,
+    // writes fp16 and re-arms the words it consumed.  Producers never wait; reducers are the last
+    // blocks in dispatch order, their spin is bounded and raises *err instead of hanging.
+    constexpr uint32_t SENT = 0xFFFFFFFFu, QNAN = 0x7FC00000u;
     const uint32_t slab_bytes = (uint32_t)quads * 16u;
-    const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)S * (uint32_t)p.tiles * slab_bytes);
-    for (int qd = tid; qd < quads; qd += NWAVES * 64) {
-        const float4_t s = block_sum4(qd);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), slres, (uint32_t)qd * 16u,
-                                               (uint32_t)(slice * p.tiles + tile) * slab_bytes, 16 /* sc1 */);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // every wave's slab stores are drained; red[] is free again
-    unsigned* flag = reinterpret_cast<unsigned*>(red);
-    if (tid == 0)
-        *flag = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*flag != (unsigned)(S - 1)) return;
-    for (int qd = tid; qd < quads; qd += NWAVES * 64) {
-        float4_t s = {0.f, 0.f, 0.f, 0.f};
-        for (int sl0 = 0; sl0 < S; sl0 += 8) {  // 8 independent 16-byte loads in flight, summed in slab order
-            float4_t v[8];
+    const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)(S - 1) * (uint32_t)p.tiles * slab_bytes);
+    if (slice != S - 1) {
+        for (int qd = tid; qd < quads; qd += NWAVES * 64) {
+            u32x4 b = __builtin_bit_cast(u32x4, block_sum4(qd));
 #pragma unroll
-            for (int u = 0; u < 8; ++u)  // slabs past S are requested out of range: zeros, no traffic
-                v[u] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                        slres, (sl0 + u < S) ? (uint32_t)qd * 16u : OOB,
-                                                        (uint32_t)((sl0 + u) * p.tiles + tile) * slab_bytes, 16));
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];  // fixed order: bitwise reproducible
+            for (int e = 0; e < 4; ++e) b[e] = (b[e] == SENT) ? QNAN : b[e];
+            __builtin_amdgcn_raw_buffer_store_b128(b, slres, (uint32_t)qd * 16u,
+                                                   (uint32_t)(slice * p.tiles + tile) * slab_bytes, 16 /* sc1 */);
         }
-        emit4(qd, s);
+        AWQ_STAMP(4);
+        return;
     }
-    if (tid == 0) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+    for (int qd = tid; qd < quads; qd += NWAVES * 64) {
+        const float4_t own = block_sum4(qd);
+        float4_t s = {0.f, 0.f, 0.f, 0.f};
+        for (int sl0 = 0; sl0 < S - 1; sl0 += 8) {  // 8 independent 16-byte loads in flight per poll
+            u32x4 v[8];
+            for (unsigned spins = 0;; ++spins) {
+                uint32_t pending = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)  // slices past S-1 are requested out of range: zeros, no traffic
+                    v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         slres, (sl0 + u < S - 1) ? (uint32_t)qd * 16u : OOB,
+                                                         (uint32_t)((sl0 + u) * p.tiles + tile) * slab_bytes, 16));
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    pending |= (v[u][0] == SENT) | (v[u][1] == SENT) | (v[u][2] == SENT) | (v[u][3] == SENT);
+                if (!pending) break;
+                if (spins > (1u << 18)) {  // give up: flag the error, use what is there
+                    *p.err = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += __builtin_bit_cast(float4_t, v[u]);  // fixed order: bitwise reproducible
+#pragma unroll
+            for (int u = 0; u < 8; ++u)  // re-arm (write-through; also drops the line from this XCD's L2)
+                if (sl0 + u < S - 1)
+                    __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, (uint32_t)qd * 16u,
+                                                           (uint32_t)((sl0 + u) * p.tiles + tile) * slab_bytes, 16);
+        }
+        emit4(qd, s + own);
+    }
+    AWQ_STAMP(5);
 }
 
 // y[m, n] = fp16( sum_s slabs[s, m, n] + bias[n] )   (two-pass mode)
@@ -355,86 +434,131 @@ __global__ __launch_bounds__(256) void awq_gemv_mfma_reduce_kernel(const float* 
     *reinterpret_cast<half4_t*>(y + i4) = o;
 }
 
-template <int WPL, int NWAVES, bool SEL, int NREG, int SETS, int FOLDS>
-void launch6(const GemvMfmaParams& p, dim3 grid, size_t lds, bool nt, hipStream_t st) {
+template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS>
+void launch6(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
     // dynamic LDS above 64 KiB needs the opt-in once per kernel (host-side attribute, no sync)
     static const bool lds_opt_in = [] {
         (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<WPL, NWAVES, SEL, NREG, SETS, FOLDS, true>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<WPL, NWAVES, SEL, NREG, SETS, FOLDS, false>),
+            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)lds_opt_in;
-    if (nt)
-        hipLaunchKernelGGL((awq_gemv_mfma_kernel<WPL, NWAVES, SEL, NREG, SETS, FOLDS, true>), grid, dim3(NWAVES * 64), lds, st, p);
-    else
-        hipLaunchKernelGGL((awq_gemv_mfma_kernel<WPL, NWAVES, SEL, NREG, SETS, FOLDS, false>), grid, dim3(NWAVES * 64), lds, st, p);
+    hipLaunchKernelGGL((awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true>), grid, dim3(NWAVES * 64), lds, st, p);
 }
 
-template <int WPL, int NWAVES, bool SEL, int NREG>
-void launch4(const GemvMfmaParams& p, dim3 grid, size_t lds, bool nt, hipStream_t st) {
-    if (p.g % 128 == 0) launch6<WPL, NWAVES, SEL, NREG, 8, 1>(p, grid, lds, nt, st);
-    else if (p.g % 64 == 0) launch6<WPL, NWAVES, SEL, NREG, 4, 1>(p, grid, lds, nt, st);
-    else if (p.g == 32) launch6<WPL, NWAVES, SEL, NREG, 4, 2>(p, grid, lds, nt, st);
-    else launch6<WPL, NWAVES, SEL, NREG, 4, 4>(p, grid, lds, nt, st);
+template <int WPL, int NWAVES, int UNIT>
+bool launch3(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    constexpr int UROWS = 16 * UNIT;
+    if (p.g % UROWS == 0) {  // a unit lies inside one group: one fold per unit
+        if (p.M == 1) launch6<WPL, NWAVES, UNIT, true, 2, 1>(p, grid, lds, st);
+        else if (p.M <= 8) launch6<WPL, NWAVES, UNIT, true, 4, 1>(p, grid, lds, st);
+        else if constexpr (WPL == 2 && NWAVES <= 4) launch6<WPL, NWAVES, UNIT, false, 4, 1>(p, grid, lds, st);
+        else return false;
+        return true;
+    }
+    if constexpr (UNIT == 2 && WPL == 2 && NWAVES == 4) {
+        if (p.g == 16) {  // two groups per 32-row unit
+            if (p.M == 1) launch6<2, 4, 2, true, 2, 2>(p, grid, lds, st);
+            else if (p.M <= 8) launch6<2, 4, 2, true, 4, 2>(p, grid, lds, st);
+            else launch6<2, 4, 2, false, 4, 2>(p, grid, lds, st);
+            return true;
+        }
+    }
+    return false;
 }
-
-template <int WPL, int NWAVES>
-void launch2(const GemvMfmaParams& p, dim3 grid, size_t lds, bool nt, hipStream_t st) {
-    if (p.M == 1) launch4<WPL, NWAVES, true, 2>(p, grid, lds, nt, st);
-    else if (p.M <= 8) launch4<WPL, NWAVES, true, 4>(p, grid, lds, nt, st);
-    else if constexpr (WPL == 2 && NWAVES <= 4) launch4<WPL, NWAVES, false, 4>(p, grid, lds, nt, st);
-}
-
-int sets_per_iter(int g) { return g % 128 == 0 ? 8 : 4; }
 
 }  // namespace
 
+#ifdef AWQ_GEMV_TRACE
+extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace(void* dev_buf) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_awq_trace), &dev_buf, sizeof(void*));
+}
+#endif
+
 bool awq_gemv_mfma_supports(int M, int K, int N, int g, int wpl) {
     if (M < 1 || M > 16) return false;
-    if (K % 16 || N % (8 * wpl)) return false;
-    if (!(g % 64 == 0 || g == 32 || g == 16)) return false;
+    if (K % 32 || N % 32) return false;  // 32-row units; 16-byte zeros / scales chunks
+    if (wpl == 4 && M > 8) return false;
+    if (!(g % 32 == 0 || g == 16)) return false;
+    if (g % 32 == 0 && g < 128 && (g & (g - 1))) return false;  // 32, 64 or a multiple of 128
+    if (g > 128 && g % 128) return false;
     return true;
 }
 
-// Default decomposition: about one block per CU, every wave at least one loop iteration.
-void awq_gemv_mfma_default_config(int M, int K, int N, int g, int* wpl, int* nwaves, int* splitk) {
-    (void)M;
-    if (*wpl == 0) *wpl = 2;
-    const int CW = 128 * *wpl;
-    const int tiles = (N + CW - 1) / CW;
-    const int niter = (K / 16 + sets_per_iter(g) - 1) / sets_per_iter(g);
-    if (*nwaves == 0) *nwaves = (tiles * niter >= 1024) ? 4 : 2;
-    if (*splitk == 0) {
-        int s = (256 + tiles - 1) / tiles;
-        const int max_s = (niter + *nwaves - 1) / *nwaves;
-        if (s > max_s) s = max_s;
-        if (s < 1) s = 1;
-        *splitk = s;
-    }
+namespace {
+struct GemvCfg {
+    int wpl, nwaves, unit, S, rows_per_block, ng_max;
+    size_t lds;
+};
+
+size_t gemv_lds_bytes(int M, int CW, int nwaves, int rows_per_block, int ng_max) {
+    const size_t staging = (size_t)(M + 1) * rows_per_block * 2 + (size_t)ng_max * (CW / 2 + 2 * CW);
+    const size_t red = (size_t)nwaves * M * (CW + 16) * 4;
+    return (staging > red ? staging : red) + 16;
 }
 
-int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int splitk, bool two_pass, bool nt) {
-    awq_gemv_mfma_default_config(a.M, a.K, a.N, a.g, &wpl, &nwaves, &splitk);
-    if (!awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, wpl)) return AWQ_ERR_UNSUPPORTED;
-    if (!(wpl == 2 || wpl == 4) || !(nwaves == 2 || nwaves == 4 || nwaves == 8)) return AWQ_ERR_UNSUPPORTED;
-    if ((wpl == 4 && (a.M > 8 || nwaves == 8)) || (a.M > 8 && nwaves == 8)) return AWQ_ERR_UNSUPPORTED;  // register budget
-    const int CW = 128 * wpl;
-    const int tiles = (a.N + CW - 1) / CW;
-    const int niter = (a.K / 16 + sets_per_iter(a.g) - 1) / sets_per_iter(a.g);
-    int S = splitk < 1 ? 1 : splitk;
-    if (S > 64) S = 64;
-    if (S > niter) S = niter;
-    {  // keep the slabs inside the workspace the caller gave us
-        const size_t per_slice = (two_pass ? (size_t)a.M * a.N : (size_t)tiles * a.M * CW) * sizeof(float);
-        const size_t fit = a.partial ? (a.partial_floats * sizeof(float)) / per_slice : 0;
-        if (S > 1 && (size_t)S > fit) S = fit < 1 ? 1 : (int)fit;
+// Fill in what the caller left at 0 and make the decomposition legal.  Returns false if no legal one.
+bool gemv_config(const AwqGemmArgs& a, bool two_pass, GemvCfg& c) {
+    const int M = a.M, K = a.K, N = a.N, g = a.g;
+    if (c.wpl == 0) c.wpl = 2;
+    if (c.wpl == 4 && M > 8) return false;
+    const int CW = 128 * c.wpl;
+    const int tiles = (N + CW - 1) / CW;
+    // Defaults from the r21 sweep (profiles/): ~2048-2752 waves in flight, i.e. every wave streams
+    // one or two units and the whole matrix is requested in the first microsecond; narrow
+    // matrices (< 32 column tiles) use 8-wave blocks and a 16-way K split.
+    const bool narrow = tiles < 32;
+    if (c.nwaves == 0) c.nwaves = (narrow && M <= 8 && c.wpl == 2) ? 8 : 4;
+    if (M > 8 && c.nwaves > 4) c.nwaves = 4;
+    if (c.wpl == 4 && c.nwaves > 4) c.nwaves = 4;
+    int S = c.S;
+    if (S == 0) S = narrow ? 16 : ((640 + tiles - 1) / tiles > 8 ? 8 : (640 + tiles - 1) / tiles);
+    // unit: the largest power of two <= 8 sets (requested, or 4 / 2 so that every wave gets one)
+    // that divides g and K
+    int unit = c.unit ? c.unit : ((K / 64) >= S * c.nwaves ? 4 : 2);
+    if (g == 16) unit = 2;
+    while (unit > 2 && ((g % (16 * unit)) || (K % (16 * unit)))) unit >>= 1;
+    if (K % (16 * unit)) return false;
+    if (g != 16 && g % (16 * unit)) return false;
+    if (c.wpl == 4 && unit == 8) unit = 4;  // register budget
+    c.unit = unit;
+    const int units = K / (16 * unit);
+    if (c.S == 0) {  // every wave at least one unit
+        const int max_s = (units + c.nwaves - 1) / c.nwaves;
+        if (S > max_s) S = max_s;
     }
-    const int ipb = (niter + S - 1) / S;
-    S = (niter + ipb - 1) / ipb;
+    if (S > 64) S = 64;
+    if (S > units) S = units;
+    if (S < 1) S = 1;
+    for (;; ++S) {  // grow the split until the staging area fits the LDS
+        const int upb = (units + S - 1) / S;
+        c.rows_per_block = upb * 16 * unit;
+        c.ng_max = c.rows_per_block / g + 2;
+        c.lds = gemv_lds_bytes(M, CW, c.nwaves, c.rows_per_block, c.ng_max);
+        c.S = (units + upb - 1) / upb;
+        if (c.lds <= 160 * 1024) break;
+        if (S >= units || S >= 64) return false;
+    }
+    if (c.S > 1) {  // keep the slabs inside the workspace the caller gave us
+        const size_t per_slice = (two_pass ? (size_t)M * N : (size_t)tiles * M * CW) * sizeof(float);
+        const size_t have = two_pass ? a.partial_floats * sizeof(float) : a.exchange_bytes;
+        const size_t fit = have / per_slice + (two_pass ? 0 : 1);  // the reducer's own slice is not stored
+        if ((size_t)c.S > fit) return false;
+    }
+    return true;
+}
+}  // namespace
+
+int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, int splitk, bool two_pass) {
+    if (!(wpl == 0 || wpl == 2 || wpl == 4) || !(nwaves == 0 || nwaves == 2 || nwaves == 4 || nwaves == 8) ||
+        !(unit == 0 || unit == 2 || unit == 4 || unit == 8))
+        return AWQ_ERR_UNSUPPORTED;
+    if (!awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, wpl ? wpl : 2)) return AWQ_ERR_UNSUPPORTED;
+    GemvCfg c{wpl, nwaves, unit, splitk, 0, 0, 0};
+    if (!gemv_config(a, two_pass, c)) return AWQ_ERR_UNSUPPORTED;
+    const int CW = 128 * c.wpl;
+    const int tiles = (a.N + CW - 1) / CW;
     GemvMfmaParams p;
     p.qweight = reinterpret_cast<const uint32_t*>(a.qweight);
     p.qzeros = reinterpret_cast<const uint32_t*>(a.qzeros);
@@ -443,33 +567,31 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int splitk, 
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
-    p.tiles = tiles; p.S = S;
-    p.iters_per_block = ipb;
+    p.tiles = tiles; p.S = c.S;
+    p.rows_per_block = c.rows_per_block;
+    p.ng_max = c.ng_max;
     p.two_pass = two_pass ? 1 : 0;
-    p.slabs = a.partial;
-    p.tickets = reinterpret_cast<unsigned*>(a.counters);
-    if (S > 1) {
-        const size_t need = two_pass ? (size_t)S * a.M * a.N * sizeof(float)
-                                     : (size_t)S * tiles * a.M * CW * sizeof(float);
-        if (!a.partial || a.partial_floats * sizeof(float) < need || !a.counters) return AWQ_ERR_WORKSPACE;
-        if ((size_t)tiles * sizeof(unsigned) > AWQ_WS_COUNTER_BYTES) return AWQ_ERR_WORKSPACE;
-    }
-    const size_t lds = (size_t)nwaves * a.M * (CW + 16) * sizeof(float);
-    if (lds > 160 * 1024) return AWQ_ERR_UNSUPPORTED;
-    dim3 grid((unsigned)(tiles * S));
-    if (wpl == 2) {
-        if (nwaves == 2) launch2<2, 2>(p, grid, lds, nt, a.stream);
-        else if (nwaves == 4) launch2<2, 4>(p, grid, lds, nt, a.stream);
-        else launch2<2, 8>(p, grid, lds, nt, a.stream);
-    } else {
-        if (nwaves == 2) launch2<4, 2>(p, grid, lds, nt, a.stream);
-        else launch2<4, 4>(p, grid, lds, nt, a.stream);
-    }
+    p.slabs = a.exchange;
+    p.scratch = a.partial;
+    p.err = a.counters;
+    if (c.S > 1 && !two_pass && (!a.exchange || !a.counters)) return AWQ_ERR_WORKSPACE;
+    if (c.S > 1 && two_pass && !a.partial) return AWQ_ERR_WORKSPACE;
+    dim3 grid((unsigned)(tiles * c.S));
+    bool ok = false;
+#define AWQ_GEMV_CASE(W, V, U) \
+    if (c.wpl == W && c.nwaves == V && c.unit == U) ok = launch3<W, V, U>(p, grid, c.lds, a.stream);
+    AWQ_GEMV_CASE(2, 2, 2) AWQ_GEMV_CASE(2, 2, 4) AWQ_GEMV_CASE(2, 2, 8)
+    AWQ_GEMV_CASE(2, 4, 2) AWQ_GEMV_CASE(2, 4, 4) AWQ_GEMV_CASE(2, 4, 8)
+    AWQ_GEMV_CASE(2, 8, 2) AWQ_GEMV_CASE(2, 8, 4) AWQ_GEMV_CASE(2, 8, 8)
+    AWQ_GEMV_CASE(4, 2, 2) AWQ_GEMV_CASE(4, 2, 4)
+    AWQ_GEMV_CASE(4, 4, 2) AWQ_GEMV_CASE(4, 4, 4)
+#undef AWQ_GEMV_CASE
+    if (!ok) return AWQ_ERR_UNSUPPORTED;
     if (hipGetLastError() != hipSuccess) return AWQ_ERR_LAUNCH;
-    if (S > 1 && two_pass) {
+    if (c.S > 1 && two_pass) {
         const int MN = a.M * a.N;
         hipLaunchKernelGGL(awq_gemv_mfma_reduce_kernel, dim3((MN / 4 + 255) / 256), dim3(256), 0, a.stream, a.partial,
-                           reinterpret_cast<const half_t*>(a.bias), reinterpret_cast<half_t*>(a.y), MN, a.N, S);
+                           reinterpret_cast<const half_t*>(a.bias), reinterpret_cast<half_t*>(a.y), MN, a.N, c.S);
         if (hipGetLastError() != hipSuccess) return AWQ_ERR_LAUNCH;
     }
     return AWQ_OK;

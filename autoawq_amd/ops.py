@@ -13,9 +13,10 @@ FLAG_TWO_PASS = 1 << 16
 FLAG_NO_NT = 1 << 17
 
 
-def gemm_flags(kernel=0, nlog=0, splitk=0, two_pass=False, no_nt=False, waves=0):
-    """nlog: VALU -> log2 column lanes (2..4); MFMA_GEMV -> packed words per lane (2|4)."""
-    f = (kernel & 0xF) | ((nlog & 0xF) << 4) | ((splitk & 0xFF) << 8) | ((waves & 0xF) << 24)
+def gemm_flags(kernel=0, nlog=0, splitk=0, two_pass=False, no_nt=False, waves=0, unit=0):
+    """nlog: VALU -> log2 column lanes (2..4); MFMA_GEMV -> packed words per lane (2|4);
+    waves / unit: MFMA_GEMV waves per block and 16-row sets per wave iteration."""
+    f = (kernel & 0xF) | ((nlog & 0xF) << 4) | ((splitk & 0xFF) << 8) | ((waves & 0xF) << 24) | ((unit & 0xF) << 20)
     if two_pass:
         f |= FLAG_TWO_PASS
     if no_nt:
@@ -45,12 +46,14 @@ _workspaces = {}
 
 
 def workspace(device, nbytes):
-    """Zero-initialised split-K workspace, one per (device, stream); grown on demand.  The
-    counter words at its head are left zero by every kernel that uses them."""
+    """Split-K workspace, one per (device, stream), grown on demand and prepared once by
+    awq_gemm_workspace_init (control words zero, exchange region = all-ones sentinel); every
+    kernel that uses it restores that state."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _lib.check(_lib.lib().awq_gemm_workspace_init(_ptr(ws), ws.numel(), _stream()), "awq_gemm_workspace_init")
         _workspaces[key] = ws
     return ws
 
@@ -61,9 +64,13 @@ def _current_workspace(device):
 
 
 def workspace_is_clean(device):
-    """True when every split-K ticket word is back to zero (the invariant each call must restore)."""
+    """True when the workspace is back in its initial state: error flag / control words zero and the
+    split-K exchange region (first half after the control words) all-ones again."""
     ws = _current_workspace(device)
-    return True if ws is None else not bool(ws[:16384].any().item())
+    if ws is None:
+        return True
+    half = ((ws.numel() - 16384) // 2) & ~255
+    return (not bool(ws[:16384].any().item())) and bool((ws[16384:16384 + half] == 0xFF).all().item())
 
 
 def unpack_int4(q):

@@ -194,7 +194,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": bytes_step / launches, "avg_launch_us": ms_step * 1e3 / launches,
-                         "note": "achieved = algorithmic bytes / event-timed step; includes inter-kernel gaps"},
+                         "kernel": "awq_gemv_mfma_kernel (4 shapes per layer: qkv, o, gate+up, down)",
+                         "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "
+                                 "HIP-event-timed replay of the captured stream / launches, i.e. it contains the "
+                                 "dispatch gap exactly as rocprofv3's back-to-back kernel durations do "
+                                 "(profiles/r01_bench_kernel_trace_stats.txt)"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.layers)

@@ -14,9 +14,9 @@
  *   - return value: AWQ_OK (0) or a negative AWQ_ERR_* code; awq_hip_error_string() names it.
  *   - stateless and re-entrant; layout facts asserted by the reference modules are re-checked
  *     (N % 8 == 0, K % group == 0 -- awq/modules/linear/gemm.py:132-133).
- *   - workspaces: *_workspace_bytes() gives the size.  The first AWQ_WS_COUNTER_BYTES of a GEMM
- *     workspace hold split-K ticket words: they MUST be zero before the first call and every
- *     call leaves them zero again; the rest is scratch.  One workspace serves one stream at a time.
+ *   - workspaces: awq_gemm_workspace_bytes() gives the size, awq_gemm_workspace_init() prepares a
+ *     fresh allocation ONCE (control words zero, split-K exchange region filled with the all-ones
+ *     sentinel); every call restores that state.  One workspace serves one stream at a time.
  */
 #ifndef AWQ_HIP_H
 #define AWQ_HIP_H
@@ -46,7 +46,7 @@ enum {
     AWQ_ERR_NULL = -6           /* a required pointer is NULL */
 };
 
-#define AWQ_WS_COUNTER_BYTES 16384 /* split-K ticket words at the head of a GEMM workspace */
+#define AWQ_WS_COUNTER_BYTES 16384 /* control words at the head of a GEMM workspace (int32 word 0 = error flag) */
 
 AWQ_EXPORT int awq_hip_abi_version(void);
 AWQ_EXPORT const char* awq_hip_error_string(int code);
@@ -73,6 +73,7 @@ AWQ_EXPORT int awq_dequantize_weights(const int32_t* qweight, const uint16_t* sc
  * awq_gemm_workspace_bytes() returned 0 for the shape.  `flags` = 0 selects the tuned kernel;
  * AWQ_GEMM_FLAG_* force a variant (tests / tuning sweeps). */
 AWQ_EXPORT size_t awq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t group_size);
+AWQ_EXPORT int awq_gemm_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
                      const int32_t* qzeros, const uint16_t* bias, uint16_t* y, int64_t M, int64_t K,
                      int64_t N, int64_t group_size, void* workspace, size_t workspace_bytes,
@@ -89,7 +90,8 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
 #define AWQ_GEMM_FLAG_SPLITK(f) (((f) >> 8) & 0xFFu) /* 0 = auto */
 #define AWQ_GEMM_FLAG_TWO_PASS (1u << 16) /* MFMA_GEMV: split-K reduce in a second kernel instead of in-launch */
 #define AWQ_GEMM_FLAG_NO_NT (1u << 17)    /* plain (temporal) weight loads */
-#define AWQ_GEMM_FLAG_WAVES(f) (((f) >> 24) & 0xFu) /* MFMA_GEMV: waves per block (4|8), 0 = auto */
+#define AWQ_GEMM_FLAG_UNIT(f) (((f) >> 20) & 0xFu)  /* MFMA_GEMV: 16-row sets per wave iteration (2|4|8), 0 = auto */
+#define AWQ_GEMM_FLAG_WAVES(f) (((f) >> 24) & 0xFu) /* MFMA_GEMV: waves per block (2|4|8), 0 = auto */
 
 #ifdef __cplusplus
 }

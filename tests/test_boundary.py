@@ -39,6 +39,7 @@ def test_header_declares_and_library_exports_same_symbols():
     assert L.awq_gemm_forward(None, None, None, None, None, None, 0, 128, 16, 128, None, 0, 0, None) == 0   # M == 0
     assert L.awq_gemm_forward(None, None, None, None, None, None, 1, 128, 16, 128, None, 0, 0, None) == -6  # NULL
     assert L.awq_gemm_workspace_bytes(1, 4096, 4096, 128) > 16384
+    assert L.awq_gemm_workspace_init(None, 0, None) == -6
 
 
 def test_product_never_imports_the_oracle():

@@ -102,10 +102,11 @@ def gemm_variants(ops):
     for wpl in (2, 4):
         v[f"mfma_w{wpl}"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl)
         v[f"mfma_w{wpl}_s1"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=1)
-        v[f"mfma_w{wpl}_s5"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=5)
+        v[f"mfma_w{wpl}_s5_u2"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=5, unit=2)
         v[f"mfma_w{wpl}_s3_two_pass"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=3, two_pass=True)
-    v["mfma_w2_8waves"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, waves=8)
-    v["mfma_w2_s64_plain_loads"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, splitk=64, no_nt=True)
+        v[f"mfma_w{wpl}_v2_u4"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, waves=2, unit=4)
+    v["mfma_w2_v8_u8"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, waves=8, unit=8)
+    v["mfma_w2_v4_u8_s64"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, waves=4, unit=8, splitk=64)
     return v
 
 
@@ -174,7 +175,7 @@ def test_gemm_deterministic_and_counters_rearmed(ops):
     tickets come back to zero so the next (different-shape) call works."""
     qw, qz, s, x, _ = fullrange_case(4096, 4096, 128, 1, seed=11, realistic=True)
     dq, dz, ds, dx = qw.cuda(), qz.cuda(), s.cuda(), x.cuda()
-    for flags in (0, ops.gemm_flags(ops.KERNEL_VALU, nlog=3, splitk=32), ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, splitk=16), ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=4, splitk=8, waves=4)):
+    for flags in (0, ops.gemm_flags(ops.KERNEL_VALU, nlog=3, splitk=32), ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, splitk=16), ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=4, splitk=8, waves=4, unit=2)):
         first = ops.gemm_forward(dx, dq, ds, dz, flags=flags)
         for _ in range(20):
             assert torch.equal(ops.gemm_forward(dx, dq, ds, dz, flags=flags), first)

@@ -17,6 +17,8 @@ for (K, N, g, M, fl, nm) in [
     (128, 512, 128, 1, ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=4, splitk=1), "w4 s1"),
     (128, 256, 128, 3, ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, splitk=1), "w2 s1 M3"),
     (128, 256, 128, 12, ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, splitk=1), "w2 s1 M12"),
+    (4096, 4096, 128, 1, 0, "auto big"),
+    (512, 1056, 32, 3, 0, "auto ragged g32"),
 ]:
     qw, qz, sc = rand_packed(K, N, g, dev, gen)
     x = torch.randn((M, K), device=dev, generator=gen).half()

@@ -71,17 +71,15 @@ def main():
                         variants[f"valu n{nlog} s{sk}"] = ops.gemm_flags(ops.KERNEL_VALU, nlog=nlog, splitk=sk)
             for wpl in (2, 4):
                 for wv in (2, 4, 8):
-                    for sk in ((0, 2, 4, 8, 16, 32) if M == 1 else (0, 8)):
-                        variants[f"mfma w{wpl} v{wv} s{sk}"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=sk, waves=wv)
-                variants[f"mfma w{wpl} v4 s0 2pass"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, two_pass=True)
-                variants[f"mfma w{wpl} v4 s1"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=1)
-            variants["mfma w2 v4 s0 plain-ld"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, no_nt=True)
+                    for un in (2, 4, 8):
+                        for sk in ((0, 4, 8, 16, 32) if M == 1 else (0,)):
+                            variants[f"mfma w{wpl} v{wv} u{un} s{sk}"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=sk, waves=wv, unit=un)
+            variants["mfma w2 v4 u4 s0 2pass"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, waves=4, unit=4, two_pass=True)
             variants["auto"] = 0
             for name, fl in variants.items():
                 try:
                     us, y = time_variant(sets, x, fl)
                 except Exception as e:
-                    print(f"K{K} N{N} M{M} {name}: {e}")
                     continue
                 err = float((y.float() - ref).abs().max() / ref.abs().max())
                 gbs = by / us / 1e3
