@@ -36,3 +36,6 @@ int awq_launch_splitk_reduce(const AwqGemmArgs& a, int splitk);
 // block (2|4|8); unit: 16-row sets per wave iteration (2|4|8); splitk: K slices.  0 = auto each.
 bool awq_gemv_mfma_supports(int M, int K, int N, int g, int wpl);
 int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, int splitk, bool two_pass);
+// Fused dequant + LDS-tiled MFMA GEMM, any M (meant for M > 16).  bn: block tile width (128|256, 0 = auto).
+bool awq_gemm_tiled_supports(int M, int K, int N, int g);
+int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn);

@@ -123,7 +123,8 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
                 return rc;
             }
         }
-        kern = AWQ_GEMM_KERNEL_NAIVE;  // odd shapes, M > 16 until the tiled GEMM takes them
+        if (M > 16 && awq_gemm_tiled_supports(a.M, a.K, a.N, a.g)) kern = AWQ_GEMM_KERNEL_TILED;
+        else kern = AWQ_GEMM_KERNEL_NAIVE;  // odd shapes
     }
     switch (kern) {
         case AWQ_GEMM_KERNEL_NAIVE:
@@ -140,6 +141,10 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
             if (M > 16) return AWQ_ERR_UNSUPPORTED;
             g_last_kernel = "gemv_mfma";
             return awq_launch_gemv_mfma(a, nlog, waves, (int)AWQ_GEMM_FLAG_UNIT(flags), splitk, two_pass);
+        }
+        case AWQ_GEMM_KERNEL_TILED: {
+            g_last_kernel = "gemm_tiled";
+            return awq_launch_gemm_tiled(a, nlog == 2 ? 256 : (nlog == 1 ? 128 : 0));
         }
         default:
             return AWQ_ERR_UNSUPPORTED;

@@ -1,0 +1,268 @@
+// gemm_tiled.hip -- fused int4-dequant + MFMA GEMM on the GEMM layout for M > 16 (prefill and
+// batched decode), gfx950.
+//
+// Replaces the large-batch branch of awq/modules/linear/gemm.py:48-54 (dequantize_weights_cuda
+// followed by torch.matmul) and awq_ext.gemm_forward_cuda (:56-58) for M > 16 in ONE kernel: the
+// fp16 weight matrix is never materialised in HBM.
+//
+// Roofline: MFMA for M >= ~512 (AI = 2*M*K*N / bytes >> ridge 312 flop/B at M = 16384), HBM below.
+// Algorithmic bytes per call: K*N/2 + (K/g)*(N/8)*4 + (K/g)*N*2 + M*K*2 + M*N*2;
+// flops 2*M*K*N.
+//
+// Numerics: weights are dequantised to exactly the fp16 values the reference materialises
+// ((w - z) * s with one rounding, awq/utils/packing_utils.py:98-100) and multiplied with fp32
+// accumulation by v_mfma_f32_16x16x32_f16 -- the same arithmetic as dequant + fp16 GEMM.
+//
+// Structure (block = 128 x BN output tile, 4 waves as 2 x 2, K step 64, LDS double buffered)
+//   * A (activations): global 16-byte loads -> registers -> LDS rows of 72 halfs (144 B pitch:
+//     conflict-free ds_read_b64 of MFMA A fragments, 16-byte aligned ds_write_b128).
+//   * B (weights): each thread owns ONE packed word column and 4 rows of the K step; the word is
+//     decoded with the (nib | 0x6400) - (1024 + z) trick (awq_device.h), scaled, and written as 16
+//     bytes (8 N-adjacent fp16) into 16-column sub-tiles  [n/16][k][16].  The N-major layout is
+//     turned into K-major MFMA B fragments by ds_read_b64_tr_b16 (CDNA4 transpose read): lane
+//     (n, kb) receives k = 4*kb + {0..3} from one read and k = 16 + 4*kb + {0..3} from a second;
+//     the A fragment uses the same K-slot order, so no data is ever transposed by the VALU.
+//   * one barrier per K step: tile t+1 is fetched into registers before tile t is multiplied and
+//     stored into the other LDS buffer afterwards.
+#include "awq_device.h"
+#include "awq_internal.h"
+
+namespace {
+
+struct TiledParams {
+    const uint32_t* qweight;
+    const uint32_t* qzeros;
+    const half_t* scales;
+    const half_t* x;
+    const half_t* bias;
+    half_t* y;
+    int M, K, N, g;
+    int tiles_m, tiles_n;
+};
+
+typedef short short4_t __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr int BM = 128, BK = 64;
+constexpr int APITCH = BK + 8;  // halfs per A row in LDS (144 bytes)
+constexpr uint32_t OOB = 0x80000000u;
+
+AWQ_DEV rsrc_t mk_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+AWQ_DEV float4_t mfma16(half8_t a, half8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
+    constexpr int WN = BN / 2;         // columns per wave
+    constexpr int NT = WN / 16;        // 16-column MFMA tiles per wave
+    constexpr int WPT = BN / 8 / 16;   // packed words per thread per row group (BN=128: 1, 256: 2)
+    constexpr int A_BYTES = BM * APITCH * 2;
+    constexpr int B_BYTES = BK * BN * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A | B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, kb = lane >> 4;
+    // consecutive blocks walk the N tiles of one M tile (they share the activation rows in L2)
+    const int mt = blockIdx.x / p.tiles_n, nt = blockIdx.x % p.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int NW = p.N >> 3;
+
+    const rsrc_t xres = mk_rsrc(p.x, (uint32_t)((int64_t)p.M * p.K * 2));
+    const rsrc_t wres = mk_rsrc(p.qweight, (uint32_t)((int64_t)p.K * NW * 4));
+    const rsrc_t zres = mk_rsrc(p.qzeros, (uint32_t)((int64_t)(p.K / p.g) * NW * 4));
+    const rsrc_t sres = mk_rsrc(p.scales, (uint32_t)((int64_t)(p.K / p.g) * p.N * 2));
+
+    // ---- per-thread staging assignments
+    // A: 4 chunks of 16 bytes: chunk c = tid + 256*i -> row c/8, 8 halfs at k = 8*(c%8)
+    uint32_t a_voff[4];
+    int a_lds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+        a_voff[i] = (m0 + row < p.M) ? (uint32_t)(((int64_t)(m0 + row) * p.K + 8 * kc) * 2) : OOB;
+        a_lds[i] = (row * APITCH + 8 * kc) * 2;
+    }
+    // B: word column wc (of BN/8), rows 4*rg .. 4*rg+3 of the K step; WPT such assignments
+    int b_wc[WPT], b_rg[WPT];
+    uint32_t b_voff[WPT], z_voff[WPT], s_voff[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int idx = tid + 256 * i;
+        b_wc[i] = idx % (BN / 8);
+        b_rg[i] = idx / (BN / 8);  // 0..15
+        const int w = (n0 >> 3) + b_wc[i];
+        const bool ok = w < NW;
+        b_voff[i] = ok ? (uint32_t)(((int64_t)(4 * b_rg[i]) * NW + w) * 4) : OOB;
+        z_voff[i] = ok ? (uint32_t)w * 4u : OOB;
+        s_voff[i] = ok ? (uint32_t)w * 16u : OOB;
+    }
+
+    struct Regs {
+        u32x4 a[4];
+        uint32_t w[WPT][4], z[WPT];
+        u32x4 s[WPT];
+    };
+
+    auto fetch = [&](Regs& R, int t) {  // global -> registers for K step t
+        const uint32_t k0 = (uint32_t)t * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            R.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, a_voff[i], k0 * 2u, 0));
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                R.w[i][r] = __builtin_amdgcn_raw_buffer_load_b32(wres, b_voff[i], (k0 + (uint32_t)r) * (uint32_t)NW * 4u, 0);
+            const uint32_t grp = (k0 + 4u * (uint32_t)b_rg[i]) / (uint32_t)p.g;
+            R.z[i] = __builtin_amdgcn_raw_buffer_load_b32(zres, z_voff[i] + grp * (uint32_t)NW * 4u, 0, 0);
+            R.s[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sres, s_voff[i] + grp * (uint32_t)p.N * 2u, 0, 0));
+        }
+    };
+
+    auto stage = [&](const Regs& R, int buf) {  // registers -> LDS (dequantising B)
+        unsigned char* A = smem + buf * (A_BYTES + B_BYTES);
+        unsigned char* B = A + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(A + a_lds[i]) = R.a[i];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const uint32_t qz = R.z[i];
+            const half2_t z0 = u2h2(awq_pair_magic<0>(qz)), z1 = u2h2(awq_pair_magic<1>(qz));
+            const half2_t z2 = u2h2(awq_pair_magic<2>(qz)), z3 = u2h2(awq_pair_magic<3>(qz));
+            const u32x4 sv = R.s[i];
+            // sub-tile (wc/2) of 16 columns: [k][16] halfs, this word is the (wc&1) half of a row
+            unsigned char* dst = B + ((b_wc[i] >> 1) * BK * 16 + (b_wc[i] & 1) * 8) * 2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t q = R.w[i][r];
+                u32x4 o;
+                o[0] = h22u(awq_dq_pair<0>(q, z0, u2h2(sv[0])));
+                o[1] = h22u(awq_dq_pair<1>(q, z1, u2h2(sv[1])));
+                o[2] = h22u(awq_dq_pair<2>(q, z2, u2h2(sv[2])));
+                o[3] = h22u(awq_dq_pair<3>(q, z3, u2h2(sv[3])));
+                *reinterpret_cast<u32x4*>(dst + (4 * b_rg[i] + r) * 32) = o;
+            }
+        }
+    };
+
+    float4_t acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) acc[i][jn] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses (bytes) inside a buffer
+    //   A: row wm*64 + 16*i + l15, k = kk*32 + 4*kb (+16 for the second half)
+    const int a_frag = ((wm * 64 + l15) * APITCH + 4 * kb) * 2;
+    //   B (tr read): sub-tile (wn*WN/16 + jn); lane t=l15 of group kb reads 4 halfs of row
+    //   kk*32 + 4*kb + (t>>2) at columns 4*(t&3); the hardware hands lane l15 column l15
+    const int b_frag = ((wn * NT) * BK * 16 + (4 * kb + (l15 >> 2)) * 16 + 4 * (l15 & 3)) * 2;
+
+    auto compute = [&](int buf) {
+        const unsigned char* A = smem + buf * (A_BYTES + B_BYTES);
+        const unsigned char* B = A + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8_t bf[NT];
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) {
+                const unsigned char* bp = B + b_frag + (jn * BK * 16 + kk * 32 * 16) * 2;
+                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4_t*)(bp));
+                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4_t*)(bp + 16 * 16 * 2));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                bf[jn] = __builtin_bit_cast(half8_t, u32x4{l2[0], l2[1], h2[0], h2[1]});
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned char* ap = A + a_frag + (16 * i * APITCH + kk * 32) * 2;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(ap);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(ap + 32);
+                const half8_t af = __builtin_bit_cast(half8_t, u32x4{lo[0], lo[1], hi[0], hi[1]});
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) acc[i][jn] = mfma16(af, bf[jn], acc[i][jn]);
+            }
+        }
+    };
+
+    // One barrier per K step: tile t+1 is fetched into registers before tile t is multiplied and
+    // decoded into the other LDS buffer afterwards; the co-resident block of the CU covers the
+    // global-load round trip.  (A distance-2 register pipeline was tried: the second register set
+    // and the unrolled accumulator copies cost the co-resident block, 675 -> 413 TF at M = 16384.)
+    const int T = p.K / BK;
+    Regs R;
+    fetch(R, 0);
+    stage(R, 0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) fetch(R, t + 1);
+        compute(t & 1);
+        if (t + 1 < T) stage(R, (t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D register r of lane (col l15, quad kb) is row 4*kb + r of its 16x16 tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+            const int col = n0 + wn * WN + 16 * jn + l15;
+            if (col >= p.N) continue;
+            const float b = p.bias ? (float)p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + 16 * i + 4 * kb + r;
+                if (row < p.M) p.y[(int64_t)row * p.N + col] = (half_t)(acc[i][jn][r] + b);
+            }
+        }
+    }
+}
+
+template <int BN>
+void launch_tiled(const TiledParams& p, hipStream_t st) {
+    constexpr size_t lds = 2 * (BM * APITCH * 2 + BK * BN * 2);
+    static const bool lds_opt_in = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)lds_opt_in;
+    hipLaunchKernelGGL((awq_gemm_tiled_kernel<BN>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, st, p);
+}
+
+}  // namespace
+
+bool awq_gemm_tiled_supports(int M, int K, int N, int g) {
+    if (M < 1) return false;
+    if (K % 64 || N % 8) return false;
+    if (g % 4) return false;  // a thread's 4 rows of a K step share one group
+    if ((int64_t)M * K * 2 >= ((int64_t)1 << 31) || (int64_t)K * N / 2 >= ((int64_t)1 << 31)) return false;
+    return true;
+}
+
+int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn) {
+    if (!awq_gemm_tiled_supports(a.M, a.K, a.N, a.g)) return AWQ_ERR_UNSUPPORTED;
+    if (bn == 0) bn = 128;
+    if (!(bn == 128 || bn == 256)) return AWQ_ERR_UNSUPPORTED;
+    TiledParams p;
+    p.qweight = reinterpret_cast<const uint32_t*>(a.qweight);
+    p.qzeros = reinterpret_cast<const uint32_t*>(a.qzeros);
+    p.scales = reinterpret_cast<const half_t*>(a.scales);
+    p.x = reinterpret_cast<const half_t*>(a.x);
+    p.bias = reinterpret_cast<const half_t*>(a.bias);
+    p.y = reinterpret_cast<half_t*>(a.y);
+    p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
+    p.tiles_m = (a.M + BM - 1) / BM;
+    p.tiles_n = (a.N + bn - 1) / bn;
+    if ((int64_t)p.tiles_m * p.tiles_n > 0x7FFFFFFF) return AWQ_ERR_UNSUPPORTED;
+    if (bn == 128) launch_tiled<128>(p, a.stream);
+    else launch_tiled<256>(p, a.stream);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}

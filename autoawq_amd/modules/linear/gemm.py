@@ -18,9 +18,13 @@ from torch.autograd import Function
 from ... import ops
 from ...utils.packing import pack_rows_int4, quantize_int_weights_kn
 
-# Same switch-over the reference uses between its fused kernel and dequant + fp16 GEMM
-# (awq/modules/linear/gemm.py:48): product of the first two dims of x as given.
-FP16_MATMUL_HEURISTIC_TOKENS = 1024
+# M above which the matmul goes dequant (bit-exact HIP kernel) + vendor fp16 GEMM -- the reference's
+# own large-batch route (awq/modules/linear/gemm.py:48-54, there at 1024 tokens).  On MI355X the
+# fused tiled kernel (csrc/gemm_tiled.hip) currently loses to that route at every M > 16
+# (profiles/r01_gemm_tiled_vs_two_pass.txt), so the switch sits right above the decode kernels;
+# set autoawq_amd.modules.linear.gemm.PREFILL_IMPL = "fused" to force the single-kernel path.
+TWO_PASS_MIN_TOKENS = 17
+PREFILL_IMPL = "auto"  # "auto" | "fused" | "two_pass"
 
 
 class WQLinearMMFunction(Function):
@@ -54,10 +58,9 @@ class WQLinearMMFunction(Function):
 
 
 def _linear_forward(x, x2d, qweight, scales, qzeros, bias):
-    big = x.dim() >= 2 and x.shape[0] * x.shape[1] >= FP16_MATMUL_HEURISTIC_TOKENS
-    if big and not ops.has_tiled_gemm():
-        # prefill: materialise W once (bit-exact HIP dequant) and use the vendor fp16 GEMM,
-        # exactly the reference's large-batch branch (:50-54)
+    M = x2d.shape[0]
+    two_pass = PREFILL_IMPL == "two_pass" or (PREFILL_IMPL == "auto" and M >= TWO_PASS_MIN_TOKENS)
+    if two_pass and M > 16:
         W = ops.dequantize_weights(qweight, scales, qzeros)
         out = torch.matmul(x2d, W)
         return out + bias if bias is not None else out

@@ -124,7 +124,7 @@ def gemm_forward(x2d, qweight, scales, qzeros, bias=None, flags=0):
 
 def has_tiled_gemm():
     """True once the fused LDS-tiled MFMA GEMM (large M) is built into the library."""
-    return False
+    return True
 
 
 def last_kernel():

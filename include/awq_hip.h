@@ -86,7 +86,7 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
 #define AWQ_GEMM_KERNEL_MFMA_GEMV 3u /* MFMA 16x16x32 streaming GEMV / skinny GEMM, M <= 16 */
 #define AWQ_GEMM_KERNEL_TILED 4u     /* LDS-tiled MFMA GEMM with fused dequant, large M */
 #define AWQ_GEMM_FLAG_KERNEL(f) ((f)&0xFu)
-#define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto; VALU: log2 column lanes (2..4); MFMA_GEMV: words per lane (2|4) */
+#define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto; VALU: log2 column lanes (2..4); MFMA_GEMV: words per lane (2|4); TILED: 1 = 128-, 2 = 256-column tile */
 #define AWQ_GEMM_FLAG_SPLITK(f) (((f) >> 8) & 0xFFu) /* 0 = auto */
 #define AWQ_GEMM_FLAG_TWO_PASS (1u << 16) /* MFMA_GEMV: split-K reduce in a second kernel instead of in-launch */
 #define AWQ_GEMM_FLAG_NO_NT (1u << 17)    /* plain (temporal) weight loads */

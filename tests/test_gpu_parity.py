@@ -170,6 +170,36 @@ def test_gemm_vs_oracle_all_variants(ops, oracle, K, N, g, M):
     assert ops.workspace_is_clean(dx.device), "split-K tickets must be re-armed (zero) after every call"
 
 
+@pytest.mark.parametrize("K,N,g", [(512, 256, 128), (1024, 384, 64), (256, 136, 32), (4096, 512, 128), (2048, 2048, 2048)])
+@pytest.mark.parametrize("M", [17, 64, 100, 128, 300])
+@pytest.mark.parametrize("bn", [1, 2])
+def test_tiled_gemm_vs_oracle(ops, oracle, K, N, g, M, bn):
+    """fused dequant + MFMA GEMM (M > 16): reference-order numerics (fp16-rounded weights, fp32
+    accumulation), ragged M and N tiles, with bias; also the asymmetric one-hot check that would
+    expose a transposed fragment."""
+    qw, qz, s, x, bias = fullrange_case(K, N, g, M, seed=K + N + M, realistic=(N % 64 == 0))
+    y32, _ = oracle.linear_gemm(x.numpy(), qw.numpy(), qz.numpy(), s.numpy(), g, bias.numpy())
+    fl = ops.gemm_flags(ops.KERNEL_TILED, nlog=bn)
+    y = ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), flags=fl)
+    assert ops.last_kernel() == "gemm_tiled"
+    assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"tiled K{K} N{N} g{g} M{M} bn{bn}")
+    # one-hot rows pick rows of the bit-exact dequantised W (row m selects k = 7*m + 3)
+    W = ops.dequantize_weights(qw.cuda(), s.cuda(), qz.cuda())
+    e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    ks = (torch.arange(M, device="cuda") * 7 + 3) % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    out = ops.gemm_forward(e, qw.cuda(), s.cuda(), qz.cuda(), flags=fl)
+    assert torch.equal(out, W[ks])
+
+
+def test_auto_dispatch_by_m(ops):
+    qw, qz, s, x, _ = fullrange_case(512, 256, 128, 40, seed=9, realistic=True)
+    dq, dz, ds = qw.cuda(), qz.cuda(), s.cuda()
+    for M, want in [(1, "gemv_mfma"), (16, "gemv_mfma"), (17, "gemm_tiled"), (40, "gemm_tiled")]:
+        ops.gemm_forward(x[:M].cuda(), dq, ds, dz)
+        assert ops.last_kernel() == want, (M, ops.last_kernel())
+
+
 def test_gemm_deterministic_and_counters_rearmed(ops):
     """split-K slabs are summed in fixed slab order: bitwise identical across 20 runs, and the
     tickets come back to zero so the next (different-shape) call works."""
