@@ -27,6 +27,11 @@ SIGNATURES = {
     "awq_gemm_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
     "awq_gemm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_void_p, c_size_t, c_uint32, c_void_p]),
+    "awq_gemv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                 c_int64, c_uint32, c_void_p]),
+    "awq_gemv_lds_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "awq_dequantize_weights_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                            c_int64, c_void_p]),
 }
 
 

@@ -39,3 +39,11 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
 // Fused dequant + LDS-tiled MFMA GEMM, any M (meant for M > 16).  bn: block tile width (128|256, 0 = auto).
 bool awq_gemm_tiled_supports(int M, int K, int N, int g);
 int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn);
+// GEMV layout (qweight [N, K/8], qzeros [N, ZW], scales [N, 8*ZW]): MFMA GEMV, M <= 16, and the
+// bit-exact dequant to W^T [N, K].  nwaves (4|8|16) / unroll (4|8): 0 = auto.
+bool awq_gemv_nk_supports(int M, int K, int N, int g);
+size_t awq_gemv_nk_lds_bytes(int M, int K, int ZW, int nwaves);
+int awq_launch_gemv_nk(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                       uint16_t* y, int M, int K, int N, int g, int ZW, int nwaves, int unroll, hipStream_t st);
+int awq_launch_dequant_nk(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out, int K,
+                          int N, int g, int ZW, hipStream_t st);

@@ -151,4 +151,36 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     }
 }
 
+/* ---- GEMV layout ------------------------------------------------------------------------- */
+
+int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                     uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size, int64_t zeros_width,
+                     uint32_t flags, void* stream) {
+    if (K <= 0 || N < 0 || group_size <= 0 || K % group_size || K % 8 || zeros_width <= 0) return AWQ_ERR_BAD_SHAPE;
+    if (zeros_width * 8 < K / group_size) return AWQ_ERR_BAD_SHAPE;
+    if (M < 0 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    if (M == 0 || N == 0) return AWQ_OK;
+    if (!x || !qweight || !scales || !qzeros || !y) return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales)) return AWQ_ERR_BAD_ALIGNMENT;
+    if (!awq_gemv_nk_supports((int)M, (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
+    g_last_kernel = "gemv_nk";
+    return awq_launch_gemv_nk(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,
+                              (int)AWQ_GEMM_FLAG_WAVES(flags), (int)AWQ_GEMM_FLAG_UNIT(flags),
+                              static_cast<hipStream_t>(stream));
+}
+
+size_t awq_gemv_lds_bytes(int64_t M, int64_t K, int64_t zeros_width) {
+    return awq_gemv_nk_lds_bytes((int)M, (int)K, (int)zeros_width, 8);
+}
+
+int awq_dequantize_weights_gemv(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out,
+                                int64_t K, int64_t N, int64_t group_size, int64_t zeros_width, void* stream) {
+    if (K < 0 || N < 0 || group_size <= 0 || K % 8 || group_size % 8 || (K && K % group_size)) return AWQ_ERR_BAD_SHAPE;
+    if (K * N == 0) return AWQ_OK;
+    if (!qweight || !scales || !qzeros || !out) return AWQ_ERR_NULL;
+    if (!aligned16(out)) return AWQ_ERR_BAD_ALIGNMENT;
+    return awq_launch_dequant_nk(qweight, scales, qzeros, out, (int)K, (int)N, (int)group_size, (int)zeros_width,
+                                 static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

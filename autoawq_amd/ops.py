@@ -122,6 +122,47 @@ def gemm_forward(x2d, qweight, scales, qzeros, bias=None, flags=0):
     return y
 
 
+def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
+    """GEMV layout (qweight [N, K/8], qzeros [N, ZW], scales [N, 8*ZW]): y [M, N] fp16 = x2d @ W^T
+    (awq_gemv_forward).  M is processed in chunks that fit the kernel (<= 16 rows and the LDS)."""
+    _require_gpu(x2d, qweight, scales, qzeros)
+    if x2d.dtype != torch.float16:
+        raise _lib.AwqHipError("gemv_forward expects fp16 activations")
+    x2d, qweight, scales, qzeros = x2d.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    M, K = x2d.shape
+    N, ZW = qweight.shape[0], qzeros.shape[1]
+    if qweight.shape[1] * 8 != K or scales.shape != (N, ZW * 8):
+        raise _lib.AwqHipError(f"gemv_forward: shape mismatch x{tuple(x2d.shape)} qweight{tuple(qweight.shape)} "
+                               f"qzeros{tuple(qzeros.shape)} scales{tuple(scales.shape)}")
+    y = torch.empty((M, N), dtype=torch.float16, device=x2d.device)
+    if M == 0:
+        return y
+    L = _lib.lib()
+    chunk = 16
+    while chunk > 1 and L.awq_gemv_lds_bytes(chunk, K, ZW) > 160 * 1024:
+        chunk //= 2
+    with torch.cuda.device(x2d.device):
+        for m0 in range(0, M, chunk):
+            m1 = min(M, m0 + chunk)
+            rc = L.awq_gemv_forward(_ptr(x2d[m0:m1]), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y[m0:m1]),
+                                    m1 - m0, K, N, group_size, ZW, flags, _stream())
+            _lib.check(rc, "awq_gemv_forward")
+    return y
+
+
+def dequantize_weights_gemv(qweight, scales, qzeros, group_size):
+    """GEMV-layout buffers -> fp16 W^T [N, K] (awq_dequantize_weights_gemv)."""
+    _require_gpu(qweight, scales, qzeros)
+    qweight, scales, qzeros = qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    N, K = qweight.shape[0], qweight.shape[1] * 8
+    out = torch.empty((N, K), dtype=torch.float16, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        _lib.check(_lib.lib().awq_dequantize_weights_gemv(_ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(out), K, N,
+                                                          group_size, qzeros.shape[1], _stream()),
+                   "awq_dequantize_weights_gemv")
+    return out
+
+
 def has_tiled_gemm():
     """True once the fused LDS-tiled MFMA GEMM (large M) is built into the library."""
     return True

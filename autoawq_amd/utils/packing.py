@@ -30,3 +30,39 @@ def quantize_int_weights_kn(weight_nk, scales_gn, zeros_gn, group_size):
     wt = weight_nk.t()
     num = wt + scale_zeros.repeat_interleave(group_size, dim=0)
     return torch.round(num / s_half.repeat_interleave(group_size, dim=0)).to(torch.int)
+
+
+GEMV_ORDER = (0, 1, 2, 3, 4, 5, 6, 7)  # ordinal nibble order (awq/modules/linear/gemv.py:128)
+
+
+def calculate_zeros_width(in_features, group_size=128, pack_num=8):
+    """Words per qzeros row of the GEMV layouts (awq/modules/linear/gemv.py:12-24): ceil(K/g/8),
+    rounded up to a multiple of 1 / 2 / 4 for group sizes >= 128 / 64 / 32."""
+    if group_size >= 128:
+        mult = 1
+    elif group_size == 64:
+        mult = 2
+    elif group_size == 32:
+        mult = 4
+    else:
+        raise NotImplementedError
+    base = (in_features // group_size + pack_num - 1) // pack_num
+    return (base + mult - 1) // mult * mult
+
+
+def quantize_int_weights_nk(weight_nk, scales_ng, zeros_ng, padded_scales, group_size):
+    """Integer weights [N, K] with the dtype promotion of awq/modules/linear/gemv.py:110-121
+    (scale*zero in the caller's dtype, divided by the fp16 padded scales)."""
+    scale_zeros = zeros_ng * scales_ng
+    G = scales_ng.shape[1]
+    num = weight_nk + scale_zeros.repeat_interleave(group_size, dim=1)
+    return torch.round(num / padded_scales[:, :G].repeat_interleave(group_size, dim=1)).to(torch.int)
+
+
+def pack_zeros_nk(zeros_ng, zeros_width):
+    """[N, G] zero points -> int32 [N, ZW], nibble i of word c = zeros[:, 8c+i], zero past G
+    (awq/modules/linear/gemv.py:135-152)."""
+    N, G = zeros_ng.shape
+    padded = torch.zeros((N, zeros_width * 8), dtype=torch.int32, device=zeros_ng.device)
+    padded[:, :G] = zeros_ng.to(torch.int32)
+    return pack_rows_int4(padded, GEMV_ORDER)

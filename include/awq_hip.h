@@ -93,6 +93,24 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
 #define AWQ_GEMM_FLAG_UNIT(f) (((f) >> 20) & 0xFu)  /* MFMA_GEMV: 16-row sets per wave iteration (2|4|8), 0 = auto */
 #define AWQ_GEMM_FLAG_WAVES(f) (((f) >> 24) & 0xFu) /* MFMA_GEMV: waves per block (2|4|8), 0 = auto */
 
+/* ---- GEMV layout: qweight [N, K/8] i32 (ordinal nibbles), qzeros [N, ZW] i32, scales [N, 8*ZW] f16
+ *      (awq/modules/linear/gemv.py:45-69; ZW = calculate_zeros_width, gemv.py:12-24) -------------- */
+
+/* Replaces awq_ext.gemv_forward_cuda(x, qweight, scales, qzeros, group_size) (M <= 8) and
+ * awq_ext.gemmv2_forward_cuda(..., group_size, split_k_iters) (awq/modules/linear/gemv.py:168-180).
+ * y [M, N] fp16 = x [M, K] fp16 @ dequant(qweight)^T, fp32 accumulation, 1 <= M <= 16 per call and
+ * awq_gemv_lds_bytes(M, K, ZW) <= 160 KiB (the host wrapper chunks larger M); no bias (the
+ * reference adds it afterwards, gemv.py:185).  flags: AWQ_GEMM_FLAG_WAVES / _UNIT (unroll) tuning. */
+AWQ_EXPORT int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
+                                const int32_t* qzeros, uint16_t* y, int64_t M, int64_t K, int64_t N,
+                                int64_t group_size, int64_t zeros_width, uint32_t flags, void* stream);
+AWQ_EXPORT size_t awq_gemv_lds_bytes(int64_t M, int64_t K, int64_t zeros_width);
+/* out [N, K] fp16 = dequantised W^T, bit-identical to the GEMM-layout dequant of the same
+ * integers transposed (used for M > 16: dequant + fp16 GEMM, and by the tests). */
+AWQ_EXPORT int awq_dequantize_weights_gemv(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                                           uint16_t* out, int64_t K, int64_t N, int64_t group_size,
+                                           int64_t zeros_width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

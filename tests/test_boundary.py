@@ -110,3 +110,41 @@ def test_cpu_tensors_fail_loudly():
     # empty batch never reaches a kernel (gemm.py:44-45)
     out = m(torch.randn(0, 5, 256))
     assert out.shape == (0, 5, 64) and out.dtype == torch.float32
+
+
+# ------------------------------------------------------------------ WQLinear_GEMV surface (CPU)
+
+@pytest.mark.parametrize("name", ["packed_K512_N64_g128", "packed_K256_N32_g64", "packed_K128_N32_g32"])
+def test_gemv_module_surface_and_packer_match_reference(name):
+    """Buffers, shapes, dtypes and the vectorised packer == reference gemv.py packer outputs."""
+    from autoawq_amd import WQLinear_GEMV
+    from autoawq_amd.utils.packing import calculate_zeros_width
+
+    g = golden(name)
+    gs = int(g["group_size"])
+    K, N = g["w_int"].shape
+    m = WQLinear_GEMV(4, gs, K, N, True, "cpu")
+    sd = m.state_dict()
+    assert list(sd.keys()) == ["qweight", "qzeros", "scales", "bias"]
+    assert tuple(sd["qweight"].shape) == g["gemv_qweight"].shape and sd["qweight"].dtype == torch.int32
+    assert tuple(sd["qzeros"].shape) == g["gemv_qzeros"].shape and sd["qzeros"].dtype == torch.int32
+    assert tuple(sd["scales"].shape) == g["gemv_scales"].shape and sd["scales"].dtype == torch.float16
+    assert m.split_k_iters == 8 and list(dict(m.named_parameters())) == []
+    assert calculate_zeros_width(4096, 128) == 4 and calculate_zeros_width(11008, 128) == 11
+    assert calculate_zeros_width(8192, 64) == 16 and calculate_zeros_width(4096, 32) == 16
+    with pytest.raises(NotImplementedError):
+        calculate_zeros_width(4096, 16)
+    lin = torch.nn.Linear(K, N, bias=True).half()
+    lin.weight.data = torch.from_numpy(g["lin_weight"])
+    lin.bias.data = torch.from_numpy(g["bias"])
+    G = K // gs
+    scales = torch.from_numpy(g["gemv_scales"][:, :G].copy())                 # [N, G] fp16
+    zeros = torch.from_numpy(g["z_int"].T.astype(np.float32).copy())          # [N, G]
+    p = WQLinear_GEMV.from_linear(lin, 4, gs, False, scales, zeros)
+    assert np.array_equal(p.qweight.numpy(), g["gemv_qweight"])
+    assert np.array_equal(p.qzeros.numpy(), g["gemv_qzeros"])
+    assert np.array_equal(p.scales.numpy().view(np.uint16), g["gemv_scales"].view(np.uint16))
+    assert int(WQLinear_GEMV.from_linear(lin, 4, gs, init_only=True).qweight.abs().sum()) == 0
+    from autoawq_amd._lib import AwqHipError
+    with pytest.raises(AwqHipError):
+        p(torch.randn(1, 1, K))

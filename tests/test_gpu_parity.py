@@ -321,3 +321,94 @@ def test_awq_ext_shim_positional_api(ops):
     ulp = np.maximum(np.abs(ref), 2.0 ** -14) * 2.0 ** -10
     rms = np.sqrt((ref.astype(np.float64) ** 2).mean())
     assert (np.abs(out.cpu().numpy().astype(np.float32) - ref) <= 3 * ulp + 1e-3 * np.abs(ref) + 1e-3 * rms).all()
+
+
+# ------------------------------------------------------------------ GEMV layout (WQLinear_GEMV)
+
+def gemv_case(K, N, g, M, seed):
+    """Random GEMV-layout buffers: full-range packed words, zero-padded scales / zero nibbles past
+    K/g groups exactly like the reference packer leaves them (gemv.py:97-106,143-152)."""
+    from autoawq_amd.utils.packing import calculate_zeros_width
+
+    gen = torch.Generator().manual_seed(seed)
+    zw = calculate_zeros_width(K, g)
+    G = K // g
+    qw = torch.randint(MIN_INT32, MAX_INT32, (N, K // 8), dtype=torch.int32, generator=gen)
+    zn = torch.randint(0, 16, (N, zw * 8), dtype=torch.int32, generator=gen)
+    zn[:, G:] = 0
+    qz = torch.zeros((N, zw), dtype=torch.int32)
+    for i in range(8):
+        qz |= zn[:, i::8] << (4 * i)
+    sc = torch.zeros((N, zw * 8), dtype=torch.float16)
+    sc[:, :G] = (torch.rand((N, G), generator=gen) * 0.02 + 0.005).half()
+    x = torch.randn((M, K), generator=gen).half()
+    return qw, qz, sc, x
+
+
+@pytest.mark.parametrize("name", ["packed_K512_N64_g128", "packed_K256_N32_g64", "packed_K128_N32_g32"])
+def test_gemv_layout_golden(ops, oracle, name):
+    """reference-packed GEMV buffers: dequant bit-exact == GEMM-layout W^T; product vs the
+    reference's own forward output."""
+    g = golden(name)
+    gs = int(g["group_size"])
+    qw, qz, sc = dev(g["gemv_qweight"]), dev(g["gemv_qzeros"]), dev(g["gemv_scales"])
+    Wt = ops.dequantize_weights_gemv(qw, sc, qz, gs)
+    assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(g["W"].T).view(np.uint16))
+    y = ops.gemv_forward(dev(g["x"]), qw, sc, qz, gs).cpu().numpy().astype(np.float64)
+    y32, _ = oracle.matmul(g["x"], g["W"])
+    wsig = oracle.weight_rounding_sigma(g["x"], g["W"])
+    assert_product_close(y, y32, f"{name} gemv layout", wsigma=wsig)
+
+
+@pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (11008, 4096, 128), (4096, 11008, 128), (1024, 72, 64),
+                                   (512, 40, 32), (2048, 200, 2048), (256, 16, 128)])
+@pytest.mark.parametrize("M", [1, 2, 5, 8, 16, 33])
+def test_gemv_layout_vs_oracle(ops, oracle, K, N, g, M):
+    if M > 2 and K * N > 4096 * 4096:
+        pytest.skip("large shapes are covered at small M; keeps the oracle time bounded")
+    qw, qz, sc, x = gemv_case(K, N, g, M, seed=K + 3 * N + M)
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)      # [K, N] fp16, reference rounding
+    Wt = ops.dequantize_weights_gemv(qw.cuda(), sc.cuda(), qz.cuda(), g)
+    assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
+    y32, _ = oracle.matmul(x.numpy(), W)
+    wsig = oracle.weight_rounding_sigma(x.numpy(), W)
+    for flags in (0, ops.gemm_flags(waves=4, unit=8), ops.gemm_flags(waves=16, unit=4)):
+        y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=flags)
+        assert ops.last_kernel() == "gemv_nk"
+        assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemv K{K} N{N} g{g} M{M} f{flags:x}", wsigma=wsig)
+    # bitwise reproducible, one-hot rows select rows of the bit-exact W, zero in -> zero out
+    y1 = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g)
+    assert torch.equal(y1, ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g))
+    e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    ks = (torch.arange(M, device="cuda") * 37 + 5) % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    assert torch.equal(ops.gemv_forward(e, qw.cuda(), sc.cuda(), qz.cuda(), g), Wt.t()[ks])
+    assert int(ops.gemv_forward(torch.zeros_like(e), qw.cuda(), sc.cuda(), qz.cuda(), g).abs().max()) == 0
+
+
+def test_gemv_module_forward_semantics(ops, oracle):
+    from autoawq_amd import WQLinear_GEMV
+
+    g = golden("packed_K512_N64_g128")
+    m = WQLinear_GEMV(4, 128, 512, 64, True, "cuda")
+    m.qweight, m.qzeros, m.scales, m.bias = (dev(g["gemv_qweight"]), dev(g["gemv_qzeros"]), dev(g["gemv_scales"]),
+                                             dev(g["bias"]))
+    x = dev(g["x"])
+    y32, _ = oracle.matmul(g["x"], g["W"], g["bias"])
+    wsig = oracle.weight_rounding_sigma(g["x"], g["W"])
+    out = m(x.view(1, 4, 512))
+    assert out.shape == (1, 4, 64) and out.dtype == torch.float16
+    # bias is added after the fp16 rounding of the product (gemv.py:183-185): one more ulp
+    tol_ulp = np.maximum(np.abs(y32), 2.0 ** -14) * 2.0 ** -10
+    assert (np.abs(out[0].cpu().numpy().astype(np.float64) - y32) <= product_tol_(y32) + 6 * wsig + 2 * tol_ulp).all()
+    o32 = m(x.float())
+    assert o32.dtype == torch.float32 and o32.shape == (4, 64)
+    big = torch.randn((70, 512), generator=torch.Generator().manual_seed(2)).half()
+    yb, _ = oracle.matmul(big.numpy(), g["W"], g["bias"])
+    ob = m(big.cuda())  # >= 65 rows: dequant + fp16 GEMM route
+    assert (np.abs(ob.cpu().numpy().astype(np.float64) - yb) <= product_tol_(yb) + 3 * np.maximum(np.abs(yb), 2.0 ** -14) * 2.0 ** -10).all()
+
+
+def product_tol_(ref32):
+    from conftest import product_tol
+    return product_tol(ref32)
