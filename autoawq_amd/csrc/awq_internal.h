@@ -47,3 +47,10 @@ int awq_launch_gemv_nk(const uint16_t* x, const int32_t* qweight, const uint16_t
                        uint16_t* y, int M, int K, int N, int g, int ZW, int nwaves, int unroll, hipStream_t st);
 int awq_launch_dequant_nk(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out, int K,
                           int N, int g, int ZW, hipStream_t st);
+// Grouped (MoE) GEMM over stacked expert tensors (awq/modules/fused/moe.py:60-89), M = 16-row token blocks.
+size_t awq_grouped_workspace_bytes_impl(int max_blocks, int K, int N);
+int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const int* expert_ids, const int* num_post_pad,
+                            const float* pair_weights, int num_pairs, int x_div, int max_blocks, int64_t expert_qw_words,
+                            int64_t expert_z_words, int64_t expert_s_halfs);
+// out[r, d] = silu(in[r, d]) * in[r, D + d]   (awq_ext.silu_and_mul, moe.py:73-76)
+int awq_launch_silu_and_mul(const uint16_t* in, uint16_t* out, int64_t rows, int64_t D, hipStream_t st);

@@ -151,6 +151,52 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     }
 }
 
+/* ---- fused MLP / MoE ------------------------------------------------------------------- */
+
+int awq_silu_and_mul(const uint16_t* gate_up, uint16_t* out, int64_t rows, int64_t d, void* stream) {
+    if (rows < 0 || d < 0 || d % 8) return AWQ_ERR_BAD_SHAPE;
+    if (rows * d == 0) return AWQ_OK;
+    if (!gate_up || !out) return AWQ_ERR_NULL;
+    if (!aligned16(gate_up) || !aligned16(out)) return AWQ_ERR_BAD_ALIGNMENT;
+    return awq_launch_silu_and_mul(gate_up, out, rows, d, static_cast<hipStream_t>(stream));
+}
+
+size_t awq_grouped_gemm_workspace_bytes(int64_t max_blocks, int64_t K, int64_t N) {
+    if (max_blocks <= 0 || K <= 0 || N <= 0) return 0;
+    return awq_grouped_workspace_bytes_impl((int)max_blocks, (int)K, (int)N);
+}
+
+int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                             uint16_t* y, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                             const int32_t* num_tokens_post_padded, const float* pair_weights, int64_t num_pairs,
+                             int64_t x_div, int64_t max_blocks, int64_t num_experts, int64_t K, int64_t N,
+                             int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_gemm_layout(K, N, group_size);
+    if (rc) return rc;
+    if (num_pairs < 0 || x_div < 1 || max_blocks < 0 || num_experts < 1) return AWQ_ERR_BAD_SHAPE;
+    if (num_pairs == 0 || max_blocks == 0 || N == 0) return AWQ_OK;
+    if (!x || !qweight || !scales || !qzeros || !y || !sorted_token_ids || !expert_ids || !num_tokens_post_padded)
+        return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales) || !aligned16(qzeros) || !aligned16(y))
+        return AWQ_ERR_BAD_ALIGNMENT;
+    if ((int64_t)num_experts * K * N / 2 >= ((int64_t)1 << 40)) return AWQ_ERR_UNSUPPORTED;
+    if ((int64_t)K * N / 2 >= ((int64_t)1 << 31)) return AWQ_ERR_UNSUPPORTED;
+    AwqGemmArgs a;
+    a.x = x; a.qweight = qweight; a.scales = scales; a.qzeros = qzeros; a.bias = nullptr; a.y = y;
+    a.M = 16; a.K = (int)K; a.N = (int)N; a.g = (int)group_size;
+    a.stream = static_cast<hipStream_t>(stream);
+    a.counters = nullptr; a.partial = nullptr; a.partial_floats = 0; a.exchange = nullptr; a.exchange_bytes = 0;
+    if (workspace && workspace_bytes > AWQ_WS_COUNTER_BYTES) {  // [control][exchange]: no scratch half here
+        a.counters = static_cast<int*>(workspace);
+        a.exchange = reinterpret_cast<float*>(static_cast<char*>(workspace) + AWQ_WS_COUNTER_BYTES);
+        a.exchange_bytes = workspace_bytes - AWQ_WS_COUNTER_BYTES;
+    }
+    const int64_t NW = N / 8, G = K / group_size;
+    g_last_kernel = "gemv_mfma_grouped";
+    return awq_launch_grouped_gemm(a, sorted_token_ids, expert_ids, num_tokens_post_padded, pair_weights, (int)num_pairs,
+                                   (int)x_div, (int)max_blocks, K * NW, G * NW, G * N);
+}
+
 /* ---- GEMV layout ------------------------------------------------------------------------- */
 
 int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,

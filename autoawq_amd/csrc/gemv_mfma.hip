@@ -57,6 +57,14 @@ struct GemvMfmaParams {
     int rows_per_block;  // K slice per block: a whole number of 16*UNIT-row units
     int ng_max;          // groups a slice can touch (sizes the LDS staging area)
     int two_pass;
+    // ---- grouped (MoE) mode: one 16-row token block per blockIdx / (tiles*S), each with its own
+    // expert's weights (awq/modules/fused/moe.py:60-89).  All null / 0 in the plain mode.
+    const int* sorted_ids;    // [nblk*16] (token, expert) pair index per row, >= num_pairs = padding
+    const int* expert_ids;    // [nblk] expert of each 16-row block
+    const int* num_post_pad;  // device scalar: rows in use (multiple of 16)
+    const float* pair_weights;  // [num_pairs] routing weights, applied to the output if non-null
+    int num_pairs, x_div;     // activation row of pair i = i / x_div
+    int64_t expert_qw_words, expert_z_words, expert_s_halfs;  // per-expert strides
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -112,7 +120,7 @@ __device__ unsigned long long* g_awq_trace = nullptr;
 // NREG: live D registers per lane (2 when M == 1, else 4).  UNIT: 16-row sets a wave streams per
 // loop iteration (4*UNIT loads per lane in flight); FOLDS: group folds per unit (UNIT*16/FOLDS
 // rows each: a divisor of g, <= 128).
-template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool NT>
+template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool NT, bool MOE = false>
 __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaParams p) {
     typedef typename Words<WPL>::T WV;
     constexpr int CPL = 8 * WPL;         // columns per lane
@@ -130,7 +138,15 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kb = lane >> 4;
-    const int tile = blockIdx.x % p.tiles, slice = blockIdx.x / p.tiles;
+    const int tile = blockIdx.x % p.tiles, slice = (blockIdx.x / p.tiles) % p.S;
+    const int tblk = MOE ? blockIdx.x / (p.tiles * p.S) : 0;  // 16-row token block (grouped mode)
+    if constexpr (MOE) {
+        if (16 * tblk >= *p.num_post_pad) return;  // uniform for every block of this token block
+        const int64_t e = p.expert_ids[tblk];
+        p.qweight += e * p.expert_qw_words;
+        p.qzeros += e * p.expert_z_words;
+        p.scales += e * p.expert_s_halfs;
+    }
     const int NW = p.N >> 3;
     const int colw = (tile * 16 + j) * WPL;  // first packed word of this lane
     const bool active = colw < NW;
@@ -158,7 +174,16 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
             const int m = c / xchunks, cc = c % xchunks;
             const int row = r0 + 8 * cc;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (m < M && row < r1) v = *reinterpret_cast<const u32x4*>(p.x + (int64_t)m * p.K + row);
+            if (m < M && row < r1) {
+                int64_t xrow = m;
+                bool ok = true;
+                if constexpr (MOE) {  // gather: row m of the block is pair sorted_ids[16*tblk + m]
+                    const int pid = p.sorted_ids[16 * tblk + m];
+                    ok = pid < p.num_pairs;
+                    xrow = pid / p.x_div;
+                }
+                if (ok) v = *reinterpret_cast<const u32x4*>(p.x + xrow * p.K + row);
+            }
             *reinterpret_cast<u32x4*>(xs + (size_t)m * RS + 8 * cc) = v;
         }
         constexpr int QC = CW / 32;  // 16-byte chunks of packed zeros per group row of the tile
@@ -327,12 +352,19 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         const int m = qd / (CW / 4), c4 = (qd % (CW / 4)) * 4;
         const int col = col0 + c4;
         if (col >= p.N) return;  // N % 8 == 0: a quad is all in or all out
+        int64_t orow = m;
+        if constexpr (MOE) {  // scatter to the pair's row, optionally scaled by its routing weight
+            const int pid = p.sorted_ids[16 * tblk + m];
+            if (pid >= p.num_pairs) return;
+            orow = pid;
+            if (p.pair_weights) s *= p.pair_weights[pid];
+        }
         if (p.bias) {
             const half4_t b4 = *reinterpret_cast<const half4_t*>(p.bias + col);
             s += float4_t{(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
         }
         const half4_t o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
-        *reinterpret_cast<half4_t*>(p.y + (int64_t)m * p.N + col) = o;
+        *reinterpret_cast<half4_t*>(p.y + orow * p.N + col) = o;
     };
 
     const int S = p.S;
@@ -360,14 +392,15 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     // blocks in dispatch order, their spin is bounded and raises *err instead of hanging.
     constexpr uint32_t SENT = 0xFFFFFFFFu, QNAN = 0x7FC00000u;
     const uint32_t slab_bytes = (uint32_t)quads * 16u;
-    const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)(S - 1) * (uint32_t)p.tiles * slab_bytes);
+    const uint32_t tb0 = (uint32_t)tblk * (uint32_t)(S - 1) * (uint32_t)p.tiles;  // this token block's slabs
+    const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)((gridDim.x / (p.tiles * S)) * (S - 1)) * (uint32_t)p.tiles * slab_bytes);
     if (slice != S - 1) {
         for (int qd = tid; qd < quads; qd += NWAVES * 64) {
             u32x4 b = __builtin_bit_cast(u32x4, block_sum4(qd));
 #pragma unroll
             for (int e = 0; e < 4; ++e) b[e] = (b[e] == SENT) ? QNAN : b[e];
             __builtin_amdgcn_raw_buffer_store_b128(b, slres, (uint32_t)qd * 16u,
-                                                   (uint32_t)(slice * p.tiles + tile) * slab_bytes, 16 /* sc1 */);
+                                                   (tb0 + (uint32_t)(slice * p.tiles + tile)) * slab_bytes, 16 /* sc1 */);
         }
         AWQ_STAMP(4);
         return;
@@ -384,7 +417,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                 for (int u = 0; u < 8; ++u)  // slices past S-1 are requested out of range: zeros, no traffic
                     v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                          slres, (sl0 + u < S - 1) ? (uint32_t)qd * 16u : OOB,
-                                                         (uint32_t)((sl0 + u) * p.tiles + tile) * slab_bytes, 16));
+                                                         (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes, 16));
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     pending |= (v[u][0] == SENT) | (v[u][1] == SENT) | (v[u][2] == SENT) | (v[u][3] == SENT);
@@ -401,7 +434,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
             for (int u = 0; u < 8; ++u)  // re-arm (write-through; also drops the line from this XCD's L2)
                 if (sl0 + u < S - 1)
                     __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, (uint32_t)qd * 16u,
-                                                           (uint32_t)((sl0 + u) * p.tiles + tile) * slab_bytes, 16);
+                                                           (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes, 16);
         }
         emit4(qd, s + own);
     }
@@ -550,6 +583,85 @@ bool gemv_config(const AwqGemmArgs& a, bool two_pass, GemvCfg& c) {
 }
 }  // namespace
 
+namespace {
+template <int UNIT>
+void launch_moe(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    static const bool lds_opt_in = [] {
+        (void)hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<2, 4, UNIT, false, 4, 1, true, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)lds_opt_in;
+    hipLaunchKernelGGL((awq_gemv_mfma_kernel<2, 4, UNIT, false, 4, 1, true, true>), grid, dim3(256), lds, st, p);
+}
+}  // namespace
+
+// Grouped (MoE) GEMM: `max_blocks` 16-row token blocks, block b multiplies the gathered rows
+// sorted_ids[16b .. 16b+15] with expert expert_ids[b]'s weights; blocks past *num_post_pad exit.
+size_t awq_grouped_workspace_bytes_impl(int max_blocks, int K, int N) {
+    (void)K;
+    const size_t tiles = (size_t)(N + 255) / 256;
+    return (size_t)AWQ_WS_COUNTER_BYTES + (size_t)max_blocks * 7 * tiles * 16 * 256 * 4;  // S <= 8
+}
+
+int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const int* expert_ids, const int* num_post_pad,
+                            const float* pair_weights, int num_pairs, int x_div, int max_blocks, int64_t expert_qw_words,
+                            int64_t expert_z_words, int64_t expert_s_halfs) {
+    if (a.M != 16 || max_blocks < 1) return AWQ_ERR_BAD_SHAPE;
+    if (!awq_gemv_mfma_supports(16, a.K, a.N, a.g, 2) || a.g % 32) return AWQ_ERR_UNSUPPORTED;
+    GemvCfg c{2, 4, 0, 0, 0, 0, 0};
+    AwqGemmArgs probe = a;
+    probe.exchange_bytes = (size_t)-1 >> 1;  // the split is bounded below instead
+    if (!gemv_config(probe, false, c)) return AWQ_ERR_UNSUPPORTED;
+    if (a.g % (16 * c.unit)) return AWQ_ERR_UNSUPPORTED;
+    const int CW = 256;
+    const int tiles = (a.N + CW - 1) / CW;
+    // re-balance the K split for max_blocks x tiles blocks already in the grid (cap S at 8)
+    const int units = a.K / (16 * c.unit);
+    int S = (512 + tiles * max_blocks - 1) / (tiles * max_blocks);
+    if (S > 8) S = 8;
+    if (S > (units + 3) / 4) S = (units + 3) / 4;
+    if (S < 1) S = 1;
+    for (;; ++S) {
+        const int upb = (units + S - 1) / S;
+        c.rows_per_block = upb * 16 * c.unit;
+        c.ng_max = c.rows_per_block / a.g + 2;
+        c.lds = gemv_lds_bytes(16, CW, 4, c.rows_per_block, c.ng_max);
+        c.S = (units + upb - 1) / upb;
+        if (c.lds <= 160 * 1024) break;
+        if (S >= units || S >= 64) return AWQ_ERR_UNSUPPORTED;
+    }
+    if (c.S > 1) {
+        const size_t need = (size_t)max_blocks * (c.S - 1) * tiles * 16 * CW * sizeof(float);
+        if (!a.exchange || !a.counters || a.exchange_bytes < need) return AWQ_ERR_WORKSPACE;
+    }
+    GemvMfmaParams p;
+    p.qweight = reinterpret_cast<const uint32_t*>(a.qweight);
+    p.qzeros = reinterpret_cast<const uint32_t*>(a.qzeros);
+    p.scales = reinterpret_cast<const half_t*>(a.scales);
+    p.x = reinterpret_cast<const half_t*>(a.x);
+    p.bias = nullptr;
+    p.y = reinterpret_cast<half_t*>(a.y);
+    p.M = 16; p.K = a.K; p.N = a.N; p.g = a.g;
+    p.tiles = tiles; p.S = c.S;
+    p.rows_per_block = c.rows_per_block;
+    p.ng_max = c.ng_max;
+    p.two_pass = 0;
+    p.slabs = a.exchange;
+    p.scratch = nullptr;
+    p.err = a.counters;
+    p.sorted_ids = sorted_ids; p.expert_ids = expert_ids; p.num_post_pad = num_post_pad;
+    p.pair_weights = pair_weights;
+    p.num_pairs = num_pairs; p.x_div = x_div;
+    p.expert_qw_words = expert_qw_words; p.expert_z_words = expert_z_words; p.expert_s_halfs = expert_s_halfs;
+    dim3 grid((unsigned)(tiles * c.S * max_blocks));
+    if (c.unit == 2) launch_moe<2>(p, grid, c.lds, a.stream);
+    else if (c.unit == 4) launch_moe<4>(p, grid, c.lds, a.stream);
+    else launch_moe<8>(p, grid, c.lds, a.stream);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
 int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, int splitk, bool two_pass) {
     if (!(wpl == 0 || wpl == 2 || wpl == 4) || !(nwaves == 0 || nwaves == 2 || nwaves == 4 || nwaves == 8) ||
         !(unit == 0 || unit == 2 || unit == 4 || unit == 8))
@@ -574,6 +686,8 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
     p.slabs = a.exchange;
     p.scratch = a.partial;
     p.err = a.counters;
+    p.sorted_ids = nullptr; p.expert_ids = nullptr; p.num_post_pad = nullptr; p.pair_weights = nullptr;
+    p.num_pairs = 0; p.x_div = 1; p.expert_qw_words = p.expert_z_words = p.expert_s_halfs = 0;
     if (c.S > 1 && !two_pass && (!a.exchange || !a.counters)) return AWQ_ERR_WORKSPACE;
     if (c.S > 1 && two_pass && !a.partial) return AWQ_ERR_WORKSPACE;
     dim3 grid((unsigned)(tiles * c.S));

@@ -163,6 +163,91 @@ def dequantize_weights_gemv(qweight, scales, qzeros, group_size):
     return out
 
 
+def silu_and_mul(gate_up, out=None):
+    """[..., 2d] fp16 = [gate | up] -> [..., d] = silu(gate) * up (awq_silu_and_mul)."""
+    _require_gpu(gate_up)
+    gate_up = gate_up.contiguous()
+    d = gate_up.shape[-1] // 2
+    if out is None:
+        out = torch.empty(gate_up.shape[:-1] + (d,), dtype=torch.float16, device=gate_up.device)
+    rows = gate_up.numel() // (2 * d) if d else 0
+    with torch.cuda.device(gate_up.device):
+        _lib.check(_lib.lib().awq_silu_and_mul(_ptr(gate_up), _ptr(out), rows, d, _stream()), "awq_silu_and_mul")
+    return out
+
+
+_moe_workspaces = {}
+
+
+def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_ids, expert_ids,
+                         num_tokens_post_padded, mul_weights, split_k_iters=8):
+    """awq_ext.grouped_gemm_forward semantics (awq/modules/fused/moe.py:60-89): x [T, 1 | topk, K] fp16,
+    stacked GEMM-layout expert tensors [E, ...]; returns [T, topk, N] fp16.  Nothing is read back
+    to the host: the routing tensors are consumed on the device."""
+    _require_gpu(x, qweight, scales, qzeros, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_padded)
+    T, topk = topk_weights.shape
+    E, K, NW = qweight.shape
+    N = NW * 8
+    G = qzeros.shape[1]
+    x = x.contiguous()
+    x_div = topk if x.shape[1] == 1 else 1
+    if x.shape[0] * x.shape[1] * x_div != T * topk or x.shape[-1] != K:
+        raise _lib.AwqHipError(f"grouped_gemm_forward: x{tuple(x.shape)} does not match {T} tokens x top-{topk}")
+    qweight, scales, qzeros = qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    sorted_token_ids = sorted_token_ids.contiguous()
+    y = torch.empty((T, topk, N), dtype=torch.float16, device=x.device)
+    max_blocks = expert_ids.numel()
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        need = L.awq_grouped_gemm_workspace_bytes(max_blocks, K, N)
+        key = (x.device.index, _stream())
+        ws = _moe_workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+            _lib.check(L.awq_gemm_workspace_init(_ptr(ws), ws.numel(), _stream()), "awq_gemm_workspace_init")
+            _moe_workspaces[key] = ws
+        w = topk_weights.contiguous().float() if mul_weights else None
+        rc = L.awq_grouped_gemm_forward(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y),
+                                        _ptr(sorted_token_ids), _ptr(expert_ids), _ptr(num_tokens_post_padded),
+                                        _ptr(w), T * topk, x_div, max_blocks, E, K, N, K // G, _ptr(ws), ws.numel(),
+                                        _stream())
+    _lib.check(rc, "awq_grouped_gemm_forward")
+    return y
+
+
+def moe_align_block_size(topk_ids, block_size, num_experts):
+    """Device-side (no host read) restatement of moe_align_block_size (awq/modules/fused/moe.py:94-134):
+    returns (sorted_token_ids [numel + E*(block-1)] padded with `numel`, expert_ids [numel + E] one per
+    block (entries past the used blocks are 0), num_tokens_post_padded [1]) as int32 tensors."""
+    flat = topk_ids.reshape(-1).to(torch.int64)
+    numel = flat.numel()
+    dev = flat.device
+    counts = torch.bincount(flat, minlength=num_experts)[:num_experts]
+    padded = (counts + block_size - 1) // block_size * block_size
+    pad_end = torch.cumsum(padded, 0)
+    pad_start = pad_end - padded
+    raw_start = torch.cumsum(counts, 0) - counts
+    order = torch.argsort(flat, stable=True)                 # pairs grouped by expert, original order kept
+    e_sorted = flat[order]
+    rank = torch.arange(numel, device=dev) - raw_start[e_sorted]
+    pos = pad_start[e_sorted] + rank
+    sorted_ids = torch.full((numel + num_experts * (block_size - 1),), numel, dtype=torch.int32, device=dev)
+    sorted_ids[pos] = order.to(torch.int32)
+    nblk = numel + num_experts  # capacity used by the reference (moe.py:121-123)
+    blk_first_row = torch.arange(nblk, device=dev) * block_size
+    expert_ids = torch.searchsorted(pad_end, blk_first_row, right=True).clamp_(max=num_experts - 1).to(torch.int32)
+    return sorted_ids, expert_ids, pad_end[-1:].to(torch.int32)
+
+
+def fused_topk(gating_output, topk, renormalize):
+    """awq/modules/fused/moe.py:137-171 (the branch the reference itself takes on ROCm)."""
+    routing = torch.softmax(gating_output, dim=-1, dtype=torch.float32)
+    w, ids = torch.topk(routing, topk, dim=-1)
+    if renormalize:
+        w = w / w.sum(dim=-1, keepdim=True)
+    return w, ids.to(torch.int32)
+
+
 def has_tiled_gemm():
     """True once the fused LDS-tiled MFMA GEMM (large M) is built into the library."""
     return True

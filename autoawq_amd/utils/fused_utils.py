@@ -1,0 +1,48 @@
+"""Buffer-level fusion helpers (reference: awq/utils/fused_utils.py:45-162).
+
+`fuse_qkv` / `fuse_linears` concatenate the packed buffers of sibling WQLinear modules so one
+kernel launch serves them: GEMM layout concatenates along N (dim 1 of qweight / qzeros / scales),
+GEMV layout along the output rows (dim 0).  With `operation=torch.stack` the experts of an MoE layer
+are stacked on a new leading dim (awq/models/mixtral.py:130-158)."""
+import torch
+
+from ..modules.linear.gemm import WQLinear_GEMM
+from ..modules.linear.gemv import WQLinear_GEMV
+
+
+def fuse_linears(linears, device=None, dim=1, operation=torch.cat):
+    """Same call forms as awq/utils/fused_utils.py:145-162 (`dim=1, operation=torch.cat` joins N of
+    GEMM-layout modules; `dim=0, operation=torch.stack` stacks experts)."""
+    first = linears[0]
+    device = device if device is not None else first.qweight.device
+    total_out = sum(l.out_features for l in linears) if operation is torch.cat else first.out_features
+    fused = type(first)(first.w_bit, first.group_size, first.in_features, total_out, bias=first.bias is not None,
+                        dev=device)
+    fused.qweight = operation([l.qweight for l in linears], dim=dim).to(device)
+    fused.qzeros = operation([l.qzeros for l in linears], dim=dim).to(device)
+    fused.scales = operation([l.scales for l in linears], dim=dim).to(device)
+    if first.bias is not None:
+        fused.bias = operation([l.bias for l in linears], dim=0).to(device)
+    for l in linears:
+        del l.qweight, l.qzeros, l.scales
+    return fused
+
+
+def fuse_qkv(module, q_proj, k_proj, v_proj):
+    """awq/utils/fused_utils.py:45-142 for the two layouts implemented here."""
+    first = q_proj
+    bias = torch.cat([q_proj.bias, k_proj.bias, v_proj.bias], dim=0) if q_proj.bias is not None else None
+    if isinstance(first, WQLinear_GEMV):
+        cls, dim = WQLinear_GEMV, 0
+    else:
+        cls, dim = WQLinear_GEMM, 1
+    qkv = cls(first.w_bit, first.group_size, first.in_features,
+              q_proj.out_features + k_proj.out_features + v_proj.out_features, bias is not None,
+              first.qweight.device)
+    qkv.qweight = torch.cat([q_proj.qweight, k_proj.qweight, v_proj.qweight], dim=dim)
+    qkv.qzeros = torch.cat([q_proj.qzeros, k_proj.qzeros, v_proj.qzeros], dim=dim)
+    qkv.scales = torch.cat([q_proj.scales, k_proj.scales, v_proj.scales], dim=dim)
+    qkv.bias = bias
+    for m in (q_proj, k_proj, v_proj):
+        del m.qweight, m.qzeros, m.scales
+    return qkv

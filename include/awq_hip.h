@@ -93,6 +93,28 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
 #define AWQ_GEMM_FLAG_UNIT(f) (((f) >> 20) & 0xFu)  /* MFMA_GEMV: 16-row sets per wave iteration (2|4|8), 0 = auto */
 #define AWQ_GEMM_FLAG_WAVES(f) (((f) >> 24) & 0xFu) /* MFMA_GEMV: waves per block (2|4|8), 0 = auto */
 
+/* ---- fused MLP / MoE (GEMM layout, experts stacked on a leading dim: awq/models/mixtral.py:130-158) */
+
+/* Replaces awq_ext.silu_and_mul(out, gate_up) (awq/modules/fused/moe.py:73-76):
+ * gate_up [rows, 2d] fp16 = [gate | up], out [rows, d] = silu(gate) * up. */
+AWQ_EXPORT int awq_silu_and_mul(const uint16_t* gate_up, uint16_t* out, int64_t rows, int64_t d, void* stream);
+
+/* Replaces awq_ext.grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_ids,
+ * expert_ids, num_tokens_post_padded, mul_weights, split_k_iters) (moe.py:60-89).
+ * qweight [E, K, N/8], qzeros [E, K/g, N/8], scales [E, K/g, N]; sorted_token_ids / expert_ids /
+ * num_tokens_post_padded as produced by moe_align_block_size with block 16 (moe.py:94-134), all on
+ * the device (no host read: capturable).  Row i of y [num_pairs, N] (pair = token*topk + slot) =
+ * x[i / x_div] @ W[expert of pair i], times pair_weights[i] if that pointer is non-NULL.
+ * max_blocks = capacity of expert_ids in 16-row blocks; the workspace is prepared once with
+ * awq_gemm_workspace_init like a GEMM workspace. */
+AWQ_EXPORT size_t awq_grouped_gemm_workspace_bytes(int64_t max_blocks, int64_t K, int64_t N);
+AWQ_EXPORT int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
+                                        const int32_t* qzeros, uint16_t* y, const int32_t* sorted_token_ids,
+                                        const int32_t* expert_ids, const int32_t* num_tokens_post_padded,
+                                        const float* pair_weights, int64_t num_pairs, int64_t x_div,
+                                        int64_t max_blocks, int64_t num_experts, int64_t K, int64_t N,
+                                        int64_t group_size, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- GEMV layout: qweight [N, K/8] i32 (ordinal nibbles), qzeros [N, ZW] i32, scales [N, 8*ZW] f16
  *      (awq/modules/linear/gemv.py:45-69; ZW = calculate_zeros_width, gemv.py:12-24) -------------- */
 

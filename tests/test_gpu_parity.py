@@ -412,3 +412,120 @@ def test_gemv_module_forward_semantics(ops, oracle):
 def product_tol_(ref32):
     from conftest import product_tol
     return product_tol(ref32)
+
+
+# ------------------------------------------------------------------ fused MLP / MoE
+
+def test_silu_and_mul_vs_oracle(ops, oracle):
+    gen = torch.Generator().manual_seed(4)
+    gu = (torch.randn((37, 2 * 1408), generator=gen) * 3).half()
+    gu.view(-1)[:6] = torch.tensor([0.0, -0.0, 65504, -65504, 1e-4, -20.0]).half()
+    want = oracle.silu_and_mul(gu.numpy())
+    got = ops.silu_and_mul(gu.cuda()).cpu().numpy()
+    w32, g32 = want.astype(np.float32), got.astype(np.float32)
+    fin = np.isfinite(w32)
+    assert np.array_equal(np.isfinite(g32), fin)
+    ulp = np.maximum(np.abs(w32[fin]), 2.0 ** -14) * 2.0 ** -10
+    assert (np.abs(g32[fin] - w32[fin]) <= ulp).all()
+    assert (got != want).mean() < 0.01  # the two exp() implementations agree almost everywhere
+
+
+def stacked_experts(E, K, N, g, seed):
+    gen = torch.Generator().manual_seed(seed)
+    qw = torch.randint(MIN_INT32, MAX_INT32, (E, K, N // 8), dtype=torch.int32, generator=gen)
+    qz = torch.randint(MIN_INT32, MAX_INT32, (E, K // g, N // 8), dtype=torch.int32, generator=gen)
+    sc = (torch.rand((E, K // g, N), generator=gen) * 0.02 + 0.005).half()
+    return qw, qz, sc
+
+
+@pytest.mark.parametrize("T,E,topk,K,N", [(4, 8, 2, 256, 512), (1, 8, 2, 512, 256), (19, 4, 2, 256, 1024), (40, 8, 2, 128, 256)])
+def test_grouped_gemm_vs_oracle(ops, oracle, T, E, topk, K, N):
+    """grouped_gemm_forward (moe.py:60-89): every (token, slot) pair against its own expert."""
+    g = 128
+    qw, qz, sc = stacked_experts(E, K, N, g, seed=T + E + K)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn((T, K), generator=gen).half()
+    logits = torch.randn((T, E), generator=gen)
+    w, ids = ops.fused_topk(logits.cuda(), topk, True)
+    s_ids, e_ids, npad = ops.moe_align_block_size(ids, 16, E)
+    y = ops.grouped_gemm_forward(x.cuda().view(T, 1, K), qw.cuda(), sc.cuda(), qz.cuda(), w, s_ids, e_ids, npad, False)
+    assert y.shape == (T, topk, N) and ops.last_kernel() == "gemv_mfma_grouped"
+    y2 = ops.grouped_gemm_forward(x.cuda().view(T, 1, K), qw.cuda(), sc.cuda(), qz.cuda(), w, s_ids, e_ids, npad, True)
+    idc, wc = ids.cpu().numpy(), w.cpu().numpy()
+    for t in range(T):
+        for j in range(topk):
+            e = int(idc[t, j])
+            ref32, _ = oracle.linear_gemm(x[t:t + 1].numpy(), qw[e].numpy(), qz[e].numpy(), sc[e].numpy(), g)
+            W = oracle.dequant_gemm(qw[e].numpy(), qz[e].numpy(), sc[e].numpy(), g)
+            sig = oracle.weight_rounding_sigma(x[t:t + 1].numpy(), W)
+            assert_product_close(y[t, j].cpu().numpy().astype(np.float64)[None], ref32, f"pair {t},{j}", wsigma=sig)
+            assert_product_close(y2[t, j].cpu().numpy().astype(np.float64)[None], ref32 * wc[t, j], f"weighted {t},{j}",
+                                 wsigma=sig * wc[t, j])
+    assert ops.workspace_is_clean(y.device)
+
+
+def test_moe_block_vs_oracle(ops, oracle):
+    """FusedSparseMoeBlock / apply_moe_weights (moe.py:12-91) on a Mixtral-shaped toy: E=8, top-2."""
+    from autoawq_amd.modules.fused.moe import FusedSparseMoeBlock
+
+    T, E, H, I, g = 4, 8, 256, 384, 128
+    w1q, w1z, w1s = stacked_experts(E, H, 2 * I, g, seed=1)
+    w2q, w2z, w2s = stacked_experts(E, I, H, g, seed=2)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn((T, H), generator=gen).half()
+    gate = torch.nn.Linear(H, E, bias=False).half()
+    gate.weight.data = (torch.randn((E, H), generator=gen) * 0.1).half()
+
+    class Stack:  # what fuse_linears(..., operation=torch.stack) returns: an object with the buffers
+        pass
+    ws, w2 = Stack(), Stack()
+    ws.qweight, ws.qzeros, ws.scales = w1q.cuda(), w1z.cuda(), w1s.cuda()
+    w2.qweight, w2.qzeros, w2.scales = w2q.cuda(), w2z.cuda(), w2s.cuda()
+    blk = FusedSparseMoeBlock(2, gate.cuda(), ws, w2)
+    with torch.no_grad():
+        out = blk(x.cuda().view(1, T, H))
+    assert out.shape == (1, T, H)
+    logits = blk.gate(x.cuda()).detach().float().cpu().numpy()  # the router itself is not on the int4 path
+    want, ids, wt = oracle.moe_forward(x.numpy(), logits, dict(qweight=w1q.numpy(), qzeros=w1z.numpy(), scales=w1s.numpy()),
+                                       dict(qweight=w2q.numpy(), qzeros=w2z.numpy(), scales=w2s.numpy()), 2, g)
+    got = out[0].cpu().numpy().astype(np.float64)
+    w32 = want.astype(np.float64)
+    rms = np.sqrt((w32 ** 2).mean())
+    assert (np.abs(got - w32) <= 4e-3 * np.abs(w32) + 4e-3 * rms).all(), np.abs(got - w32).max() / rms
+
+
+@pytest.mark.parametrize("layout", ["gemm", "gemv"])
+def test_quant_fused_mlp_vs_oracle(ops, oracle, layout):
+    """QuantFusedMLP (mlp.py:14-70): down(silu(gate(x)) * up(x)), one fused gate|up launch."""
+    from autoawq_amd import WQLinear_GEMM, WQLinear_GEMV
+    from autoawq_amd.modules.fused.mlp import QuantFusedMLP
+
+    H, I, g, M = 256, 512, 128, 3
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn((1, M, H), generator=gen).half()
+    mods, Ws = [], []
+    for (K, N, seed) in [(H, I, 1), (I, H, 2), (H, I, 3)]:  # gate, down, up
+        if layout == "gemm":
+            qw, qz, sc, _, _ = fullrange_case(K, N, g, 1, seed=seed, realistic=True)
+            m = WQLinear_GEMM(4, g, K, N, False, "cuda")
+            W = oracle.dequant_gemm(qw.numpy(), qz.numpy(), sc.numpy(), g)
+        else:
+            qw, qz, sc, _ = gemv_case(K, N, g, 1, seed=seed)
+            m = WQLinear_GEMV(4, g, K, N, False, "cuda")
+            W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+        m.qweight, m.qzeros, m.scales = qw.cuda(), qz.cuda(), sc.cuda()
+        mods.append(m)
+        Ws.append(W)
+    mlp = QuantFusedMLP(mods[0], mods[1], mods[2])
+    out = mlp(x.cuda())
+    assert out.shape == (1, M, H)
+    x2 = x[0].numpy()
+    g32, g16 = oracle.matmul(x2, Ws[0])
+    u32, u16 = oracle.matmul(x2, Ws[2])
+    h = oracle.silu_and_mul(np.concatenate([g16, u16], axis=1))
+    y32, _ = oracle.matmul(h, Ws[1])
+    rms = np.sqrt((y32.astype(np.float64) ** 2).mean())
+    err = np.abs(out[0].cpu().numpy().astype(np.float64) - y32)
+    assert (err <= 4e-3 * np.abs(y32) + 4e-3 * rms).all(), err.max() / rms
+    rw = torch.tensor([[0.25], [0.5], [1.0]], dtype=torch.float16, device="cuda")
+    assert torch.equal(mlp(x.cuda()[0], routing_weights=rw), rw * mlp(x.cuda()[0]))
