@@ -35,6 +35,11 @@ SIGNATURES = {
     "awq_gemv_lds_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "awq_dequantize_weights_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                             c_int64, c_void_p]),
+    "awq_gemv_fast_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                      c_int64, c_int64, c_uint32, c_void_p]),
+    "awq_gemv_fast_lds_bytes_c": (c_size_t, [c_int64, c_int64, c_int64]),
+    "awq_dequantize_weights_gemv_fast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                                 c_void_p]),
 }
 
 

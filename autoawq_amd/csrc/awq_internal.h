@@ -54,3 +54,10 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
                             int64_t expert_z_words, int64_t expert_s_halfs);
 // out[r, d] = silu(in[r, d]) * in[r, D + d]   (awq_ext.silu_and_mul, moe.py:73-76)
 int awq_launch_silu_and_mul(const uint16_t* in, uint16_t* out, int64_t rows, int64_t D, hipStream_t st);
+// GEMVFast layout (qweight int16 [N/4, K], scales / qzeros fp16 [8*ZW, N], qzeros = -(s*z)).
+bool awq_gemv_fast_supports(int M, int K, int N, int g);
+size_t awq_gemv_fast_lds_bytes(int M, int K, int g, int nwaves);
+int awq_launch_gemv_fast(const uint16_t* x, const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros,
+                         uint16_t* y, int M, int K, int N, int g, int GP, int nwaves, int unroll, hipStream_t st);
+int awq_launch_dequant_fast(const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros, uint16_t* out, int K,
+                            int N, int g, hipStream_t st);

@@ -229,4 +229,35 @@ int awq_dequantize_weights_gemv(const int32_t* qweight, const uint16_t* scales, 
                                  static_cast<hipStream_t>(stream));
 }
 
+/* ---- GEMVFast layout --------------------------------------------------------------------- */
+
+int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros,
+                          uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size, int64_t group_rows,
+                          uint32_t flags, void* stream) {
+    if (K <= 0 || N < 0 || group_size <= 0 || K % group_size || N % 4 || K % 64) return AWQ_ERR_BAD_SHAPE;
+    if (group_rows < K / group_size) return AWQ_ERR_BAD_SHAPE;
+    if (M < 0 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    if (M == 0 || N == 0) return AWQ_OK;
+    if (!x || !qweight || !scales || !qzeros || !y) return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales) || !aligned16(qzeros)) return AWQ_ERR_BAD_ALIGNMENT;
+    if (!awq_gemv_fast_supports((int)M, (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
+    g_last_kernel = "gemv_fast";
+    return awq_launch_gemv_fast(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)group_rows,
+                                (int)AWQ_GEMM_FLAG_WAVES(flags), (int)AWQ_GEMM_FLAG_UNIT(flags),
+                                static_cast<hipStream_t>(stream));
+}
+
+size_t awq_gemv_fast_lds_bytes_c(int64_t M, int64_t K, int64_t group_size) {
+    return awq_gemv_fast_lds_bytes((int)M, (int)K, (int)group_size, 8);
+}
+
+int awq_dequantize_weights_gemv_fast(const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros,
+                                     uint16_t* out, int64_t K, int64_t N, int64_t group_size, void* stream) {
+    if (K < 0 || N < 0 || group_size <= 0 || K % 64 || N % 4 || (K && K % group_size)) return AWQ_ERR_BAD_SHAPE;
+    if (K * N == 0) return AWQ_OK;
+    if (!qweight || !scales || !qzeros || !out) return AWQ_ERR_NULL;
+    return awq_launch_dequant_fast(qweight, scales, qzeros, out, (int)K, (int)N, (int)group_size,
+                                   static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -1,0 +1,88 @@
+"""WQLinear_GEMVFast for MI355X: the nn.Module surface of awq/modules/linear/gemv_fast.py.
+
+Drop-in contract kept (reference gemv_fast.py:68-208):
+  * ctor (w_bit, group_size, in_features, out_features, bias, dev); attributes split_k_iters = 8,
+    interleave = 4;
+  * BUFFERS qweight [N/4, K] int16 (4-row interleaved), scales [8*ZW, N] fp16 (group major),
+    qzeros [8*ZW, N] fp16 = -(scale*zero), bias [N] fp16 | None;
+  * from_linear(linear, w_bit, group_size, init_only=False, scales=None, zeros=None);
+  * forward needs a 3-D input [batch, tokens, K] (gemv_fast.py:190), bias added afterwards.
+The reference picks its decode kernel for batch < 8 and one token, its prefill GEMM otherwise; here
+the decode kernel (csrc/gemv_fast.hip) serves up to 64 rows in 16-row passes and larger inputs take
+bit-exact dequant + vendor fp16 GEMM.
+"""
+import torch
+
+from ... import ops
+from ...utils.packing import calculate_zeros_width, pack_intweight_fast, quantize_int_weights_nk
+
+DEQUANT_MATMUL_MIN_ROWS = 65
+
+
+class WQLinear_GEMVFast(torch.nn.Module):
+    def __init__(self, w_bit, group_size, in_features, out_features, bias, dev):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.w_bit = w_bit
+        self.group_size = group_size if group_size != -1 else in_features
+        self.split_k_iters = 8
+        self.interleave = 4
+
+        assert self.in_features % self.group_size == 0
+        assert out_features % (32 // self.w_bit) == 0
+        pack_num = 32 // self.w_bit
+        int16_pack_num = 16 // self.w_bit
+        assert out_features % self.interleave == 0
+        zw = calculate_zeros_width(in_features, self.group_size)
+        self.register_buffer("qweight", torch.zeros((out_features // self.interleave,
+                                                     in_features // int16_pack_num * self.interleave),
+                                                    dtype=torch.int16, device=dev))
+        self.register_buffer("scales", torch.zeros((zw * pack_num, out_features), dtype=torch.float16, device=dev))
+        self.register_buffer("qzeros", torch.zeros((zw * pack_num, out_features), dtype=torch.float16, device=dev))
+        if bias:
+            self.register_buffer("bias", torch.zeros((out_features), dtype=torch.float16, device=dev))
+        else:
+            self.bias = None
+
+    @classmethod
+    def from_linear(cls, linear, w_bit, group_size, init_only=False, scales=None, zeros=None):
+        awq_linear = cls(w_bit, group_size, linear.in_features, linear.out_features, linear.bias is not None,
+                         linear.weight.device)
+        if init_only:
+            return awq_linear
+        assert scales is not None and zeros is not None  # both [N, G]
+        zw = calculate_zeros_width(linear.in_features, group_size)
+        qscales = torch.zeros((scales.shape[0], zw * 8), dtype=torch.float16, device=scales.device)
+        qscales[:, : scales.shape[1]] = scales
+        awq_linear.scales = qscales.transpose(1, 0).contiguous()
+        if linear.bias is not None:
+            awq_linear.bias = linear.bias.clone().half()
+        intweight = quantize_int_weights_nk(linear.weight.data, scales, zeros, qscales, group_size)
+        awq_linear.qweight = pack_intweight_fast(intweight.contiguous())
+        qzeros = torch.zeros_like(qscales)
+        G = scales.shape[1]
+        qzeros[:, :G] = -(qscales[:, :G] * zeros.to(torch.int32).to(torch.float32)).to(torch.float16)
+        awq_linear.qzeros = qzeros.transpose(1, 0).contiguous()
+        return awq_linear
+
+    @torch.no_grad()
+    def forward(self, x):
+        batch_size, n_tokens, _ = x.shape  # 3-D input required, like the reference
+        inputs = x.reshape(-1, x.shape[-1])
+        in_dtype = inputs.dtype
+        if in_dtype != torch.float16:
+            inputs = inputs.half()
+        if inputs.shape[0] >= DEQUANT_MATMUL_MIN_ROWS or self.out_features % 16:
+            Wt = ops.dequantize_weights_gemv_fast(self.qweight, self.scales, self.qzeros, self.group_size)
+            out = torch.matmul(inputs, Wt.t())
+        else:
+            out = ops.gemv_fast_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
+        if in_dtype != torch.float16:
+            out = out.to(in_dtype)
+        out = out.reshape(batch_size, n_tokens, self.out_features)
+        return out + self.bias if self.bias is not None else out
+
+    def extra_repr(self) -> str:
+        return "in_features={}, out_features={}, bias={}, w_bit={}, group_size={}".format(
+            self.in_features, self.out_features, self.bias is not None, self.w_bit, self.group_size)

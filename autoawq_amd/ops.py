@@ -248,6 +248,46 @@ def fused_topk(gating_output, topk, renormalize):
     return w, ids.to(torch.int32)
 
 
+def gemv_fast_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
+    """GEMVFast layout (qweight int16 [N/4, K], scales / qzeros fp16 [8*ZW, N]): y [M, N] fp16
+    (awq_gemv_fast_forward), M processed in chunks of <= 16 rows."""
+    _require_gpu(x2d, qweight, scales, qzeros)
+    if x2d.dtype != torch.float16:
+        raise _lib.AwqHipError("gemv_fast_forward expects fp16 activations")
+    x2d, qweight, scales, qzeros = x2d.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    M, K = x2d.shape
+    N, GP = qweight.shape[0] * 4, scales.shape[0]
+    if qweight.shape[1] != K or scales.shape != (GP, N) or qzeros.shape != (GP, N):
+        raise _lib.AwqHipError(f"gemv_fast_forward: shape mismatch x{tuple(x2d.shape)} qweight{tuple(qweight.shape)} "
+                               f"scales{tuple(scales.shape)}")
+    y = torch.empty((M, N), dtype=torch.float16, device=x2d.device)
+    if M == 0:
+        return y
+    L = _lib.lib()
+    chunk = 16
+    while chunk > 1 and L.awq_gemv_fast_lds_bytes_c(chunk, K, group_size) > 160 * 1024:
+        chunk //= 2
+    with torch.cuda.device(x2d.device):
+        for m0 in range(0, M, chunk):
+            m1 = min(M, m0 + chunk)
+            rc = L.awq_gemv_fast_forward(_ptr(x2d[m0:m1]), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y[m0:m1]),
+                                         m1 - m0, K, N, group_size, GP, flags, _stream())
+            _lib.check(rc, "awq_gemv_fast_forward")
+    return y
+
+
+def dequantize_weights_gemv_fast(qweight, scales, qzeros, group_size):
+    """GEMVFast-layout buffers -> fp16 W^T [N, K] (awq_dequantize_weights_gemv_fast)."""
+    _require_gpu(qweight, scales, qzeros)
+    qweight, scales, qzeros = qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    N, K = qweight.shape[0] * 4, qweight.shape[1]
+    out = torch.empty((N, K), dtype=torch.float16, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        _lib.check(_lib.lib().awq_dequantize_weights_gemv_fast(_ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(out), K, N,
+                                                               group_size, _stream()), "awq_dequantize_weights_gemv_fast")
+    return out
+
+
 def has_tiled_gemm():
     """True once the fused LDS-tiled MFMA GEMM (large M) is built into the library."""
     return True

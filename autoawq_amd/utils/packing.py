@@ -66,3 +66,15 @@ def pack_zeros_nk(zeros_ng, zeros_width):
     padded = torch.zeros((N, zeros_width * 8), dtype=torch.int32, device=zeros_ng.device)
     padded[:, :G] = zeros_ng.to(torch.int32)
     return pack_rows_int4(padded, GEMV_ORDER)
+
+
+def pack_intweight_fast(intweight_nk):
+    """[N, K] integers 0..15 -> int16 [N/4, K] of the GEMVFast layout (closed form of pack_intweight,
+    awq/modules/linear/gemv_fast.py:26-65 with interleave=4, kstride=64):
+    out[r, 64b + 16i + 8h + t] nibble j = w[4r + i, 64b + 32h + 8j + t]."""
+    N, K = intweight_nk.shape
+    assert N % 4 == 0 and K % 64 == 0
+    w = intweight_nk.to(torch.int32).reshape(N // 4, 4, K // 64, 2, 4, 8)  # r, i, b, h, j, t
+    w = w.permute(0, 2, 1, 3, 5, 4)                                       # r, b, i, h, t, j
+    packed = w[..., 0] | (w[..., 1] << 4) | (w[..., 2] << 8) | (w[..., 3] << 12)
+    return packed.reshape(N // 4, K).to(torch.int16)  # wraps like numpy astype("int16")

@@ -133,6 +133,22 @@ AWQ_EXPORT int awq_dequantize_weights_gemv(const int32_t* qweight, const uint16_
                                            uint16_t* out, int64_t K, int64_t N, int64_t group_size,
                                            int64_t zeros_width, void* stream);
 
+/* ---- GEMVFast layout: qweight [N/4, K] i16 (4-row interleave, awq/modules/linear/gemv_fast.py:26-65),
+ *      scales [8*ZW, N] f16, qzeros [8*ZW, N] f16 = -(scale*zero) (gemv_fast.py:86-118,175-181) ------- */
+
+/* Replaces awq_v2_ext.gemv_forward_cuda_decode(x, qweight, scales, qzeros, m, n, k, group_size) and, for
+ * small M, awq_v2_ext.gemm_forward_cuda_prefill (gemv_fast.py:185-208).  y [M, N] = x [M, K] @ W^T with
+ * W = w*s + qzeros; 1 <= M <= 16 per call (host wrapper chunks), N % 16 == 0, K % 128 == 0.
+ * group_rows = rows of scales / qzeros (8*ZW). */
+AWQ_EXPORT int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint16_t* scales,
+                                     const uint16_t* qzeros, uint16_t* y, int64_t M, int64_t K, int64_t N,
+                                     int64_t group_size, int64_t group_rows, uint32_t flags, void* stream);
+AWQ_EXPORT size_t awq_gemv_fast_lds_bytes_c(int64_t M, int64_t K, int64_t group_size);
+/* out [N, K] fp16 = dequantised W^T (W = fp16 of the fp32 fma w*s + qzeros). */
+AWQ_EXPORT int awq_dequantize_weights_gemv_fast(const int16_t* qweight, const uint16_t* scales,
+                                                const uint16_t* qzeros, uint16_t* out, int64_t K, int64_t N,
+                                                int64_t group_size, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

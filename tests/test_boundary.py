@@ -148,3 +148,32 @@ def test_gemv_module_surface_and_packer_match_reference(name):
     from autoawq_amd._lib import AwqHipError
     with pytest.raises(AwqHipError):
         p(torch.randn(1, 1, K))
+
+
+@pytest.mark.parametrize("name", ["packed_K512_N64_g128", "packed_K256_N32_g64", "packed_K128_N32_g32"])
+def test_gemvfast_module_surface_and_packer_match_reference(name):
+    """WQLinear_GEMVFast: buffers / dtypes and the closed-form packer == reference pack_intweight."""
+    from autoawq_amd import WQLinear_GEMVFast
+
+    g = golden(name)
+    gs = int(g["group_size"])
+    K, N = g["w_int"].shape
+    m = WQLinear_GEMVFast(4, gs, K, N, True, "cpu")
+    sd = m.state_dict()
+    assert list(sd.keys()) == ["qweight", "scales", "qzeros", "bias"]
+    assert tuple(sd["qweight"].shape) == g["fast_qweight"].shape and sd["qweight"].dtype == torch.int16
+    assert tuple(sd["scales"].shape) == g["fast_scales"].shape and sd["scales"].dtype == torch.float16
+    assert tuple(sd["qzeros"].shape) == g["fast_qzeros"].shape and sd["qzeros"].dtype == torch.float16
+    assert m.interleave == 4 and m.split_k_iters == 8
+    lin = torch.nn.Linear(K, N, bias=True).half()
+    lin.weight.data = torch.from_numpy(g["lin_weight"])
+    lin.bias.data = torch.from_numpy(g["bias"])
+    G = K // gs
+    scales = torch.from_numpy(g["gemv_scales"][:, :G].copy())
+    zeros = torch.from_numpy(g["z_int"].T.astype(np.float32).copy())
+    p = WQLinear_GEMVFast.from_linear(lin, 4, gs, False, scales, zeros)
+    assert np.array_equal(p.qweight.numpy(), g["fast_qweight"])
+    assert np.array_equal(p.scales.numpy().view(np.uint16), g["fast_scales"].view(np.uint16))
+    assert np.array_equal(p.qzeros.numpy().view(np.uint16), g["fast_qzeros"].view(np.uint16))
+    with pytest.raises(ValueError):
+        p(torch.randn(4, K))  # 3-D input required (gemv_fast.py:190)

@@ -529,3 +529,70 @@ def test_quant_fused_mlp_vs_oracle(ops, oracle, layout):
     assert (err <= 4e-3 * np.abs(y32) + 4e-3 * rms).all(), err.max() / rms
     rw = torch.tensor([[0.25], [0.5], [1.0]], dtype=torch.float16, device="cuda")
     assert torch.equal(mlp(x.cuda()[0], routing_weights=rw), rw * mlp(x.cuda()[0]))
+
+
+# ------------------------------------------------------------------ GEMVFast layout (WQLinear_GEMVFast)
+
+def gemvfast_case(K, N, g, M, seed):
+    from autoawq_amd.utils.packing import calculate_zeros_width
+
+    gen = torch.Generator().manual_seed(seed)
+    gp = calculate_zeros_width(K, g) * 8
+    G = K // g
+    qw = torch.randint(-32768, 32767, (N // 4, K), dtype=torch.int16, generator=gen)
+    sc = torch.zeros((gp, N), dtype=torch.float16)
+    sc[:G] = (torch.rand((G, N), generator=gen) * 0.02 + 0.005).half()
+    qz = torch.zeros((gp, N), dtype=torch.float16)
+    qz[:G] = -(sc[:G].float() * torch.randint(0, 16, (G, N), generator=gen).float()).half()
+    x = torch.randn((M, K), generator=gen).half()
+    return qw, sc, qz, x
+
+
+@pytest.mark.parametrize("name", ["packed_K512_N64_g128", "packed_K256_N32_g64", "packed_K128_N32_g32"])
+def test_gemvfast_layout_golden(ops, oracle, name):
+    g = golden(name)
+    gs = int(g["group_size"])
+    qw, sc, qz = dev(g["fast_qweight"]), dev(g["fast_scales"]), dev(g["fast_qzeros"])
+    W = oracle.dequant_gemvfast(g["fast_qweight"], g["fast_scales"], g["fast_qzeros"], gs)  # [K, N]
+    Wt = ops.dequantize_weights_gemv_fast(qw, sc, qz, gs)
+    assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
+    y = ops.gemv_fast_forward(dev(g["x"]), qw, sc, qz, gs).cpu().numpy().astype(np.float64)
+    y32, _ = oracle.matmul(g["x"], W)
+    assert_product_close(y, y32, f"{name} gemvfast", wsigma=oracle.weight_rounding_sigma(g["x"], W))
+
+
+@pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (11008, 4096, 128), (1024, 80, 64), (512, 48, 32), (2048, 208, 2048)])
+@pytest.mark.parametrize("M", [1, 3, 8, 16, 20])
+def test_gemvfast_layout_vs_oracle(ops, oracle, K, N, g, M):
+    if M > 3 and K * N > 4096 * 4096:
+        pytest.skip("large shapes are covered at small M")
+    qw, sc, qz, x = gemvfast_case(K, N, g, M, seed=K + N + M)
+    W = oracle.dequant_gemvfast(qw.numpy(), sc.numpy(), qz.numpy(), g)
+    Wt = ops.dequantize_weights_gemv_fast(qw.cuda(), sc.cuda(), qz.cuda(), g)
+    assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
+    y32, _ = oracle.matmul(x.numpy(), W)
+    wsig = oracle.weight_rounding_sigma(x.numpy(), W)
+    for flags in (0, ops.gemm_flags(waves=4, unit=8), ops.gemm_flags(waves=16, unit=4)):
+        y = ops.gemv_fast_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=flags)
+        assert ops.last_kernel() == "gemv_fast"
+        assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemvfast K{K} N{N} g{g} M{M}", wsigma=wsig)
+    e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    ks = (torch.arange(M, device="cuda") * 29 + 11) % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    assert torch.equal(ops.gemv_fast_forward(e, qw.cuda(), sc.cuda(), qz.cuda(), g), Wt.t()[ks])
+
+
+def test_gemvfast_module_forward(ops, oracle):
+    from autoawq_amd import WQLinear_GEMVFast
+
+    g = golden("packed_K512_N64_g128")
+    m = WQLinear_GEMVFast(4, 128, 512, 64, True, "cuda")
+    m.qweight, m.scales, m.qzeros, m.bias = (dev(g["fast_qweight"]), dev(g["fast_scales"]), dev(g["fast_qzeros"]),
+                                             dev(g["bias"]))
+    W = oracle.dequant_gemvfast(g["fast_qweight"], g["fast_scales"], g["fast_qzeros"], 128)
+    y32, _ = oracle.matmul(g["x"], W, g["bias"])
+    out = m(dev(g["x"]).view(4, 1, 512))
+    assert out.shape == (4, 1, 64) and out.dtype == torch.float16
+    ulp = np.maximum(np.abs(y32), 2.0 ** -14) * 2.0 ** -10
+    wsig = oracle.weight_rounding_sigma(g["x"], W)
+    assert (np.abs(out[:, 0].cpu().numpy().astype(np.float64) - y32) <= product_tol_(y32) + 6 * wsig + 2 * ulp).all()
