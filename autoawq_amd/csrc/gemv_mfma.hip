@@ -168,41 +168,64 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
 
     // ---- stage this block's activations, zeros and scales in LDS (block-cooperative, 16-byte
     // chunks): the K loop then uses the vector-memory path for packed weights ONLY.
-    {
-        const int xchunks = RS >> 3;  // 16-byte chunks per activation row
-        for (int c = tid; c < (M + 1) * xchunks; c += NTHR) {
-            const int m = c / xchunks, cc = c % xchunks;
-            const int row = r0 + 8 * cc;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (m < M && row < r1) {
-                int64_t xrow = m;
-                bool ok = true;
-                if constexpr (MOE) {  // gather: row m of the block is pair sorted_ids[16*tblk + m]
-                    const int pid = p.sorted_ids[16 * tblk + m];
-                    ok = pid < p.num_pairs;
-                    xrow = pid / p.x_div;
-                }
-                if (ok) v = *reinterpret_cast<const u32x4*>(p.x + xrow * p.K + row);
+    // Decode-sized blocks need at most one chunk of each kind per thread: those are REQUESTED here
+    // into registers and written to LDS only after the wave has issued its first unit of weight
+    // loads (below), so the staging round trip overlaps the weight stream instead of preceding it.
+    constexpr int QC = CW / 32;  // 16-byte chunks of packed zeros per group row of the tile
+    constexpr int SC = CW / 8;   // 16-byte chunks of scales per group row of the tile
+    const int xchunks = RS >> 3;  // 16-byte chunks per activation row
+    const bool reg_staged = (M + 1) * xchunks <= NTHR && ng * SC <= NTHR;
+    u32x4 st_x = {0u, 0u, 0u, 0u}, st_q = st_x, st_s = st_x;
+    auto x_chunk = [&](int c) -> u32x4 {
+        const int m = c / xchunks, cc = c % xchunks;
+        const int row = r0 + 8 * cc;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (m < M && row < r1) {
+            int64_t xrow = m;
+            bool ok = true;
+            if constexpr (MOE) {  // gather: row m of the block is pair sorted_ids[16*tblk + m]
+                const int pid = p.sorted_ids[16 * tblk + m];
+                ok = pid < p.num_pairs;
+                xrow = pid / p.x_div;
             }
-            *reinterpret_cast<u32x4*>(xs + (size_t)m * RS + 8 * cc) = v;
+            if (ok) v = *reinterpret_cast<const u32x4*>(p.x + xrow * p.K + row);
         }
-        constexpr int QC = CW / 32;  // 16-byte chunks of packed zeros per group row of the tile
-        for (int c = tid; c < ng * QC; c += NTHR) {
-            const int gl = c / QC, cc = c % QC;
-            const int w0 = tile * (CW / 8) + 4 * cc;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (w0 < NW) v = *reinterpret_cast<const u32x4*>(p.qzeros + (int64_t)(g0 + gl) * NW + w0);  // N % 32 == 0
-            *reinterpret_cast<u32x4*>(zq + gl * (CW / 8) + 4 * cc) = v;
-        }
-        constexpr int SC = CW / 8;  // 16-byte chunks of scales per group row of the tile
-        for (int c = tid; c < ng * SC; c += NTHR) {
-            const int gl = c / SC, cc = c % SC;
-            const int col = tile * CW + 8 * cc;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (col < p.N) v = *reinterpret_cast<const u32x4*>(p.scales + (int64_t)(g0 + gl) * p.N + col);
-            *reinterpret_cast<u32x4*>(zsc + gl * CW + 8 * cc) = v;
-        }
+        return v;
+    };
+    auto q_chunk = [&](int c) -> u32x4 {
+        const int gl = c / QC, cc = c % QC;
+        const int w0 = tile * (CW / 8) + 4 * cc;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (w0 < NW) v = *reinterpret_cast<const u32x4*>(p.qzeros + (int64_t)(g0 + gl) * NW + w0);  // N % 32 == 0
+        return v;
+    };
+    auto s_chunk = [&](int c) -> u32x4 {
+        const int gl = c / SC, cc = c % SC;
+        const int col = tile * CW + 8 * cc;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (col < p.N) v = *reinterpret_cast<const u32x4*>(p.scales + (int64_t)(g0 + gl) * p.N + col);
+        return v;
+    };
+    auto x_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(xs + (size_t)(c / xchunks) * RS + 8 * (c % xchunks)) = v; };
+    auto q_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(zq + (c / QC) * (CW / 8) + 4 * (c % QC)) = v; };
+    auto s_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(zsc + (c / SC) * CW + 8 * (c % SC)) = v; };
+    if (reg_staged) {
+        if (tid < (M + 1) * xchunks) st_x = x_chunk(tid);
+        if (tid < ng * QC) st_q = q_chunk(tid);
+        if (tid < ng * SC) st_s = s_chunk(tid);
+    } else {
+        for (int c = tid; c < (M + 1) * xchunks; c += NTHR) x_store(c, x_chunk(c));
+        for (int c = tid; c < ng * QC; c += NTHR) q_store(c, q_chunk(c));
+        for (int c = tid; c < ng * SC; c += NTHR) s_store(c, s_chunk(c));
     }
+    auto finish_staging = [&]() {
+        if (reg_staged) {
+            if (tid < (M + 1) * xchunks) x_store(tid, st_x);
+            if (tid < ng * QC) q_store(tid, st_q);
+            if (tid < ng * SC) s_store(tid, st_s);
+        }
+        __syncthreads();
+    };
 
     float yv[NACC][NA][NREG];
 #pragma unroll
@@ -241,8 +264,8 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
             }
             __builtin_amdgcn_sched_barrier(0);  // all requests are issued before anything is consumed
             if (u == wave) AWQ_STAMP(1);
-            if (!staged) {  // first unit: the staging stores above must be visible block-wide
-                __syncthreads();
+            if (!staged) {  // first unit: complete the staging, make it visible block-wide
+                finish_staging();
                 staged = true;
             }
 
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
             }
             if (u == wave) AWQ_STAMP(8);
         }
-        if (!staged) __syncthreads();  // waves without a unit still meet the staging barrier
+        if (!staged) finish_staging();  // waves without a unit still take part in the staging
     }
     __syncthreads();  // every wave is done with xs / zq / zsc: the LDS becomes red[]
     float* red = reinterpret_cast<float*>(smem);

@@ -192,7 +192,10 @@ def main():
                        "parallelism": f"tp{world}" if world > 1 else "single",
                        "algorithmic_bytes_per_step_all_ranks": bytes_all, "kernel": ops.last_kernel()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # HBM bytes per launch from the TCC fabric counters (own --pmc FETCH_SIZE pass,
+                         # x2 x 1024 per MI355X_MICROARCH.md; profiles/r01_pmc_fetch_size.txt), N=1 shapes
+                         "traffic": 26.980e6 if world == 1 and a.layers == LAYERS else None,
                          "bytes_per_launch": bytes_step / launches, "avg_launch_us": ms_step * 1e3 / launches,
                          "kernel": "awq_gemv_mfma_kernel (4 shapes per layer: qkv, o, gate+up, down)",
                          "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "
