@@ -61,3 +61,6 @@ int awq_launch_gemv_fast(const uint16_t* x, const int16_t* qweight, const uint16
                          uint16_t* y, int M, int K, int N, int g, int GP, int nwaves, int unroll, hipStream_t st);
 int awq_launch_dequant_fast(const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros, uint16_t* out, int K,
                             int N, int g, hipStream_t st);
+// MoE routing (softmax + top-k + block alignment) in one launch; T tokens, E <= 64 experts, k <= 8.
+int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int* sorted_ids, int* expert_ids,
+                         int* num_post_pad, int T, int E, int k, int renorm, int block, hipStream_t st);

@@ -161,6 +161,19 @@ int awq_silu_and_mul(const uint16_t* gate_up, uint16_t* out, int64_t rows, int64
     return awq_launch_silu_and_mul(gate_up, out, rows, d, static_cast<hipStream_t>(stream));
 }
 
+int awq_moe_route(const float* gating_logits, float* topk_weights, int32_t* topk_ids, int32_t* sorted_token_ids,
+                  int32_t* expert_ids, int32_t* num_tokens_post_padded, int64_t num_tokens, int64_t num_experts,
+                  int64_t topk, int renormalize, int64_t block_rows, void* stream) {
+    if (num_tokens < 0 || num_experts < 1 || topk < 1 || block_rows < 1) return AWQ_ERR_BAD_SHAPE;
+    if (num_tokens == 0) return AWQ_OK;
+    if (!gating_logits || !topk_weights || !topk_ids || !sorted_token_ids || !expert_ids || !num_tokens_post_padded)
+        return AWQ_ERR_NULL;
+    if (num_tokens * topk > (1 << 24)) return AWQ_ERR_UNSUPPORTED;
+    return awq_launch_moe_route(gating_logits, topk_weights, topk_ids, sorted_token_ids, expert_ids,
+                                num_tokens_post_padded, (int)num_tokens, (int)num_experts, (int)topk, renormalize,
+                                (int)block_rows, static_cast<hipStream_t>(stream));
+}
+
 size_t awq_grouped_gemm_workspace_bytes(int64_t max_blocks, int64_t K, int64_t N) {
     if (max_blocks <= 0 || K <= 0 || N <= 0) return 0;
     return awq_grouped_workspace_bytes_impl((int)max_blocks, (int)K, (int)N);
@@ -169,10 +182,11 @@ size_t awq_grouped_gemm_workspace_bytes(int64_t max_blocks, int64_t K, int64_t N
 int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                              uint16_t* y, const int32_t* sorted_token_ids, const int32_t* expert_ids,
                              const int32_t* num_tokens_post_padded, const float* pair_weights, int64_t num_pairs,
-                             int64_t x_div, int64_t max_blocks, int64_t num_experts, int64_t K, int64_t N,
-                             int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
+                             int64_t x_div, int64_t block_rows, int64_t max_blocks, int64_t num_experts, int64_t K,
+                             int64_t N, int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_gemm_layout(K, N, group_size);
     if (rc) return rc;
+    if (!(block_rows == 8 || block_rows == 16)) return AWQ_ERR_BAD_SHAPE;
     if (num_pairs < 0 || x_div < 1 || max_blocks < 0 || num_experts < 1) return AWQ_ERR_BAD_SHAPE;
     if (num_pairs == 0 || max_blocks == 0 || N == 0) return AWQ_OK;
     if (!x || !qweight || !scales || !qzeros || !y || !sorted_token_ids || !expert_ids || !num_tokens_post_padded)
@@ -183,7 +197,7 @@ int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweight, const ui
     if ((int64_t)K * N / 2 >= ((int64_t)1 << 31)) return AWQ_ERR_UNSUPPORTED;
     AwqGemmArgs a;
     a.x = x; a.qweight = qweight; a.scales = scales; a.qzeros = qzeros; a.bias = nullptr; a.y = y;
-    a.M = 16; a.K = (int)K; a.N = (int)N; a.g = (int)group_size;
+    a.M = (int)block_rows; a.K = (int)K; a.N = (int)N; a.g = (int)group_size;
     a.stream = static_cast<hipStream_t>(stream);
     a.counters = nullptr; a.partial = nullptr; a.partial_floats = 0; a.exchange = nullptr; a.exchange_bytes = 0;
     if (workspace && workspace_bytes > AWQ_WS_COUNTER_BYTES) {  // [control][exchange]: no scratch half here

@@ -37,3 +37,94 @@ int awq_launch_silu_and_mul(const uint16_t* in, uint16_t* out, int64_t rows, int
                        reinterpret_cast<const half_t*>(in), reinterpret_cast<half_t*>(out), rows, D);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
+
+// ---- MoE routing in ONE launch: softmax + top-k (+ renormalise) + block alignment.
+//
+// Replaces awq_ext.topk_softmax + awq_ext.moe_alig_block_size (awq/modules/fused/moe.py:94-171,
+// two kernels plus ~20 torch glue kernels in the sync-free torch restatement) for decode-sized
+// batches: the whole routing state of a step fits one workgroup.  Semantics: routing weights =
+// softmax(logits.float()) in fp32, top-k by value (lowest index first on ties), optional
+// renormalisation; sorted_token_ids = pair indices grouped by expert in pair order, each expert's
+// run padded to a multiple of `block` with the sentinel num_pairs; expert_ids[b] = expert of block b.
+namespace {
+constexpr int ROUTE_MAX_E = 64, ROUTE_MAX_K = 8;
+
+__global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restrict__ logits, float* __restrict__ topk_w,
+                                                           int* __restrict__ topk_ids, int* __restrict__ sorted_ids,
+                                                           int* __restrict__ expert_ids, int* __restrict__ num_post_pad,
+                                                           int T, int E, int k, int renorm, int block, int cap_sorted,
+                                                           int cap_blocks) {
+    __shared__ int counts[ROUTE_MAX_E], pad_start[ROUTE_MAX_E + 1];
+    const int tid = threadIdx.x;
+    const int P = T * k;
+    if (tid < E) counts[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+        float v[ROUTE_MAX_E];
+        float mx = -INFINITY;
+        for (int e = 0; e < E; ++e) {
+            v[e] = logits[(int64_t)t * E + e];
+            mx = fmaxf(mx, v[e]);
+        }
+        float sum = 0.f;
+        for (int e = 0; e < E; ++e) {
+            v[e] = expf(v[e] - mx);
+            sum += v[e];
+        }
+        const float inv = 1.0f / sum;
+        float wsel[ROUTE_MAX_K];
+        int isel[ROUTE_MAX_K];
+        float wsum = 0.f;
+        for (int j = 0; j < k; ++j) {
+            int best = 0;
+            float bv = -1.f;
+            for (int e = 0; e < E; ++e)
+                if (v[e] > bv) {
+                    bv = v[e];
+                    best = e;
+                }
+            v[best] = -2.f;  // taken
+            wsel[j] = bv * inv;
+            isel[j] = best;
+            wsum += wsel[j];
+            atomicAdd(&counts[best], 1);
+        }
+        for (int j = 0; j < k; ++j) {
+            topk_w[(int64_t)t * k + j] = renorm ? wsel[j] / wsum : wsel[j];
+            topk_ids[(int64_t)t * k + j] = isel[j];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int e = 0; e < E; ++e) {
+            pad_start[e] = pos;
+            pos += (counts[e] + block - 1) / block * block;
+        }
+        pad_start[E] = pos;
+        *num_post_pad = pos;
+    }
+    __syncthreads();
+    for (int i = tid; i < cap_sorted; i += 256) sorted_ids[i] = P;
+    for (int b = tid; b < cap_blocks; b += 256) {
+        int e = 0;
+        while (e < E - 1 && b * block >= pad_start[e + 1]) ++e;
+        expert_ids[b] = e;
+    }
+    __syncthreads();  // the fill above and the id tables written in phase 1 are visible to the block
+    if (tid < E) {  // stable placement: one thread per expert walks the pairs in order
+        int pos = pad_start[tid];
+        for (int p = 0; p < P; ++p)
+            if (topk_ids[p] == tid) sorted_ids[pos++] = p;
+    }
+}
+}  // namespace
+
+int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int* sorted_ids, int* expert_ids,
+                         int* num_post_pad, int T, int E, int k, int renorm, int block, hipStream_t st) {
+    if (T < 1 || E < 1 || E > ROUTE_MAX_E || k < 1 || k > ROUTE_MAX_K || k > E || block < 1) return AWQ_ERR_UNSUPPORTED;
+    const int P = T * k;
+    hipLaunchKernelGGL(awq_moe_route_kernel, dim3(1), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,
+                       num_post_pad, T, E, k, renorm, block, P + E * (block - 1), P + E);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}

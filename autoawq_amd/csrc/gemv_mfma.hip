@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     const int tile = blockIdx.x % p.tiles, slice = (blockIdx.x / p.tiles) % p.S;
     const int tblk = MOE ? blockIdx.x / (p.tiles * p.S) : 0;  // 16-row token block (grouped mode)
     if constexpr (MOE) {
-        if (16 * tblk >= *p.num_post_pad) return;  // uniform for every block of this token block
+        if (p.M * tblk >= *p.num_post_pad) return;  // uniform for every block of this token block (p.M rows each)
         const int64_t e = p.expert_ids[tblk];
         p.qweight += e * p.expert_qw_words;
         p.qzeros += e * p.expert_z_words;
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         if (m < M && row < r1) {
             int64_t xrow = m;
             bool ok = true;
-            if constexpr (MOE) {  // gather: row m of the block is pair sorted_ids[16*tblk + m]
-                const int pid = p.sorted_ids[16 * tblk + m];
+            if constexpr (MOE) {  // gather: row m of the block is pair sorted_ids[M*tblk + m]
+                const int pid = p.sorted_ids[p.M * tblk + m];
                 ok = pid < p.num_pairs;
                 xrow = pid / p.x_div;
             }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         if (col >= p.N) return;  // N % 8 == 0: a quad is all in or all out
         int64_t orow = m;
         if constexpr (MOE) {  // scatter to the pair's row, optionally scaled by its routing weight
-            const int pid = p.sorted_ids[16 * tblk + m];
+            const int pid = p.sorted_ids[p.M * tblk + m];
             if (pid >= p.num_pairs) return;
             orow = pid;
             if (p.pair_weights) s *= p.pair_weights[pid];
@@ -607,21 +607,22 @@ bool gemv_config(const AwqGemmArgs& a, bool two_pass, GemvCfg& c) {
 }  // namespace
 
 namespace {
-template <int UNIT>
+template <int UNIT, bool SEL>
 void launch_moe(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
     static const bool lds_opt_in = [] {
         (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<2, 4, UNIT, false, 4, 1, true, true>),
+            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)lds_opt_in;
-    hipLaunchKernelGGL((awq_gemv_mfma_kernel<2, 4, UNIT, false, 4, 1, true, true>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true>), grid, dim3(256), lds, st, p);
 }
 }  // namespace
 
-// Grouped (MoE) GEMM: `max_blocks` 16-row token blocks, block b multiplies the gathered rows
-// sorted_ids[16b .. 16b+15] with expert expert_ids[b]'s weights; blocks past *num_post_pad exit.
+// Grouped (MoE) GEMM: `max_blocks` token blocks of a.M (8 or 16) rows, block b multiplies the gathered
+// rows sorted_ids[M*b .. M*b+M-1] with expert expert_ids[b]'s weights; blocks past *num_post_pad exit.
+// 8-row blocks use the selector-row kernel (one MFMA per fragment): the decode case.
 size_t awq_grouped_workspace_bytes_impl(int max_blocks, int K, int N) {
     (void)K;
     const size_t tiles = (size_t)(N + 255) / 256;
@@ -631,8 +632,8 @@ size_t awq_grouped_workspace_bytes_impl(int max_blocks, int K, int N) {
 int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const int* expert_ids, const int* num_post_pad,
                             const float* pair_weights, int num_pairs, int x_div, int max_blocks, int64_t expert_qw_words,
                             int64_t expert_z_words, int64_t expert_s_halfs) {
-    if (a.M != 16 || max_blocks < 1) return AWQ_ERR_BAD_SHAPE;
-    if (!awq_gemv_mfma_supports(16, a.K, a.N, a.g, 2) || a.g % 32) return AWQ_ERR_UNSUPPORTED;
+    if (!(a.M == 16 || a.M == 8) || max_blocks < 1) return AWQ_ERR_BAD_SHAPE;
+    if (!awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2) || a.g % 32) return AWQ_ERR_UNSUPPORTED;
     GemvCfg c{2, 4, 0, 0, 0, 0, 0};
     AwqGemmArgs probe = a;
     probe.exchange_bytes = (size_t)-1 >> 1;  // the split is bounded below instead
@@ -650,13 +651,13 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
         const int upb = (units + S - 1) / S;
         c.rows_per_block = upb * 16 * c.unit;
         c.ng_max = c.rows_per_block / a.g + 2;
-        c.lds = gemv_lds_bytes(16, CW, 4, c.rows_per_block, c.ng_max);
+        c.lds = gemv_lds_bytes(a.M, CW, 4, c.rows_per_block, c.ng_max);
         c.S = (units + upb - 1) / upb;
         if (c.lds <= 160 * 1024) break;
         if (S >= units || S >= 64) return AWQ_ERR_UNSUPPORTED;
     }
     if (c.S > 1) {
-        const size_t need = (size_t)max_blocks * (c.S - 1) * tiles * 16 * CW * sizeof(float);
+        const size_t need = (size_t)max_blocks * (c.S - 1) * tiles * a.M * CW * sizeof(float);
         if (!a.exchange || !a.counters || a.exchange_bytes < need) return AWQ_ERR_WORKSPACE;
     }
     GemvMfmaParams p;
@@ -666,7 +667,7 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     p.x = reinterpret_cast<const half_t*>(a.x);
     p.bias = nullptr;
     p.y = reinterpret_cast<half_t*>(a.y);
-    p.M = 16; p.K = a.K; p.N = a.N; p.g = a.g;
+    p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
     p.tiles = tiles; p.S = c.S;
     p.rows_per_block = c.rows_per_block;
     p.ng_max = c.ng_max;
@@ -679,9 +680,15 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     p.num_pairs = num_pairs; p.x_div = x_div;
     p.expert_qw_words = expert_qw_words; p.expert_z_words = expert_z_words; p.expert_s_halfs = expert_s_halfs;
     dim3 grid((unsigned)(tiles * c.S * max_blocks));
-    if (c.unit == 2) launch_moe<2>(p, grid, c.lds, a.stream);
-    else if (c.unit == 4) launch_moe<4>(p, grid, c.lds, a.stream);
-    else launch_moe<8>(p, grid, c.lds, a.stream);
+    if (a.M == 8) {
+        if (c.unit == 2) launch_moe<2, true>(p, grid, c.lds, a.stream);
+        else if (c.unit == 4) launch_moe<4, true>(p, grid, c.lds, a.stream);
+        else launch_moe<8, true>(p, grid, c.lds, a.stream);
+    } else {
+        if (c.unit == 2) launch_moe<2, false>(p, grid, c.lds, a.stream);
+        else if (c.unit == 4) launch_moe<4, false>(p, grid, c.lds, a.stream);
+        else launch_moe<8, false>(p, grid, c.lds, a.stream);
+    }
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

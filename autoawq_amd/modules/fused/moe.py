@@ -15,7 +15,9 @@ import torch
 
 from ... import ops
 
-BLOCK_ROWS = 16  # token rows per grouped-GEMM block (moe.py:55: moe_align_block_size(topk_ids, 16, E))
+BLOCK_ROWS = 16        # token rows per grouped-GEMM block (moe.py:55: moe_align_block_size(topk_ids, 16, E))
+DECODE_BLOCK_ROWS = 8  # decode-sized batches: 8-row blocks run the selector-row kernel (one MFMA per fragment)
+DECODE_MAX_PAIRS = 64
 
 
 class FusedSparseMoeBlock(torch.nn.Module):
@@ -36,17 +38,23 @@ class FusedSparseMoeBlock(torch.nn.Module):
 
 def apply_moe_weights(w1: Dict[str, torch.Tensor], w2: Dict[str, torch.Tensor], x: torch.Tensor,
                       gating_output: torch.Tensor, topk: int, renormalize: bool) -> torch.Tensor:
-    topk_weights, topk_ids = fused_topk(gating_output, topk, renormalize)
-    sorted_token_ids, expert_ids, num_tokens_post_padded = moe_align_block_size(topk_ids, BLOCK_ROWS, w1.qweight.shape[0])
+    num_experts = w1.qweight.shape[0]
+    rows = DECODE_BLOCK_ROWS if x.shape[0] * topk <= DECODE_MAX_PAIRS else BLOCK_ROWS
+    if num_experts <= 64 and topk <= 8 and x.shape[0] <= 1024:  # one-launch routing
+        topk_weights, topk_ids, sorted_token_ids, expert_ids, num_tokens_post_padded = ops.moe_route(
+            gating_output, topk, renormalize, rows)
+    else:
+        topk_weights, topk_ids = fused_topk(gating_output, topk, renormalize)
+        sorted_token_ids, expert_ids, num_tokens_post_padded = moe_align_block_size(topk_ids, rows, num_experts)
     in_dtype = x.dtype
     xh = x.half() if in_dtype != torch.float16 else x
     xh = xh.view(xh.shape[0], 1, *xh.shape[1:])
     gate_up = ops.grouped_gemm_forward(xh, w1.qweight, w1.scales, w1.qzeros, topk_weights, sorted_token_ids, expert_ids,
-                                       num_tokens_post_padded, False, 8)
+                                       num_tokens_post_padded, False, 8, block_rows=rows)
     out = torch.empty((gate_up.shape[:-1] + (gate_up.shape[-1] // 2,)), dtype=torch.float16, device=x.device)
     ops.silu_and_mul(gate_up, out)
     out = ops.grouped_gemm_forward(out, w2.qweight, w2.scales, w2.qzeros, topk_weights, sorted_token_ids, expert_ids,
-                                   num_tokens_post_padded, True, 8)
+                                   num_tokens_post_padded, True, 8, block_rows=rows)
     out = torch.sum(out, dim=1)
     return out.to(in_dtype) if in_dtype != torch.float16 else out
 

@@ -180,10 +180,11 @@ _moe_workspaces = {}
 
 
 def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_ids, expert_ids,
-                         num_tokens_post_padded, mul_weights, split_k_iters=8):
+                         num_tokens_post_padded, mul_weights, split_k_iters=8, block_rows=16):
     """awq_ext.grouped_gemm_forward semantics (awq/modules/fused/moe.py:60-89): x [T, 1 | topk, K] fp16,
     stacked GEMM-layout expert tensors [E, ...]; returns [T, topk, N] fp16.  Nothing is read back
-    to the host: the routing tensors are consumed on the device."""
+    to the host: the routing tensors are consumed on the device.  block_rows = the block size the
+    routing tensors were aligned with (16 like the reference, or 8: decode-sized batches)."""
     _require_gpu(x, qweight, scales, qzeros, topk_weights, sorted_token_ids, expert_ids, num_tokens_post_padded)
     T, topk = topk_weights.shape
     E, K, NW = qweight.shape
@@ -209,10 +210,29 @@ def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_
         w = topk_weights.contiguous().float() if mul_weights else None
         rc = L.awq_grouped_gemm_forward(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y),
                                         _ptr(sorted_token_ids), _ptr(expert_ids), _ptr(num_tokens_post_padded),
-                                        _ptr(w), T * topk, x_div, max_blocks, E, K, N, K // G, _ptr(ws), ws.numel(),
+                                        _ptr(w), T * topk, x_div, block_rows, max_blocks, E, K, N, K // G, _ptr(ws),
+                                        ws.numel(),
                                         _stream())
     _lib.check(rc, "awq_grouped_gemm_forward")
     return y
+
+
+def moe_route(gating_output, topk, renormalize, block_size):
+    """softmax + top-k (+ renormalise) + block alignment in ONE launch (awq_moe_route): returns
+    (topk_weights [T, k] fp32, topk_ids [T, k] i32, sorted_token_ids, expert_ids, num_tokens_post_padded)."""
+    _require_gpu(gating_output)
+    g = gating_output.float().contiguous()
+    T, E = g.shape
+    dev = g.device
+    w = torch.empty((T, topk), dtype=torch.float32, device=dev)
+    ids = torch.empty((T, topk), dtype=torch.int32, device=dev)
+    sorted_ids = torch.empty((T * topk + E * (block_size - 1),), dtype=torch.int32, device=dev)
+    expert_ids = torch.empty((T * topk + E,), dtype=torch.int32, device=dev)
+    npad = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().awq_moe_route(_ptr(g), _ptr(w), _ptr(ids), _ptr(sorted_ids), _ptr(expert_ids), _ptr(npad), T, E,
+                                            topk, 1 if renormalize else 0, block_size, _stream()), "awq_moe_route")
+    return w, ids, sorted_ids, expert_ids, npad
 
 
 def moe_align_block_size(topk_ids, block_size, num_experts):
@@ -222,7 +242,8 @@ def moe_align_block_size(topk_ids, block_size, num_experts):
     flat = topk_ids.reshape(-1).to(torch.int64)
     numel = flat.numel()
     dev = flat.device
-    counts = torch.bincount(flat, minlength=num_experts)[:num_experts]
+    # one-hot sum instead of torch.bincount: bincount reads its output size back to the host
+    counts = (flat.unsqueeze(1) == torch.arange(num_experts, device=dev).unsqueeze(0)).sum(0)
     padded = (counts + block_size - 1) // block_size * block_size
     pad_end = torch.cumsum(padded, 0)
     pad_start = pad_end - padded

@@ -32,6 +32,23 @@ def algorithmic_bytes(K, N, M, g, bias=False):
     return K * N // 2 + (K // g) * (N // 8) * 4 + (K // g) * N * 2 + M * K * 2 + M * N * 2 + (N * 2 if bias else 0)
 
 
+def rand_packed_nk(K, N, g, dev, gen, fast=False):
+    """Random buffers in the GEMV (qweight [N, K/8]) or GEMVFast (int16 [N/4, K]) layout."""
+    from autoawq_amd.utils.packing import calculate_zeros_width
+
+    lim = 0x7FFFFFFF
+    zw = calculate_zeros_width(K, g)
+    if fast:
+        qw = torch.randint(-32768, 32767, (N // 4, K), dtype=torch.int16, device=dev, generator=gen)
+        sc = (torch.rand((zw * 8, N), device=dev, generator=gen) * 0.02 + 0.005).half()
+        qz = -(sc.float() * torch.randint(0, 16, (zw * 8, N), device=dev, generator=gen).float()).half()
+        return qw, qz, sc
+    qw = torch.randint(-lim - 1, lim, (N, K // 8), dtype=torch.int32, device=dev, generator=gen)
+    qz = torch.randint(-lim - 1, lim, (N, zw), dtype=torch.int32, device=dev, generator=gen)
+    sc = (torch.rand((N, zw * 8), device=dev, generator=gen) * 0.02 + 0.005).half()
+    return qw, qz, sc
+
+
 def rand_packed(K, N, g, dev, gen):
     lim = 0x7FFFFFFF
     qw = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, device=dev, generator=gen)
@@ -40,7 +57,7 @@ def rand_packed(K, N, g, dev, gen):
     return qw, qz, sc
 
 
-def build_model(dev, rank, world, layers, seed=1234):
+def build_model(dev, rank, world, layers, seed=1234, layout="gemm"):
     """Per-rank shard shapes: column split of qkv / gate+up, whole-group row split of o / down."""
     from autoawq_amd.tp import split_even_units
 
@@ -55,9 +72,13 @@ def build_model(dev, rank, world, layers, seed=1234):
     for _ in range(layers):
         layer = []
         for name, K, N, reduce_after in shapes:
-            qw, qz, sc = rand_packed(K, N, GROUP, dev, gen)
+            if layout == "gemm":
+                qw, qz, sc = rand_packed(K, N, GROUP, dev, gen)
+            else:
+                qw, qz, sc = rand_packed_nk(K, N, GROUP, dev, gen, fast=(layout == "gemvfast"))
             x = torch.randn((1, K), device=dev, generator=gen).half()
-            layer.append(dict(name=name, K=K, N=N, qw=qw, qz=qz, sc=sc, x=x, reduce=reduce_after and world > 1))
+            layer.append(dict(name=name, K=K, N=N, qw=qw, qz=qz, sc=sc, x=x, reduce=reduce_after and world > 1,
+                              layout=layout))
         model.append(layer)
     return model, shapes
 
@@ -66,7 +87,12 @@ def run_step(model, outs, ops, dist):
     i = 0
     for layer in model:
         for lin in layer:
-            y = ops.gemm_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"])
+            if lin["layout"] == "gemm":
+                y = ops.gemm_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"])
+            elif lin["layout"] == "gemv":
+                y = ops.gemv_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"], GROUP)
+            else:
+                y = ops.gemv_fast_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"], GROUP)
             if lin["reduce"]:
                 dist.all_reduce(y)
             outs[i] = y
@@ -105,6 +131,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--layers", type=int, default=LAYERS, help="debug only; the metric is quoted at 32")
+    ap.add_argument("--layout", choices=["gemm", "gemv", "gemvfast"], default="gemm",
+                    help="checkpoint format of the Linears: WQLinear_GEMM (default) / _GEMV / _GEMVFast buffers")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -127,10 +155,14 @@ def main():
     from autoawq_amd import _lib, ops
 
     _lib.lib()
-    model, shapes = build_model(dev, rank, world, a.layers)
+    if world > 1 and a.layout != "gemm":
+        raise SystemExit("tensor-parallel shards are implemented for the GEMM layout")
+    model, shapes = build_model(dev, rank, world, a.layers, layout=a.layout)
     nl = sum(len(l) for l in model)
     outs = [None] * nl
     bytes_step = sum(algorithmic_bytes(l["K"], l["N"], 1, GROUP) for layer in model for l in layer)
+    if a.layout == "gemvfast":  # zeros are stored as fp16 -(s*z): 2 bytes instead of half a byte per (group, column)
+        bytes_step += sum((l["K"] // GROUP) * l["N"] * 3 // 2 for layer in model for l in layer)
 
     stream = torch.cuda.Stream(device=dev)
     graph, used_graph = None, False
@@ -188,14 +220,14 @@ def main():
             "dtype": "int4 weights x fp16 activations, fp32 accumulate", "data": "synthetic",
             "config": {"workload": "Llama-2-7B-shape AWQ int4 g128, GEMV bs=1 decode: 32 layers x "
                                    "{qkv 4096->12288, o 4096->4096, gate+up 4096->22016, down 11008->4096}",
-                       "layers": a.layers, "launches_per_step": launches, "hipgraph": used_graph,
+                       "layers": a.layers, "launches_per_step": launches, "hipgraph": used_graph, "layout": a.layout,
                        "parallelism": f"tp{world}" if world > 1 else "single",
                        "algorithmic_bytes_per_step_all_ranks": bytes_all, "kernel": ops.last_kernel()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # HBM bytes per launch from the TCC fabric counters (own --pmc FETCH_SIZE pass,
                          # x2 x 1024 per MI355X_MICROARCH.md; profiles/r01_pmc_fetch_size.txt), N=1 shapes
-                         "traffic": 26.980e6 if world == 1 and a.layers == LAYERS else None,
+                         "traffic": 26.980e6 if world == 1 and a.layers == LAYERS and a.layout == "gemm" else None,
                          "bytes_per_launch": bytes_step / launches, "avg_launch_us": ms_step * 1e3 / launches,
                          "kernel": "awq_gemv_mfma_kernel (4 shapes per layer: qkv, o, gate+up, down)",
                          "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "

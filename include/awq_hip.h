@@ -99,11 +99,21 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
  * gate_up [rows, 2d] fp16 = [gate | up], out [rows, d] = silu(gate) * up. */
 AWQ_EXPORT int awq_silu_and_mul(const uint16_t* gate_up, uint16_t* out, int64_t rows, int64_t d, void* stream);
 
+/* Replaces awq_ext.topk_softmax + awq_ext.moe_alig_block_size (moe.py:94-171) in one launch:
+ * gating_logits [T, E] fp32 -> topk_weights [T, k] fp32 (softmax, optionally renormalised),
+ * topk_ids [T, k], sorted_token_ids [T*k + E*(block_rows-1)] (sentinel T*k), expert_ids [T*k + E],
+ * num_tokens_post_padded [1].  E <= 64, k <= 8. */
+AWQ_EXPORT int awq_moe_route(const float* gating_logits, float* topk_weights, int32_t* topk_ids,
+                             int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_padded,
+                             int64_t num_tokens, int64_t num_experts, int64_t topk, int renormalize,
+                             int64_t block_rows, void* stream);
+
 /* Replaces awq_ext.grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_ids,
  * expert_ids, num_tokens_post_padded, mul_weights, split_k_iters) (moe.py:60-89).
  * qweight [E, K, N/8], qzeros [E, K/g, N/8], scales [E, K/g, N]; sorted_token_ids / expert_ids /
- * num_tokens_post_padded as produced by moe_align_block_size with block 16 (moe.py:94-134), all on
- * the device (no host read: capturable).  Row i of y [num_pairs, N] (pair = token*topk + slot) =
+ * num_tokens_post_padded as produced by moe_align_block_size with block `block_rows` = 16 (the
+ * reference's value, moe.py:55) or 8 (decode: selector-row MFMA kernel), all on the device (no host
+ * read: capturable).  Row i of y [num_pairs, N] (pair = token*topk + slot) =
  * x[i / x_div] @ W[expert of pair i], times pair_weights[i] if that pointer is non-NULL.
  * max_blocks = capacity of expert_ids in 16-row blocks; the workspace is prepared once with
  * awq_gemm_workspace_init like a GEMM workspace. */
@@ -112,7 +122,7 @@ AWQ_EXPORT int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweigh
                                         const int32_t* qzeros, uint16_t* y, const int32_t* sorted_token_ids,
                                         const int32_t* expert_ids, const int32_t* num_tokens_post_padded,
                                         const float* pair_weights, int64_t num_pairs, int64_t x_div,
-                                        int64_t max_blocks, int64_t num_experts, int64_t K, int64_t N,
+                                        int64_t block_rows, int64_t max_blocks, int64_t num_experts, int64_t K, int64_t N,
                                         int64_t group_size, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- GEMV layout: qweight [N, K/8] i32 (ordinal nibbles), qzeros [N, ZW] i32, scales [N, 8*ZW] f16

@@ -438,8 +438,9 @@ def stacked_experts(E, K, N, g, seed):
     return qw, qz, sc
 
 
+@pytest.mark.parametrize("rows", [8, 16])
 @pytest.mark.parametrize("T,E,topk,K,N", [(4, 8, 2, 256, 512), (1, 8, 2, 512, 256), (19, 4, 2, 256, 1024), (40, 8, 2, 128, 256)])
-def test_grouped_gemm_vs_oracle(ops, oracle, T, E, topk, K, N):
+def test_grouped_gemm_vs_oracle(ops, oracle, T, E, topk, K, N, rows):
     """grouped_gemm_forward (moe.py:60-89): every (token, slot) pair against its own expert."""
     g = 128
     qw, qz, sc = stacked_experts(E, K, N, g, seed=T + E + K)
@@ -447,10 +448,12 @@ def test_grouped_gemm_vs_oracle(ops, oracle, T, E, topk, K, N):
     x = torch.randn((T, K), generator=gen).half()
     logits = torch.randn((T, E), generator=gen)
     w, ids = ops.fused_topk(logits.cuda(), topk, True)
-    s_ids, e_ids, npad = ops.moe_align_block_size(ids, 16, E)
-    y = ops.grouped_gemm_forward(x.cuda().view(T, 1, K), qw.cuda(), sc.cuda(), qz.cuda(), w, s_ids, e_ids, npad, False)
+    s_ids, e_ids, npad = ops.moe_align_block_size(ids, rows, E)
+    y = ops.grouped_gemm_forward(x.cuda().view(T, 1, K), qw.cuda(), sc.cuda(), qz.cuda(), w, s_ids, e_ids, npad, False,
+                                 block_rows=rows)
     assert y.shape == (T, topk, N) and ops.last_kernel() == "gemv_mfma_grouped"
-    y2 = ops.grouped_gemm_forward(x.cuda().view(T, 1, K), qw.cuda(), sc.cuda(), qz.cuda(), w, s_ids, e_ids, npad, True)
+    y2 = ops.grouped_gemm_forward(x.cuda().view(T, 1, K), qw.cuda(), sc.cuda(), qz.cuda(), w, s_ids, e_ids, npad, True,
+                                  block_rows=rows)
     idc, wc = ids.cpu().numpy(), w.cpu().numpy()
     for t in range(T):
         for j in range(topk):
@@ -596,3 +599,20 @@ def test_gemvfast_module_forward(ops, oracle):
     ulp = np.maximum(np.abs(y32), 2.0 ** -14) * 2.0 ** -10
     wsig = oracle.weight_rounding_sigma(g["x"], W)
     assert (np.abs(out[:, 0].cpu().numpy().astype(np.float64) - y32) <= product_tol_(y32) + 6 * wsig + 2 * ulp).all()
+
+
+@pytest.mark.parametrize("T,E,k,blk", [(4, 8, 2, 8), (1, 8, 2, 16), (37, 8, 2, 16), (64, 16, 4, 16), (200, 64, 8, 8), (5, 3, 1, 4)])
+def test_moe_route_kernel_vs_torch_and_oracle(ops, oracle, T, E, k, blk):
+    """one-launch routing == softmax/topk (torch, the reference's ROCm branch moe.py:152-156) + the
+    oracle's moe_align restatement."""
+    logits = torch.randn((T, E), generator=torch.Generator().manual_seed(T + E)) * 2
+    w, ids, s_ids, e_ids, npad = ops.moe_route(logits.cuda(), k, True, blk)
+    tw, ti = ops.fused_topk(logits.cuda(), k, True)
+    assert torch.equal(ids, ti)
+    assert torch.allclose(w, tw, rtol=1e-5, atol=1e-7)
+    ws, we, wn = oracle.moe_align(ids.cpu().numpy(), E, blk)
+    assert int(npad) == wn
+    assert np.array_equal(s_ids.cpu().numpy(), ws)
+    assert np.array_equal(e_ids.cpu().numpy()[: wn // blk], we[: wn // blk])
+    w2, _, _, _, _ = ops.moe_route(logits.cuda(), k, False, blk)
+    assert torch.allclose(w2, torch.topk(torch.softmax(logits.float(), -1), k, -1)[0].cuda(), rtol=1e-5, atol=1e-7)
