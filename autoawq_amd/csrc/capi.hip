@@ -144,7 +144,7 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
         }
         case AWQ_GEMM_KERNEL_TILED: {
             g_last_kernel = "gemm_tiled";
-            return awq_launch_gemm_tiled(a, nlog == 2 ? 256 : (nlog == 1 ? 128 : 0));
+            return awq_launch_gemm_tiled(a, nlog == 2 ? 256 : (nlog == 1 ? 128 : 0), splitk);
         }
         default:
             return AWQ_ERR_UNSUPPORTED;

@@ -13,7 +13,7 @@
 // ((w - z) * s with one rounding, awq/utils/packing_utils.py:98-100) and multiplied with fp32
 // accumulation by v_mfma_f32_16x16x32_f16 -- the same arithmetic as dequant + fp16 GEMM.
 //
-// Structure (block = 128 x BN output tile, 4 waves as 2 x 2, K step 64, LDS double buffered)
+// Structure (block = BM x BN output tile, BM in {32, 64, 128}, 4 waves, K step 64, LDS double buffered)
 //   * A (activations): global 16-byte loads -> registers -> LDS rows of 72 halfs (144 B pitch:
 //     conflict-free ds_read_b64 of MFMA A fragments, 16-byte aligned ds_write_b128).
 //   * B (weights): each thread owns ONE packed word column and 4 rows of the K step; the word is
@@ -38,12 +38,15 @@ struct TiledParams {
     half_t* y;
     int M, K, N, g;
     int tiles_m, tiles_n;
+    int S, steps_per_slice;  // split-K: K steps [slice*steps_per_slice, ...) per block
+    float* slabs;            // exchange region [S-1][tiles][4 waves][4*NT][64 lanes] float4, sentinel-filled
+    int* err;
 };
 
 typedef short short4_t __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-constexpr int BM = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int APITCH = BK + 8;  // halfs per A row in LDS (144 bytes)
 constexpr uint32_t OOB = 0x80000000u;
 
@@ -55,10 +58,16 @@ AWQ_DEV float4_t mfma16(half8_t a, half8_t b, float4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int BN>
+// BM x BN output tile per block; the 4 waves are laid out 2 x 2 for BM = 128 and 1 x 4 below.
+template <int BM, int BN, bool SPLITK>
 __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
-    constexpr int WN = BN / 2;         // columns per wave
-    constexpr int NT = WN / 16;        // 16-column MFMA tiles per wave
+    constexpr int WGM = BM >= 128 ? 2 : 1;  // waves along M
+    constexpr int WGN = 4 / WGM;            // waves along N
+    constexpr int WM = BM / WGM;            // rows per wave
+    constexpr int MI = WM / 16;             // 16-row MFMA tiles per wave
+    constexpr int WN = BN / WGN;            // columns per wave
+    constexpr int NT = WN / 16;             // 16-column MFMA tiles per wave
+    constexpr int ACH = BM / 32;            // 16-byte activation chunks per thread per K step
     constexpr int WPT = BN / 8 / 16;   // packed words per thread per row group (BN=128: 1, 256: 2)
     constexpr int A_BYTES = BM * APITCH * 2;
     constexpr int B_BYTES = BK * BN * 2;
@@ -66,10 +75,11 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int l15 = lane & 15, kb = lane >> 4;
     // consecutive blocks walk the N tiles of one M tile (they share the activation rows in L2)
-    const int mt = blockIdx.x / p.tiles_n, nt = blockIdx.x % p.tiles_n;
+    const int tile_id = blockIdx.x % (p.tiles_m * p.tiles_n), slice = blockIdx.x / (p.tiles_m * p.tiles_n);
+    const int mt = tile_id / p.tiles_n, nt = tile_id % p.tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
     const int NW = p.N >> 3;
 
@@ -79,11 +89,11 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
     const rsrc_t sres = mk_rsrc(p.scales, (uint32_t)((int64_t)(p.K / p.g) * p.N * 2));
 
     // ---- per-thread staging assignments
-    // A: 4 chunks of 16 bytes: chunk c = tid + 256*i -> row c/8, 8 halfs at k = 8*(c%8)
-    uint32_t a_voff[4];
-    int a_lds[4];
+    // A: ACH chunks of 16 bytes: chunk c = tid + 256*i -> row c/8, 8 halfs at k = 8*(c%8)
+    uint32_t a_voff[ACH];
+    int a_lds[ACH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ACH; ++i) {
         const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
         a_voff[i] = (m0 + row < p.M) ? (uint32_t)(((int64_t)(m0 + row) * p.K + 8 * kc) * 2) : OOB;
         a_lds[i] = (row * APITCH + 8 * kc) * 2;
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
     }
 
     struct Regs {
-        u32x4 a[4];
+        u32x4 a[ACH];
         uint32_t w[WPT][4], z[WPT];
         u32x4 s[WPT];
     };
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
     auto fetch = [&](Regs& R, int t) {  // global -> registers for K step t
         const uint32_t k0 = (uint32_t)t * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < ACH; ++i)
             R.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, a_voff[i], k0 * 2u, 0));
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
         unsigned char* A = smem + buf * (A_BYTES + B_BYTES);
         unsigned char* B = A + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(A + a_lds[i]) = R.a[i];
+        for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(A + a_lds[i]) = R.a[i];
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const uint32_t qz = R.z[i];
@@ -151,15 +161,15 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
         }
     };
 
-    float4_t acc[4][NT];
+    float4_t acc[MI][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) acc[i][jn] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses (bytes) inside a buffer
-    //   A: row wm*64 + 16*i + l15, k = kk*32 + 4*kb (+16 for the second half)
-    const int a_frag = ((wm * 64 + l15) * APITCH + 4 * kb) * 2;
+    //   A: row wm*WM + 16*i + l15, k = kk*32 + 4*kb (+16 for the second half)
+    const int a_frag = ((wm * WM + l15) * APITCH + 4 * kb) * 2;
     //   B (tr read): sub-tile (wn*WN/16 + jn); lane t=l15 of group kb reads 4 halfs of row
     //   kk*32 + 4*kb + (t>>2) at columns 4*(t&3); the hardware hands lane l15 column l15
     const int b_frag = ((wn * NT) * BK * 16 + (4 * kb + (l15 >> 2)) * 16 + 4 * (l15 & 3)) * 2;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
                 bf[jn] = __builtin_bit_cast(half8_t, u32x4{l2[0], l2[1], h2[0], h2[1]});
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 const unsigned char* ap = A + a_frag + (16 * i * APITCH + kk * 32) * 2;
                 const u32x2 lo = *reinterpret_cast<const u32x2*>(ap);
                 const u32x2 hi = *reinterpret_cast<const u32x2*>(ap + 32);
@@ -197,20 +207,74 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
     // global-load round trip.  (A distance-2 register pipeline was tried: the second register set
     // and the unrolled accumulator copies cost the co-resident block, 675 -> 413 TF at M = 16384.)
     const int T = p.K / BK;
+    const int t0 = slice * p.steps_per_slice, t1 = min(T, t0 + p.steps_per_slice);
     Regs R;
-    fetch(R, 0);
+    fetch(R, t0);
     stage(R, 0);
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) fetch(R, t + 1);
-        compute(t & 1);
-        if (t + 1 < T) stage(R, (t + 1) & 1);
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) fetch(R, t + 1);
+        compute((t - t0) & 1);
+        if (t + 1 < t1) stage(R, (t - t0 + 1) & 1);
         __syncthreads();
+    }
+
+    // ---- split-K combine in one fabric hop through self-validating slabs (same protocol as
+    // gemv_mfma.hip): a wave's accumulators travel as [i][jn][lane] float4, fully coalesced; the
+    // block of the last K slice polls, adds in slice order, then runs the epilogue.
+    if constexpr (SPLITK) {
+        constexpr uint32_t SENT = 0xFFFFFFFFu, QNAN = 0x7FC00000u;
+        constexpr uint32_t WAVE_BYTES = MI * NT * 64 * 16, TILE_BYTES = 4 * WAVE_BYTES;
+        const uint32_t ntiles = (uint32_t)(p.tiles_m * p.tiles_n);
+        const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)(p.S - 1) * ntiles * TILE_BYTES);
+        const uint32_t lane_off = (uint32_t)wave * WAVE_BYTES + (uint32_t)lane * 16u;
+        if (slice != p.S - 1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    u32x4 b = __builtin_bit_cast(u32x4, acc[i][jn]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = (b[e] == SENT) ? QNAN : b[e];
+                    __builtin_amdgcn_raw_buffer_store_b128(b, slres, lane_off + (uint32_t)(i * NT + jn) * 1024u,
+                                                           ((uint32_t)slice * ntiles + (uint32_t)tile_id) * TILE_BYTES, 16);
+                }
+            return;
+        }
+        const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+        for (int sl = 0; sl < p.S - 1; ++sl) {  // slice order: bitwise reproducible
+            const uint32_t soff = ((uint32_t)sl * ntiles + (uint32_t)tile_id) * TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                u32x4 v[NT];
+                for (unsigned spins = 0;; ++spins) {
+                    uint32_t pending = 0;
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn)
+                        v[jn] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              slres, lane_off + (uint32_t)(i * NT + jn) * 1024u, soff, 16));
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn)
+                        pending |= (v[jn][0] == SENT) | (v[jn][1] == SENT) | (v[jn][2] == SENT) | (v[jn][3] == SENT);
+                    if (!pending) break;
+                    if (spins > (1u << 18)) {
+                        *p.err = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) {
+                    acc[i][jn] += __builtin_bit_cast(float4_t, v[jn]);
+                    __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, lane_off + (uint32_t)(i * NT + jn) * 1024u, soff, 16);
+                }
+            }
+        }
     }
 
     // ---- epilogue: D register r of lane (col l15, quad kb) is row 4*kb + r of its 16x16 tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) {
             const int col = n0 + wn * WN + 16 * jn + l15;
@@ -218,23 +282,26 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
             const float b = p.bias ? (float)p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + 16 * i + 4 * kb + r;
+                const int row = m0 + wm * WM + 16 * i + 4 * kb + r;
                 if (row < p.M) p.y[(int64_t)row * p.N + col] = (half_t)(acc[i][jn][r] + b);
             }
         }
     }
 }
 
-template <int BN>
-void launch_tiled(const TiledParams& p, hipStream_t st) {
+template <int BM, int BN>
+void launch_tiled(const TiledParams& p, unsigned grid, hipStream_t st) {
     constexpr size_t lds = 2 * (BM * APITCH * 2 + BK * BN * 2);
     static const bool lds_opt_in = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)lds_opt_in;
-    hipLaunchKernelGGL((awq_gemm_tiled_kernel<BN>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, st, p);
+    if (p.S > 1) hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false>), dim3(grid), dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -247,7 +314,7 @@ bool awq_gemm_tiled_supports(int M, int K, int N, int g) {
     return true;
 }
 
-int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn) {
+int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     if (!awq_gemm_tiled_supports(a.M, a.K, a.N, a.g)) return AWQ_ERR_UNSUPPORTED;
     if (bn == 0) bn = 128;
     if (!(bn == 128 || bn == 256)) return AWQ_ERR_UNSUPPORTED;
@@ -259,10 +326,33 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn) {
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
+    const int BM = a.M <= 32 ? 32 : (a.M <= 64 ? 64 : 128);  // smallest tile that holds the batch: less split-K exchange
+    if (BM < 128) bn = 128;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + bn - 1) / bn;
-    if ((int64_t)p.tiles_m * p.tiles_n > 0x7FFFFFFF) return AWQ_ERR_UNSUPPORTED;
-    if (bn == 128) launch_tiled<128>(p, a.stream);
-    else launch_tiled<256>(p, a.stream);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    const int T = a.K / BK;
+    // split K until ~2 blocks per CU are in the grid (small M: few output tiles, long K loops)
+    int S = splitk > 0 ? splitk : (int)((512 + tiles - 1) / tiles);
+    if (S > 16) S = 16;
+    if (S > T / 4) S = T / 4 > 0 ? T / 4 : 1;  // at least 4 K steps per block
+    const size_t tile_bytes = (size_t)BM * bn * sizeof(float);
+    if (S > 1) {
+        const size_t fit = a.exchange ? a.exchange_bytes / ((size_t)tiles * tile_bytes) + 1 : 1;
+        if ((size_t)S > fit) S = (int)fit;
+    }
+    if (S < 1) S = 1;
+    const int sps = (T + S - 1) / S;
+    S = (T + sps - 1) / sps;
+    p.S = S; p.steps_per_slice = sps;
+    p.slabs = a.exchange;
+    p.err = a.counters;
+    if (S > 1 && (!a.exchange || !a.counters)) return AWQ_ERR_WORKSPACE;
+    if (tiles * S > 0x7FFFFFFF) return AWQ_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)(tiles * S);
+    if (BM == 32) launch_tiled<32, 128>(p, grid, a.stream);
+    else if (BM == 64) launch_tiled<64, 128>(p, grid, a.stream);
+    else if (bn == 128) launch_tiled<128, 128>(p, grid, a.stream);
+    else launch_tiled<128, 256>(p, grid, a.stream);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

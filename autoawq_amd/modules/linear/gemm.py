@@ -18,12 +18,13 @@ from torch.autograd import Function
 from ... import ops
 from ...utils.packing import pack_rows_int4, quantize_int_weights_kn
 
-# M above which the matmul goes dequant (bit-exact HIP kernel) + vendor fp16 GEMM -- the reference's
-# own large-batch route (awq/modules/linear/gemm.py:48-54, there at 1024 tokens).  On MI355X the
-# fused tiled kernel (csrc/gemm_tiled.hip) currently loses to that route at every M > 16
-# (profiles/r01_gemm_tiled_vs_two_pass.txt), so the switch sits right above the decode kernels;
-# set autoawq_amd.modules.linear.gemm.PREFILL_IMPL = "fused" to force the single-kernel path.
-TWO_PASS_MIN_TOKENS = 17
+# Dispatch by token count M (measured on MI355X, profiles/r01_gemm_tiled_vs_two_pass.txt and
+# profiles/r01_small_m.txt):  M <= 16 decode kernel (csrc/gemv_mfma.hip);  17..128 fused dequant +
+# MFMA GEMM with split-K (csrc/gemm_tiled.hip: 23-50 us vs 42-57 us for the two-pass route at
+# 4096x11008);  above that dequant (bit-exact HIP kernel) + vendor fp16 GEMM -- the reference's own
+# large-batch route (awq/modules/linear/gemm.py:48-54, there from 1024 tokens), which hipBLASLt
+# still wins at MFMA-bound sizes (1125 vs 672 TF at M = 16384).  PREFILL_IMPL forces a route.
+TWO_PASS_MIN_TOKENS = 129
 PREFILL_IMPL = "auto"  # "auto" | "fused" | "two_pass"
 
 

@@ -180,9 +180,12 @@ def test_tiled_gemm_vs_oracle(ops, oracle, K, N, g, M, bn):
     qw, qz, s, x, bias = fullrange_case(K, N, g, M, seed=K + N + M, realistic=(N % 64 == 0))
     y32, _ = oracle.linear_gemm(x.numpy(), qw.numpy(), qz.numpy(), s.numpy(), g, bias.numpy())
     fl = ops.gemm_flags(ops.KERNEL_TILED, nlog=bn)
-    y = ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), flags=fl)
-    assert ops.last_kernel() == "gemm_tiled"
-    assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"tiled K{K} N{N} g{g} M{M} bn{bn}")
+    for sk in (0, 1, 3):  # auto split-K (in-launch exchange), none, odd
+        y = ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=bn, splitk=sk))
+        assert ops.last_kernel() == "gemm_tiled"
+        assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"tiled K{K} N{N} g{g} M{M} bn{bn} s{sk}")
+    assert ops.workspace_is_clean(y.device)
+    assert torch.equal(y, ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=bn, splitk=3)))
     # one-hot rows pick rows of the bit-exact dequantised W (row m selects k = 7*m + 3)
     W = ops.dequantize_weights(qw.cuda(), s.cuda(), qz.cuda())
     e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
