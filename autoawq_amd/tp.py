@@ -88,5 +88,6 @@ class RowParallelWQLinear(nn.Module):
         if self.world > 1:
             import torch.distributed as dist
 
-            dist.all_reduce(y, group=self.group)
+            if dist.is_available() and dist.is_initialized():  # one process per GPU: RCCL over xGMI
+                dist.all_reduce(y, group=self.group)
         return y

@@ -217,7 +217,7 @@ def main():
             "metric": "decode tok/s @bs=1 (int4 linears), 7B AWQ-int4 g128", "value": tok_s, "unit": "tok/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "int4 weights x fp16 activations, fp32 accumulate", "data": "synthetic",
+            "dtype": "f16 (int4 weights, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "Llama-2-7B-shape AWQ int4 g128, GEMV bs=1 decode: 32 layers x "
                                    "{qkv 4096->12288, o 4096->4096, gate+up 4096->22016, down 11008->4096}",
                        "layers": a.layers, "launches_per_step": launches, "hipgraph": used_graph, "layout": a.layout,

@@ -619,3 +619,38 @@ def test_moe_route_kernel_vs_torch_and_oracle(ops, oracle, T, E, k, blk):
     assert np.array_equal(e_ids.cpu().numpy()[: wn // blk], we[: wn // blk])
     w2, _, _, _, _ = ops.moe_route(logits.cuda(), k, False, blk)
     assert torch.allclose(w2, torch.topk(torch.softmax(logits.float(), -1), k, -1)[0].cuda(), rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------ tensor-parallel shards on one GPU
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tp_shards_sequentially_on_one_gpu(ops, oracle, world):
+    """the sharding math is provable on one device by running the per-rank shards one
+    after the other -- column-parallel shards concatenate, row-parallel partial sums (whole
+    groups per rank, uneven 86-group split of the Llama-2-7B down_proj) add up to the unsharded
+    product; the kernels see the per-rank shard shapes bench.py --gpus N uses."""
+    from autoawq_amd import WQLinear_GEMM
+    from autoawq_amd.tp import ColumnParallelWQLinear, RowParallelWQLinear, split_even_units
+
+    K, N, g, M = 11008, 4096, 128, 2  # down_proj: 86 groups
+    qw, qz, s, x, bias = fullrange_case(K, N, g, M, seed=77, realistic=True)
+    full = WQLinear_GEMM(4, g, K, N, True, "cuda")
+    full.qweight, full.qzeros, full.scales, full.bias = qw.cuda(), qz.cuda(), s.cuda(), bias.cuda()
+    y_full = full(x.cuda())
+    parts = [c for _, c in split_even_units(K // g, world)]
+    assert sum(parts) == 86 and max(parts) - min(parts) <= 1
+    acc = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        rp = RowParallelWQLinear(full, r, world)
+        k0, k1 = rp.bounds
+        assert k0 % g == 0 and k1 % g == 0 and (rp.shard.bias is not None) == (r == 0)
+        acc += rp.shard(x.cuda()[:, k0:k1]).float()
+    y32, _ = oracle.linear_gemm(x.numpy(), qw.numpy(), qz.numpy(), s.numpy(), g, bias.numpy())
+    W = oracle.dequant_gemm(qw.numpy(), qz.numpy(), s.numpy(), g)
+    assert_product_close(acc.cpu().numpy().astype(np.float64), y32, f"row-parallel tp{world}",
+                         wsigma=oracle.weight_rounding_sigma(x.numpy(), W) + world * np.abs(y32) * 2.0 ** -11)
+    assert (acc.half().float() - y_full.float()).abs().max() <= 4e-3 * y_full.float().abs().max()
+    cols = [ColumnParallelWQLinear(full, r, world)(x.cuda()) for r in range(world)]
+    # same columns, but a narrower shard may pick another K split: equal up to the fp32 summation order
+    yc = torch.cat(cols, dim=-1).float()
+    assert (yc - y_full.float()).abs().max() <= 2 * 2.0 ** -10 * y_full.float().abs().max()
