@@ -58,17 +58,20 @@ AWQ_DEV float4_t mfma16(half8_t a, half8_t b, float4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// BM x BN output tile per block; the 4 waves are laid out 2 x 2 for BM = 128 and 1 x 4 below.
+// BM x BN output tile per block; waves are laid out 2 x 2 (128 x 128), 2 x 4 (128 x 256: 8 waves,
+// each 64 x 64 like the 128 x 128 tile, half the activation traffic per flop) or 1 x 4 (BM < 128).
 template <int BM, int BN, bool SPLITK>
-__global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
-    constexpr int WGM = BM >= 128 ? 2 : 1;  // waves along M
-    constexpr int WGN = 4 / WGM;            // waves along N
+__global__ __launch_bounds__((BM >= 128 ? 2 : 1) * (BN >= 256 ? 4 : (BM >= 128 ? 2 : 4)) * 64)
+void awq_gemm_tiled_kernel(TiledParams p) {
+    constexpr int WGM = BM >= 128 ? 2 : 1;                     // waves along M
+    constexpr int WGN = BN >= 256 ? 4 : (BM >= 128 ? 2 : 4);   // waves along N
+    constexpr int NTHR = WGM * WGN * 64;
     constexpr int WM = BM / WGM;            // rows per wave
     constexpr int MI = WM / 16;             // 16-row MFMA tiles per wave
     constexpr int WN = BN / WGN;            // columns per wave
     constexpr int NT = WN / 16;             // 16-column MFMA tiles per wave
-    constexpr int ACH = BM / 32;            // 16-byte activation chunks per thread per K step
-    constexpr int WPT = BN / 8 / 16;   // packed words per thread per row group (BN=128: 1, 256: 2)
+    constexpr int ACH = BM * 8 / NTHR;      // 16-byte activation chunks per thread per K step
+    constexpr int WPT = (BN / 8) * 16 / NTHR;  // (word column, 4-row group) assignments per thread
     constexpr int A_BYTES = BM * APITCH * 2;
     constexpr int B_BYTES = BK * BN * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A | B]
@@ -89,12 +92,12 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
     const rsrc_t sres = mk_rsrc(p.scales, (uint32_t)((int64_t)(p.K / p.g) * p.N * 2));
 
     // ---- per-thread staging assignments
-    // A: ACH chunks of 16 bytes: chunk c = tid + 256*i -> row c/8, 8 halfs at k = 8*(c%8)
+    // A: ACH chunks of 16 bytes: chunk c = tid + NTHR*i -> row c/8, 8 halfs at k = 8*(c%8)
     uint32_t a_voff[ACH];
     int a_lds[ACH];
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
-        const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+        const int c = tid + NTHR * i, row = c >> 3, kc = c & 7;
         a_voff[i] = (m0 + row < p.M) ? (uint32_t)(((int64_t)(m0 + row) * p.K + 8 * kc) * 2) : OOB;
         a_lds[i] = (row * APITCH + 8 * kc) * 2;
     }
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
     uint32_t b_voff[WPT], z_voff[WPT], s_voff[WPT];
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         b_wc[i] = idx % (BN / 8);
         b_rg[i] = idx / (BN / 8);  // 0..15
         const int w = (n0 >> 3) + b_wc[i];
@@ -224,11 +227,17 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
     // block of the last K slice polls, adds in slice order, then runs the epilogue.
     if constexpr (SPLITK) {
         constexpr uint32_t SENT = 0xFFFFFFFFu, QNAN = 0x7FC00000u;
-        constexpr uint32_t WAVE_BYTES = MI * NT * 64 * 16, TILE_BYTES = 4 * WAVE_BYTES;
+        constexpr uint32_t WAVE_BYTES = MI * NT * 64 * 16, TILE_BYTES = WGM * WGN * WAVE_BYTES;
         const uint32_t ntiles = (uint32_t)(p.tiles_m * p.tiles_n);
         const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)(p.S - 1) * ntiles * TILE_BYTES);
         const uint32_t lane_off = (uint32_t)wave * WAVE_BYTES + (uint32_t)lane * 16u;
+        // NOTE on every 16-byte buffer store below: the slab offset goes into the VGPR offset and
+        // soffset stays the constant 0.  With an SGPR soffset the compiler's hazard recogniser
+        // assumes "VALU may overwrite the data VGPRs of a >8-byte MUBUF store right away" is safe;
+        // on gfx950 it is not (the next v_add clobbered dword 0 of the last chunk in some lanes,
+        // profiles/r01_store_hazard.txt) -- with soffset = 0 it inserts the wait states.
         if (slice != p.S - 1) {
+            const uint32_t pbase = lane_off + ((uint32_t)slice * ntiles + (uint32_t)tile_id) * TILE_BYTES;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -236,8 +245,7 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
                     u32x4 b = __builtin_bit_cast(u32x4, acc[i][jn]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b[e] = (b[e] == SENT) ? QNAN : b[e];
-                    __builtin_amdgcn_raw_buffer_store_b128(b, slres, lane_off + (uint32_t)(i * NT + jn) * 1024u,
-                                                           ((uint32_t)slice * ntiles + (uint32_t)tile_id) * TILE_BYTES, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(b, slres, pbase + (uint32_t)(i * NT + jn) * 1024u, 0, 16);
                 }
             return;
         }
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256) void awq_gemm_tiled_kernel(TiledParams p) {
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
                     acc[i][jn] += __builtin_bit_cast(float4_t, v[jn]);
-                    __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, lane_off + (uint32_t)(i * NT + jn) * 1024u, soff, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, lane_off + soff + (uint32_t)(i * NT + jn) * 1024u, 0, 16);
                 }
             }
         }
@@ -300,8 +308,9 @@ void launch_tiled(const TiledParams& p, unsigned grid, hipStream_t st) {
         return true;
     }();
     (void)lds_opt_in;
-    if (p.S > 1) hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, true>), dim3(grid), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false>), dim3(grid), dim3(256), lds, st, p);
+    constexpr int NTHR = (BM >= 128 ? 2 : 1) * (BN >= 256 ? 4 : (BM >= 128 ? 2 : 4)) * 64;
+    if (p.S > 1) hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, true>), dim3(grid), dim3(NTHR), lds, st, p);
+    else hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false>), dim3(grid), dim3(NTHR), lds, st, p);
 }
 
 }  // namespace

@@ -422,8 +422,10 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
             u32x4 b = __builtin_bit_cast(u32x4, block_sum4(qd));
 #pragma unroll
             for (int e = 0; e < 4; ++e) b[e] = (b[e] == SENT) ? QNAN : b[e];
-            __builtin_amdgcn_raw_buffer_store_b128(b, slres, (uint32_t)qd * 16u,
-                                                   (tb0 + (uint32_t)(slice * p.tiles + tile)) * slab_bytes, 16 /* sc1 */);
+            // soffset must stay the constant 0 on 16-byte buffer stores (see gemm_tiled.hip: with
+            // an SGPR soffset no wait states are inserted before the data VGPRs are rewritten)
+            __builtin_amdgcn_raw_buffer_store_b128(b, slres, (uint32_t)qd * 16u + (tb0 + (uint32_t)(slice * p.tiles + tile)) * slab_bytes,
+                                                   0, 16 /* sc1 */);
         }
         AWQ_STAMP(4);
         return;
@@ -456,8 +458,8 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
 #pragma unroll
             for (int u = 0; u < 8; ++u)  // re-arm (write-through; also drops the line from this XCD's L2)
                 if (sl0 + u < S - 1)
-                    __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, (uint32_t)qd * 16u,
-                                                           (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, (uint32_t)qd * 16u + (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes,
+                                                           0, 16);
         }
         emit4(qd, s + own);
     }

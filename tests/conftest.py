@@ -48,4 +48,7 @@ def assert_product_close(y, ref32, what="", wsigma=None):
     # one fp16 ulp of slack for the final rounding of the output itself
     ulp = np.maximum(np.abs(ref32), 2.0 ** -14) * 2.0 ** -10
     bad = np.abs(y - ref32) > tol + ulp
-    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.size} outside tolerance, max err {np.abs(y - ref32).max()}"
+    if bad.any():
+        idx = np.argwhere(bad)
+        where = ", ".join(f"{tuple(int(v) for v in i)}: {y[tuple(i)]:.4f} vs {ref32[tuple(i)]:.4f}" for i in idx[:48])
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.size} outside tolerance, max err {np.abs(y - ref32).max()}; at {where}")

@@ -1,0 +1,36 @@
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from autoawq_amd import ops
+lim = 0x7FFFFFFF
+def case(K, N, g, M, seed):
+    gen = torch.Generator().manual_seed(seed)
+    qw = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, generator=gen)
+    qz = torch.randint(-lim - 1, lim, (K // g, N // 8), dtype=torch.int32, generator=gen)
+    sc = (torch.rand((K // g, N), generator=gen) * 0.02 + 0.005).half()
+    x = torch.randn((M, K), generator=gen).half()
+    return qw.cuda(), qz.cuda(), sc.cuda(), x.cuda()
+cases = [(2048, 2048, 2048, 300, 0), (512, 256, 128, 17, ops.gemm_flags(ops.KERNEL_TILED, nlog=1)), (4096, 4096, 128, 1, 0), (4096, 11008, 128, 8, 0)]
+data = [case(*c[:4], seed=i) for i, c in enumerate(cases)]
+firsts = {}
+bad = 0
+for it in range(400):
+    for i, c in enumerate(cases):
+        ops._workspaces.clear()
+        # dirty the allocator's free blocks with finite floats, from a different set of CUs each time
+        junk = torch.full((48 << 20,), 1.25 + it, dtype=torch.float32, device="cuda")
+        junk2 = junk * 2
+        del junk, junk2
+        qw, qz, sc, x = data[i]
+        y = ops.gemm_forward(x, qw, sc, qz, flags=c[4])
+        if i not in firsts:
+            firsts[i] = y.clone()
+        elif not torch.equal(y, firsts[i]):
+            d = (y.float() - firsts[i].float()).abs()
+            idx = torch.nonzero(d > 0)
+            bad += 1
+            print(f"MISMATCH case {c} iter {it}: {idx.shape[0]} elems, max {float(d.max()):.4f}, rows {sorted(set(idx[:,0].tolist()))[:8]} cols {sorted(set(idx[:,1].tolist()))[:20]}", flush=True)
+    if bad > 12: break
+torch.cuda.synchronize()
+print("done", bad, "clean", ops.workspace_is_clean(torch.device("cuda")))
