@@ -196,6 +196,32 @@ def test_tiled_gemm_vs_oracle(ops, oracle, K, N, g, M, bn):
     assert diff.numel() == 0, f"one-hot rows differ at {diff[:48].tolist()} ({diff.shape[0]} elements)"
 
 
+def test_tiled_splitk_more_blocks_than_cus(ops):
+    """M = 300 at 2048 x 2048 with a workspace large enough for S = 8: 48 tiles x 8 slices = 384
+    blocks, every producer wave streams 16 chunks of 16 bytes into the exchange.  This is the
+    configuration in which a rewritten store-data register (profiles/r01_store_hazard.txt) showed;
+    one-hot rows make every slice's contribution individually visible."""
+    K = N = 2048
+    M = 300
+    qw, qz, s, x, _ = fullrange_case(K, N, K, M, seed=77, realistic=True)
+    dq, ds, dz = qw.cuda(), s.cuda(), qz.cuda()
+    ops.workspace(dq.device, 16384 + (64 << 20))
+    W = ops.dequantize_weights(dq, ds, dz)
+    ks = (torch.arange(M, device="cuda") * 7 + 3) % K
+    e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    for bn in (1, 2):
+        for _ in range(5):
+            out = ops.gemm_forward(e, dq, ds, dz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=bn))
+            diff = torch.nonzero(out != W[ks])
+            assert diff.numel() == 0, f"bn{bn}: one-hot rows differ at {diff[:32].tolist()}"
+        one = ops.gemm_forward(x.cuda(), dq, ds, dz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=bn, splitk=1))
+        for _ in range(5):
+            y = ops.gemm_forward(x.cuda(), dq, ds, dz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=bn))
+            assert (y.float() - one.float()).abs().max() <= 2e-3 * one.float().abs().max()
+    assert ops.workspace_is_clean(dq.device)
+
+
 def test_auto_dispatch_by_m(ops):
     qw, qz, s, x, _ = fullrange_case(512, 256, 128, 40, seed=9, realistic=True)
     dq, dz, ds = qw.cuda(), qz.cuda(), s.cuda()
