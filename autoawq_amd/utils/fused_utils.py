@@ -8,6 +8,7 @@ import torch
 
 from ..modules.linear.gemm import WQLinear_GEMM
 from ..modules.linear.gemv import WQLinear_GEMV
+from ..modules.linear.gemv_fast import WQLinear_GEMVFast
 
 
 def fuse_linears(linears, device=None, dim=1, operation=torch.cat):
@@ -29,19 +30,27 @@ def fuse_linears(linears, device=None, dim=1, operation=torch.cat):
 
 
 def fuse_qkv(module, q_proj, k_proj, v_proj):
-    """awq/utils/fused_utils.py:45-142 for the two layouts implemented here."""
+    """awq/utils/fused_utils.py:45-142 for the three layouts served here: GEMM concatenates N on
+    dim 1 of every buffer (`:87-96`), GEMV on dim 0 (`:76-86`), GEMVFast qweight on dim 0 and
+    scales / zeros on dim 1 (`:125-135`); the source modules give their buffers up (`:139-140`)."""
     first = q_proj
     bias = torch.cat([q_proj.bias, k_proj.bias, v_proj.bias], dim=0) if q_proj.bias is not None else None
     if isinstance(first, WQLinear_GEMV):
-        cls, dim = WQLinear_GEMV, 0
+        cls, dw, dzs = WQLinear_GEMV, 0, 0
+    elif isinstance(first, WQLinear_GEMVFast):
+        cls, dw, dzs = WQLinear_GEMVFast, 0, 1
+    elif isinstance(first, WQLinear_GEMM):
+        cls, dw, dzs = WQLinear_GEMM, 1, 1
     else:
-        cls, dim = WQLinear_GEMM, 1
+        raise TypeError(f"fuse_qkv: unsupported linear type {type(first).__name__}")
     qkv = cls(first.w_bit, first.group_size, first.in_features,
               q_proj.out_features + k_proj.out_features + v_proj.out_features, bias is not None,
               first.qweight.device)
-    qkv.qweight = torch.cat([q_proj.qweight, k_proj.qweight, v_proj.qweight], dim=dim)
-    qkv.qzeros = torch.cat([q_proj.qzeros, k_proj.qzeros, v_proj.qzeros], dim=dim)
-    qkv.scales = torch.cat([q_proj.scales, k_proj.scales, v_proj.scales], dim=dim)
+    qkv.qweight = torch.cat([q_proj.qweight, k_proj.qweight, v_proj.qweight], dim=dw)
+    qkv.qzeros = torch.cat([q_proj.qzeros, k_proj.qzeros, v_proj.qzeros], dim=dzs).contiguous()
+    qkv.scales = torch.cat([q_proj.scales, k_proj.scales, v_proj.scales], dim=dzs).contiguous()
+    if hasattr(first, "split_k_iters"):
+        qkv.split_k_iters = first.split_k_iters
     qkv.bias = bias
     for m in (q_proj, k_proj, v_proj):
         del m.qweight, m.qzeros, m.scales
