@@ -37,6 +37,7 @@ struct TiledParams {
     const half_t* bias;
     half_t* y;
     int M, K, N, g;
+    uint32_t g_magic;  // 2^32 / g + 1: (k * g_magic) >> 32 == k / g for k < K (K * g < 2^32, checked by the launcher)
     int tiles_m, tiles_n;
     int S, steps_per_slice;  // split-K: K steps [slice*steps_per_slice, ...) per block
     float* slabs;            // exchange region [S-1][tiles][4 waves][4*NT][64 lanes] float4, sentinel-filled
@@ -60,6 +61,18 @@ AWQ_DEV float4_t mfma16(half8_t a, half8_t b, float4_t c) {
 
 // BM x BN output tile per block; waves are laid out 2 x 2 (128 x 128), 2 x 4 (128 x 256: 8 waves,
 // each 64 x 64 like the 128 x 128 tile, half the activation traffic per flop) or 1 x 4 (BM < 128).
+// Phase timestamps for tools/trace_tiled.py (debug build only: -DAWQ_GEMV_TRACE)
+#ifdef AWQ_GEMV_TRACE
+__device__ unsigned long long* g_awq_trace_tiled = nullptr;
+#define AWQ_TSTAMP(slot)                                                                                 \
+    do {                                                                                                 \
+        if (g_awq_trace_tiled && lane == 0)                                                              \
+            g_awq_trace_tiled[((size_t)blockIdx.x * 8 + wave) * 16 + (slot)] = wall_clock64();            \
+    } while (0)
+#else
+#define AWQ_TSTAMP(slot) do { } while (0)
+#endif
+
 template <int BM, int BN, bool SPLITK>
 __global__ __launch_bounds__((BM >= 128 ? 2 : 1) * (BN >= 256 ? 4 : (BM >= 128 ? 2 : 4)) * 64)
 void awq_gemm_tiled_kernel(TiledParams p) {
@@ -85,6 +98,7 @@ void awq_gemm_tiled_kernel(TiledParams p) {
     const int mt = tile_id / p.tiles_n, nt = tile_id % p.tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
     const int NW = p.N >> 3;
+    AWQ_TSTAMP(0);
 
     const rsrc_t xres = mk_rsrc(p.x, (uint32_t)((int64_t)p.M * p.K * 2));
     const rsrc_t wres = mk_rsrc(p.qweight, (uint32_t)((int64_t)p.K * NW * 4));
@@ -122,19 +136,23 @@ void awq_gemm_tiled_kernel(TiledParams p) {
         u32x4 s[WPT];
     };
 
-    auto fetch = [&](Regs& R, int t) {  // global -> registers for K step t
+    // global -> registers for K step t.  `valid == false` keeps the instruction count (the
+    // outstanding-load bookkeeping of the pipelined loop stays static) but moves every lane out
+    // of range: zeros, no memory traffic.
+    auto fetch = [&](Regs& R, int t, bool valid = true) {
         const uint32_t k0 = (uint32_t)t * BK;
+        const uint32_t kill = valid ? 0u : OOB;
 #pragma unroll
         for (int i = 0; i < ACH; ++i)
-            R.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, a_voff[i], k0 * 2u, 0));
+            R.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, a_voff[i] | kill, valid ? k0 * 2u : 0u, 0));
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                R.w[i][r] = __builtin_amdgcn_raw_buffer_load_b32(wres, b_voff[i], (k0 + (uint32_t)r) * (uint32_t)NW * 4u, 0);
-            const uint32_t grp = (k0 + 4u * (uint32_t)b_rg[i]) / (uint32_t)p.g;
-            R.z[i] = __builtin_amdgcn_raw_buffer_load_b32(zres, z_voff[i] + grp * (uint32_t)NW * 4u, 0, 0);
-            R.s[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sres, s_voff[i] + grp * (uint32_t)p.N * 2u, 0, 0));
+                R.w[i][r] = __builtin_amdgcn_raw_buffer_load_b32(wres, b_voff[i] | kill, valid ? (k0 + (uint32_t)r) * (uint32_t)NW * 4u : 0u, 0);
+            const uint32_t grp = __umulhi(k0 + 4u * (uint32_t)b_rg[i], p.g_magic);  // row / g without a divide
+            R.z[i] = __builtin_amdgcn_raw_buffer_load_b32(zres, (z_voff[i] + grp * (uint32_t)NW * 4u) | kill, 0, 0);
+            R.s[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sres, (s_voff[i] + grp * (uint32_t)p.N * 2u) | kill, 0, 0));
         }
     };
 
@@ -205,23 +223,57 @@ void awq_gemm_tiled_kernel(TiledParams p) {
         }
     };
 
-    // One barrier per K step: tile t+1 is fetched into registers before tile t is multiplied and
-    // decoded into the other LDS buffer afterwards; the co-resident block of the CU covers the
-    // global-load round trip.  (A distance-2 register pipeline was tried: the second register set
-    // and the unrolled accumulator copies cost the co-resident block, 675 -> 413 TF at M = 16384.)
+    // One barrier per K step; global loads run DEPTH tiles ahead in registers: tile t+DEPTH is
+    // requested before tile t is multiplied, tile t+1 (requested DEPTH-1 steps ago) is decoded into
+    // the other LDS buffer afterwards.  The small-batch tiles (BM <= 64) are latency-bound -- a
+    // block's tile is 8 KB per step -- so they keep 4 tiles in flight (17 registers each); the
+    // 128-row tiles keep one (a second register set there costs the co-resident block:
+    // 675 -> 413 TF at M = 16384).
+    constexpr int DEPTH = BM >= 128 ? 1 : 4;
     const int T = p.K / BK;
     const int t0 = slice * p.steps_per_slice, t1 = min(T, t0 + p.steps_per_slice);
-    Regs R;
-    fetch(R, t0);
-    stage(R, 0);
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        if (t + 1 < t1) fetch(R, t + 1);
-        compute((t - t0) & 1);
-        if (t + 1 < t1) stage(R, (t - t0 + 1) & 1);
+    Regs R[DEPTH];
+    if constexpr (DEPTH == 1) {
+        fetch(R[0], t0);
+        stage(R[0], 0);
         __syncthreads();
+        for (int t = t0; t < t1; ++t) {
+            if (t + 1 < t1) fetch(R[0], t + 1);
+            compute((t - t0) & 1);
+            if (t + 1 < t1) stage(R[0], (t - t0 + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // Steady state without a branch: every step issues exactly one tile's loads (out of
+        // range past the slice) and decodes exactly one, so the compiler's s_waitcnt vmcnt(N)
+        // lets DEPTH-1 tiles stay in flight (with conditional fetches it fell back to vmcnt(0)
+        // every step and the whole round trip was exposed: 1.1 us per K step).
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(R[d], t0 + d, t0 + d < t1);
+        AWQ_TSTAMP(1);
+        stage(R[0], 0);
+        __syncthreads();
+        AWQ_TSTAMP(2);
+        int t = t0;
+        for (; t + DEPTH <= t1; t += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {  // (t - t0) is a multiple of the even DEPTH: LDS buffer = d & 1
+                fetch(R[d], t + d + DEPTH, t + d + DEPTH < t1);
+                compute(d & 1);
+                stage(R[(d + 1) % DEPTH], (d + 1) & 1);  // past the slice: decodes zeros into the idle buffer
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d)  // tail: fewer than DEPTH steps, all of them already requested
+            if (t + d < t1) {
+                compute(d & 1);
+                if (t + d + 1 < t1) stage(R[d + 1], (d + 1) & 1);
+                __syncthreads();
+            }
     }
 
+    AWQ_TSTAMP(3);
     // ---- split-K combine in one fabric hop through self-validating slabs (same protocol as
     // gemv_mfma.hip): a wave's accumulators travel as [i][jn][lane] float4, fully coalesced; the
     // block of the last K slice polls, adds in slice order, then runs the epilogue.
@@ -247,39 +299,56 @@ void awq_gemm_tiled_kernel(TiledParams p) {
                     for (int e = 0; e < 4; ++e) b[e] = (b[e] == SENT) ? QNAN : b[e];
                     __builtin_amdgcn_raw_buffer_store_b128(b, slres, pbase + (uint32_t)(i * NT + jn) * 1024u, 0, 16);
                 }
+            AWQ_TSTAMP(4);
             return;
         }
         const u32x4 sent4 = {SENT, SENT, SENT, SENT};
-        for (int sl = 0; sl < p.S - 1; ++sl) {  // slice order: bitwise reproducible
-            const uint32_t soff = ((uint32_t)sl * ntiles + (uint32_t)tile_id) * TILE_BYTES;
+        // Every poll is a fabric round trip, so a round requests up to 16 chunks per lane -- all
+        // (i, jn) accumulators of GSL slices -- before anything is checked: S = 6 at BM = 32 takes
+        // 2 round trips instead of 10 (a 32-row batch at 4096 x 11008: 24 -> see profiles/).
+        constexpr int PER = MI * NT;                    // 16-byte chunks per lane per slice
+        constexpr int GSL = PER >= 16 ? 1 : 16 / PER;   // slices per round
+        for (int sl0 = 0; sl0 < p.S - 1; sl0 += GSL) {  // slice order: bitwise reproducible
+            u32x4 v[GSL][PER];
+            uint32_t soff[GSL];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                u32x4 v[NT];
-                for (unsigned spins = 0;; ++spins) {
-                    uint32_t pending = 0;
+            for (int g = 0; g < GSL; ++g) soff[g] = ((uint32_t)(sl0 + g) * ntiles + (uint32_t)tile_id) * TILE_BYTES;
+            for (unsigned spins = 0;; ++spins) {
+                uint32_t pending = 0;
 #pragma unroll
-                    for (int jn = 0; jn < NT; ++jn)
-                        v[jn] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                              slres, lane_off + (uint32_t)(i * NT + jn) * 1024u, soff, 16));
+                for (int g = 0; g < GSL; ++g)
 #pragma unroll
-                    for (int jn = 0; jn < NT; ++jn)
-                        pending |= (v[jn][0] == SENT) | (v[jn][1] == SENT) | (v[jn][2] == SENT) | (v[jn][3] == SENT);
-                    if (!pending) break;
-                    if (spins > (1u << 18)) {
-                        *p.err = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
+                    for (int c = 0; c < PER; ++c)  // slices past S-1: out of range, zeros, no traffic
+                        v[g][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                slres, (sl0 + g < p.S - 1) ? lane_off + (uint32_t)c * 1024u : OOB,
+                                                                soff[g], 16));
+#pragma unroll
+                for (int g = 0; g < GSL; ++g)
+#pragma unroll
+                    for (int c = 0; c < PER; ++c)
+                        pending |= (v[g][c][0] == SENT) | (v[g][c][1] == SENT) | (v[g][c][2] == SENT) | (v[g][c][3] == SENT);
+                if (!pending) break;
+                if (spins > (1u << 18)) {
+                    *p.err = 1;
+                    break;
                 }
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) {
-                    acc[i][jn] += __builtin_bit_cast(float4_t, v[jn]);
-                    __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, lane_off + soff + (uint32_t)(i * NT + jn) * 1024u, 0, 16);
-                }
+                __builtin_amdgcn_s_sleep(1);
             }
+#pragma unroll
+            for (int g = 0; g < GSL; ++g)
+#pragma unroll
+                for (int c = 0; c < PER; ++c) acc[c / NT][c % NT] += __builtin_bit_cast(float4_t, v[g][c]);
+#pragma unroll
+            for (int g = 0; g < GSL; ++g)
+                if (sl0 + g < p.S - 1) {
+#pragma unroll
+                    for (int c = 0; c < PER; ++c)
+                        __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, lane_off + soff[g] + (uint32_t)c * 1024u, 0, 16);
+                }
         }
     }
 
+    AWQ_TSTAMP(5);
     // ---- epilogue: D register r of lane (col l15, quad kb) is row 4*kb + r of its 16x16 tile
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -295,6 +364,7 @@ void awq_gemm_tiled_kernel(TiledParams p) {
             }
         }
     }
+    AWQ_TSTAMP(6);
 }
 
 template <int BM, int BN>
@@ -315,11 +385,18 @@ void launch_tiled(const TiledParams& p, unsigned grid, hipStream_t st) {
 
 }  // namespace
 
+#ifdef AWQ_GEMV_TRACE
+extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_tiled(void* dev_buf) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_awq_trace_tiled), &dev_buf, sizeof(void*));
+}
+#endif
+
 bool awq_gemm_tiled_supports(int M, int K, int N, int g) {
     if (M < 1) return false;
     if (K % 64 || N % 8) return false;
     if (g % 4) return false;  // a thread's 4 rows of a K step share one group
     if ((int64_t)M * K * 2 >= ((int64_t)1 << 31) || (int64_t)K * N / 2 >= ((int64_t)1 << 31)) return false;
+    if ((int64_t)(K + 64) * g >= ((int64_t)1 << 32)) return false;  // exactness of the multiply-high group index
     return true;
 }
 
@@ -335,8 +412,9 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
+    p.g_magic = (uint32_t)((((uint64_t)1 << 32) / (uint64_t)a.g) + 1);
     const int BM = a.M <= 32 ? 32 : (a.M <= 64 ? 64 : 128);  // smallest tile that holds the batch: less split-K exchange
-    if (BM < 128) bn = 128;
+    if (BM < 128) bn = 128;  // (32|64) x 256 with four tiles in flight drops to one wave per SIMD: 22 -> 27 us at M = 32
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + bn - 1) / bn;
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
