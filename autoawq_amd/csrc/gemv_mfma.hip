@@ -97,6 +97,19 @@ AWQ_DEV uint32_t pair16(uint32_t q) {
     return and_or(t, 0x03C003C0u, 0x4C004C00u);
 }
 
+// The same pair with the nibbles left where they are: bits 0-3 / 16-19 under exponent 2^10
+// (0x6400: 1024 + w), bits 4-7 / 20-23 under exponent 2^6 (0x5400: 64 + w); nibbles 2, 3, 6, 7 come
+// from ONE shared `q >> 8`.  5 VALU ops per packed word instead of 8; the bias (1024 or 64) goes
+// through the group factorisation like the 16 above: y += s * (acc - (bias_J + z) * sum_x), every
+// product still exact in fp32.
+template <int J>
+AWQ_DEV uint32_t pairb(uint32_t q, uint32_t q8) {
+    if constexpr (J == 0) return and_or(q, 0x000F000Fu, 0x64006400u);
+    else if constexpr (J == 1) return and_or(q, 0x00F000F0u, 0x54005400u);
+    else if constexpr (J == 2) return and_or(q8, 0x000F000Fu, 0x64006400u);
+    else return and_or(q8, 0x00F000F0u, 0x54005400u);
+}
+
 AWQ_DEV float4_t mfma16(u32x4v a, u32x4v b, float4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0,
                                                   0, 0);
@@ -305,9 +318,10 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
 #pragma unroll
                     for (int wd = 0; wd < WPL; ++wd) {
                         const uint32_t q0 = q[t][0][wd], q1 = q[t][1][wd], q2 = q[t][2][wd], q3 = q[t][3][wd];
+                        const uint32_t h0 = q0 >> 8, h1 = q1 >> 8, h2 = q2 >> 8, h3 = q3 >> 8;
 #define AWQ_MMA_J(J)                                                                                     \
     {                                                                                                    \
-        const u32x4v bf = {pair16<J>(q0), pair16<J>(q1), pair16<J>(q2), pair16<J>(q3)};                  \
+        const u32x4v bf = {pairb<J>(q0, h0), pairb<J>(q1, h1), pairb<J>(q2, h2), pairb<J>(q3, h3)};      \
         acc[wd * 4 + J][0] = mfma16(a0, bf, acc[wd * 4 + J][0]);                                         \
         if constexpr (!SEL) acc[wd * 4 + J][1] = mfma16(a1, bf, acc[wd * 4 + J][1]);                     \
     }
@@ -325,7 +339,8 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                 for (int wd = 0; wd < WPL; ++wd) {
                     const u32x4 sv = *reinterpret_cast<const u32x4*>(zsc + gl * CW + j * CPL + 8 * wd);
                     const uint32_t zw = qzv[wd];
-                    const uint32_t zp[4] = {pair16<0>(zw), pair16<1>(zw), pair16<2>(zw), pair16<3>(zw)};
+                    const uint32_t zw8 = zw >> 8;  // (bias_J + z) pairs, the same biases as the weights
+                    const uint32_t zp[4] = {pairb<0>(zw, zw8), pairb<1>(zw, zw8), pairb<2>(zw, zw8), pairb<3>(zw, zw8)};
 #pragma unroll
                     for (int J = 0; J < 4; ++J) {
                         const half2_t z2 = u2h2(zp[J]), s2 = u2h2(sv[J]);
