@@ -596,6 +596,12 @@ bool gemv_config(const AwqGemmArgs& a, bool two_pass, GemvCfg& c) {
     if (c.wpl == 4 && c.nwaves > 4) c.nwaves = 4;
     int S = c.S;
     if (S == 0) S = narrow ? 16 : ((640 + tiles - 1) / tiles > 8 ? 8 : (640 + tiles - 1) / tiles);
+    if (c.S == 0 && !narrow && M <= 4) {
+        // ~768 blocks = three per CU, evenly: 48 tiles x 16 slices beats x 8 (1.5 per CU: half the
+        // chip carries two blocks, half one) by 8 % on 4096 x 12288 (profiles/r01_gemv_sweep.txt, r76)
+        S = (768 + tiles / 2) / tiles;
+        if (S > 16) S = 16;
+    }
     if (c.S == 0 && M > 8) {  // 16-row slabs: fewer, fatter slices (r62 sweep: 22016 wide 28 -> 24 us at S = 4)
         const int cap = K >= 8192 ? 16 : 8;
         S = (320 + tiles - 1) / tiles > cap ? cap : (320 + tiles - 1) / tiles;
