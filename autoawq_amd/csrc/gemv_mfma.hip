@@ -609,6 +609,7 @@ bool gemv_config(const AwqGemmArgs& a, bool two_pass, GemvCfg& c) {
     // unit: the largest power of two <= 8 sets (requested, or 4 / 2 so that every wave gets one)
     // that divides g and K
     int unit = c.unit ? c.unit : ((K / 64) >= S * c.nwaves ? 4 : 2);
+    if (!c.unit && tiles >= 64 && M <= 4 && S <= 8) unit = 2;  // very wide (gate|up): 4 short units per wave, 3 % (r76/r77 sweeps)
     if (g == 16) unit = 2;
     while (unit > 2 && ((g % (16 * unit)) || (K % (16 * unit)))) unit >>= 1;
     if (K % (16 * unit)) return false;
