@@ -58,12 +58,15 @@ AWQ_DEV float4_t mfma16(u32x4v a, u32x4v b, float4_t c) {
                                                   0, 0);
 }
 
-// fp16 pair (16 + nibble t, 16 + nibble t+4) of a packed word
+// fp16 pair (bias_T + nibble t, bias_T + nibble t+4) of a packed word with the nibbles left in
+// place: bits 0-3 / 16-19 under exponent 2^10 (bias 1024), bits 4-7 / 20-23 under 2^6 (bias 64),
+// nibbles 2, 3, 6, 7 through one shared `q >> 8`: 5 VALU ops per word (see gemv_mfma.hip).
 template <int T>
-AWQ_DEV uint32_t pair16o(uint32_t q) {
-    constexpr int SH = 6 - 4 * T;
-    const uint32_t v = SH >= 0 ? (q << (SH >= 0 ? SH : 0)) : (q >> (SH < 0 ? -SH : 0));
-    return and_or(v, 0x03C003C0u, 0x4C004C00u);
+AWQ_DEV uint32_t pairbo(uint32_t q, uint32_t q8) {
+    if constexpr (T == 0) return and_or(q, 0x000F000Fu, 0x64006400u);
+    else if constexpr (T == 1) return and_or(q, 0x00F000F0u, 0x54005400u);
+    else if constexpr (T == 2) return and_or(q8, 0x000F000Fu, 0x64006400u);
+    else return and_or(q8, 0x00F000F0u, 0x54005400u);
 }
 
 // NG: quantisation groups per 128-K iteration (1: g % 128 == 0, 2: g == 64, 4: g == 32).
@@ -144,36 +147,44 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_nk_kernel(GemvNkParams p
         for (int u = 0; u < U; ++u) {
             const int it = it0 + u * NWAVES;
             if (it >= kiter) break;
-            float4_t acc[NG], sx[NG];
+            // B fragment of the zero points in the same slots and biases: (bias_T + z) pairs, so
+            // acc - accz = sum_k x * (w - z) with one extra MFMA and no sum-of-x term
+            float4_t acc[NG], accz[NG];
+            u32x4v bz[NG];
+            float scl[NG];
 #pragma unroll
-            for (int h = 0; h < NG; ++h) acc[h] = sx[h] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < NG; ++h) {
+                acc[h] = accz[h] = float4_t{0.f, 0.f, 0.f, 0.f};
+                const int grp = (128 * it + (128 / NG) * h) / p.g;
+                scl[h] = (float)zsc[j * SW + grp];
+                const uint32_t z = (zq[j * p.ZW + (grp >> 3)] >> (4 * (grp & 7))) & 15u;
+                const uint32_t zz = z | (z << 16);
+                const uint32_t be = 0x64006400u | zz, bo = 0x54005400u | (zz << 4);
+                bz[h] = u32x4v{be, bo, be, bo};
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const u32x4v a = *reinterpret_cast<const u32x4v*>(xlane + 128 * it + 8 * s);
-                const uint32_t w = q[u][s];
-                const u32x4v b = {pair16o<0>(w), pair16o<1>(w), pair16o<2>(w), pair16o<3>(w)};
+                const uint32_t w = q[u][s], w8 = w >> 8;
+                const u32x4v b = {pairbo<0>(w, w8), pairbo<1>(w, w8), pairbo<2>(w, w8), pairbo<3>(w, w8)};
                 if constexpr (NG == 1) {
                     acc[0] = mfma16(a, b, acc[0]);
-                    sx[0] = mfma16(a, ones, sx[0]);
+                    accz[0] = mfma16(a, bz[0], accz[0]);
                 } else {
 #pragma unroll
                     for (int h = 0; h < NG; ++h) {  // only the K lanes of group h contribute
                         const bool mine = (kb / (4 / NG)) == h;
                         const u32x4v am = mine ? a : u32x4v{0u, 0u, 0u, 0u};
                         acc[h] = mfma16(am, b, acc[h]);
-                        sx[h] = mfma16(am, ones, sx[h]);
+                        accz[h] = mfma16(am, bz[h], accz[h]);
                     }
                 }
             }
-            // fold: y[m][n] += s[n,g] * (acc - (16 + z[n,g]) * sum_x[m]); D reg r = batch row 4*kb + r
+            // fold: y[m][n] += s[n,g] * sum_k x (w - z); D reg r = batch row 4*kb + r
 #pragma unroll
-            for (int h = 0; h < NG; ++h) {
-                const int grp = (128 * it + (128 / NG) * h) / p.g;
-                const float sc = (float)zsc[j * SW + grp];
-                const float z16 = 16.f + (float)((zq[j * p.ZW + (grp >> 3)] >> (4 * (grp & 7))) & 15u);
+            for (int h = 0; h < NG; ++h)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yv[r] = __builtin_fmaf(sc, __builtin_fmaf(-z16, sx[h][r], acc[h][r]), yv[r]);
-            }
+                for (int r = 0; r < 4; ++r) yv[r] = __builtin_fmaf(scl[h], acc[h][r] - accz[h][r], yv[r]);
         }
     }
     if (!staged) __syncthreads();
