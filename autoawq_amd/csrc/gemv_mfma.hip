@@ -690,7 +690,12 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
         c.ng_max = c.rows_per_block / a.g + 2;
         c.lds = gemv_lds_bytes(a.M, CW, 4, c.rows_per_block, c.ng_max);
         c.S = (units + upb - 1) / upb;
-        if (c.lds <= 160 * 1024) break;
+        // Only the token blocks of experts that were hit do any work (5 of 16 in the Mixtral bs = 4
+        // case), so the grid size says little; what matters is that three blocks fit a CU: split K
+        // (up to the 8 slices the workspace is sized for) until the staging area is <= 48 KB.
+        // One 95 KB block per CU streamed w1|w3 at 3.1 TB/s (profiles/r01_moe_mixtral_bs4.txt).
+        const size_t floor_lds = (size_t)4 * a.M * (CW + 16) * 4 + 16;  // the fold area does not shrink with S
+        if (c.lds <= (floor_lds > 48 * 1024 ? floor_lds : 48 * 1024) || ((S >= 8 || S >= units) && c.lds <= 160 * 1024)) break;
         if (S >= units || S >= 64) return AWQ_ERR_UNSUPPORTED;
     }
     if (c.S > 1) {
