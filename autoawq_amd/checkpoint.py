@@ -183,10 +183,11 @@ def read_state_dict(path: str, device="cpu") -> Dict[str, torch.Tensor]:
 
 
 def load_quantized(model: nn.Module, path: str, quant_config: Optional[AwqConfig] = None, device=None, layers=None,
-                   strict: bool = True):
+                   strict: bool = True, repack: Optional[str] = None):
     """Skeleton `model` (fp16 nn.Linear everywhere) + checkpoint directory -> quantised model.
     Shapes and dtypes of every quantised buffer are checked against the module built from the
-    skeleton (a wrong `group_size` / `version` fails here, not inside a kernel)."""
+    skeleton (a wrong `group_size` / `version` fails here, not inside a kernel).  `repack="gemm"`
+    (or "gemv" / "gemv_fast") converts the loaded modules to another layout after loading."""
     if quant_config is None:
         quant_config = AwqConfig.from_pretrained(path if os.path.isdir(path) else os.path.dirname(path))
     replaced = replace_quantized_linears(model, quant_config, layers)
@@ -211,6 +212,12 @@ def load_quantized(model: nn.Module, path: str, quant_config: Optional[AwqConfig
         model.tie_weights()
     if device is not None:
         model.to(device)
+    if repack is not None and repack.lower() != quant_config.version:
+        # declared, optional: serve a checkpoint of one format with the kernels of another
+        # (integer repack on the device, bit-exact: autoawq_amd/utils/convert.py)
+        from .utils.convert import convert_model
+
+        convert_model(model, repack)
     return model, quant_config
 
 

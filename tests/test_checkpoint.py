@@ -184,3 +184,36 @@ def test_fused_qkv_of_loaded_checkpoint_on_gpu(version):
         out = fused(h)
     assert out.shape == sep.shape == (1, 5, 512)
     assert (out.float() - sep.float()).abs().max() <= 2e-3 * sep.float().abs().max()
+
+
+@pytest.mark.parametrize("src", VERSIONS)
+@pytest.mark.parametrize("dst", VERSIONS)
+def test_layout_conversion_is_bit_exact(src, dst):
+    """Repacking the reference-written checkpoint of one format gives the reference-written
+    checkpoint of the other format, tensor for tensor (no floating-point work on the weights)."""
+    from autoawq_amd.checkpoint import load_quantized, read_state_dict
+    from autoawq_amd.utils.convert import convert_model
+
+    model, _ = load_quantized(skeleton(), ckpt(src))
+    n = convert_model(model, dst)
+    assert n == (0 if src == dst else 7)
+    want = read_state_dict(ckpt(dst))
+    got = model.state_dict()
+    for k, v in want.items():
+        assert got[k].shape == v.shape and got[k].dtype == v.dtype and torch.equal(got[k], v), (src, dst, k)
+
+
+@pytest.mark.gpu
+def test_repack_on_load_runs_the_gemm_kernels():
+    """A GEMV-format checkpoint repacked to the GEMM layout on the device gives the reference's
+    logits through the GEMM-layout kernels."""
+    from autoawq_amd.checkpoint import load_quantized
+    from autoawq_amd.modules.linear import WQLinear_GEMM
+
+    g = golden("tiny_llama_awq_gemm_outputs")
+    model, cfg = load_quantized(skeleton(), ckpt("gemv"), device="cuda", repack="gemm")
+    assert cfg.version == "gemv" and type(model.model.layers[0].mlp.down_proj) is WQLinear_GEMM
+    assert model.model.layers[0].mlp.down_proj.qweight.is_cuda
+    with torch.no_grad():
+        logits = model(torch.from_numpy(g["input_ids"]).cuda()).logits.float().cpu().numpy()
+    assert np.abs(logits - g["logits"]).max() <= 2e-2 * np.abs(g["logits"]).max()
