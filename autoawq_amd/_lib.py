@@ -12,8 +12,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libawq_hip.so")
 
 _lib = None
 
-c_void_p, c_int, c_int64, c_size_t, c_uint32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
-                                                  ctypes.c_size_t, ctypes.c_uint32)
+c_void_p, c_int, c_int64, c_size_t, c_uint32, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                           ctypes.c_size_t, ctypes.c_uint32, ctypes.c_float)
 
 # name -> (restype, argtypes); must list every symbol include/awq_hip.h declares
 # (tests/test_boundary.py cross-checks this table against the header and the .so).
@@ -28,6 +28,10 @@ SIGNATURES = {
     "awq_gemm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_void_p, c_size_t, c_uint32, c_void_p]),
     "awq_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "awq_rmsnorm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
+    "awq_rope_kv_append": (c_int, [c_void_p] * 7 + [c_int64] * 8 + [c_void_p]),
+    "awq_decode_attention_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "awq_decode_attention": (c_int, [c_void_p] * 5 + [c_int64] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
     "awq_moe_route": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_int64, c_int, c_int64, c_void_p]),
     "awq_grouped_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "awq_grouped_gemm_forward": (c_int, [c_void_p] * 9 + [c_int64] * 8 + [c_void_p, c_size_t, c_void_p]),

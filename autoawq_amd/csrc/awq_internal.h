@@ -64,3 +64,14 @@ int awq_launch_dequant_fast(const int16_t* qweight, const uint16_t* scales, cons
 // MoE routing (softmax + top-k + block alignment) in one launch; T tokens, E <= 64 experts, k <= 8.
 int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int* sorted_ids, int* expert_ids,
                          int* num_post_pad, int T, int E, int k, int renorm, int block, hipStream_t st);
+
+// decoder.hip: RMSNorm (+ residual add when `residual` is non-null), RoPE + KV-cache append, single-query attention
+int awq_launch_rmsnorm(const uint16_t* x, uint16_t* residual, const uint16_t* w, uint16_t* out, int64_t M, int64_t H,
+                       float eps, hipStream_t st);
+int awq_launch_rope_kv_append(const uint16_t* qkv, uint16_t* q_out, uint16_t* k_cache, uint16_t* v_cache, const float* cos_t,
+                              const float* sin_t, const int32_t* pos_dev, int start_pos, int B, int S, int Hq, int Hkv, int D,
+                              int rot, int Tmax, hipStream_t st);
+size_t awq_decode_attention_workspace_bytes_impl(int B, int Hq, int max_splits);
+int awq_launch_decode_attention(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out,
+                                const int32_t* len_dev, int seq_len, int max_len, int B, int Hq, int Hkv, int D, int Tmax,
+                                float scale, void* workspace, size_t workspace_bytes, hipStream_t st);

@@ -275,3 +275,43 @@ int awq_dequantize_weights_gemv_fast(const int16_t* qweight, const uint16_t* sca
 }
 
 }  // extern "C"
+
+// ---- fused decoder block (decoder.hip)
+int awq_rmsnorm_forward(const uint16_t* x, uint16_t* residual, const uint16_t* weight, uint16_t* out, int64_t M, int64_t H,
+                        float eps, void* stream) {
+    if (M < 0 || H <= 0) return AWQ_ERR_BAD_SHAPE;
+    if (M == 0) return AWQ_OK;
+    if (!x || !weight || !out) return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(weight) || !aligned16(out) || (residual && !aligned16(residual))) return AWQ_ERR_BAD_ALIGNMENT;
+    return awq_launch_rmsnorm(x, residual, weight, out, M, H, eps, static_cast<hipStream_t>(stream));
+}
+
+int awq_rope_kv_append(const uint16_t* qkv, uint16_t* q_out, uint16_t* k_cache, uint16_t* v_cache, const float* cos_table,
+                       const float* sin_table, const int32_t* pos_dev, int64_t start_pos, int64_t B, int64_t S,
+                       int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t rotary_dim, int64_t max_seq,
+                       void* stream) {
+    if (B < 0 || S < 0 || B * S > INT32_MAX / 1024 || max_seq < 1 || max_seq > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    if (B * S == 0) return AWQ_OK;
+    if (!qkv || !q_out || !k_cache || !v_cache || (rotary_dim > 0 && (!cos_table || !sin_table))) return AWQ_ERR_NULL;
+    return awq_launch_rope_kv_append(qkv, q_out, k_cache, v_cache, cos_table, sin_table, pos_dev, (int)start_pos, (int)B,
+                                     (int)S, (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)rotary_dim, (int)max_seq,
+                                     static_cast<hipStream_t>(stream));
+}
+
+size_t awq_decode_attention_workspace_bytes(int64_t B, int64_t n_heads) {
+    if (B <= 0 || n_heads <= 0) return 0;
+    return awq_decode_attention_workspace_bytes_impl((int)B, (int)n_heads, 64);
+}
+
+int awq_decode_attention(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out,
+                         const int32_t* len_dev, int64_t seq_len, int64_t max_len, int64_t B, int64_t n_heads,
+                         int64_t n_kv_heads, int64_t head_dim, int64_t max_seq, float scale, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    if (B < 0 || B > 65535 || n_heads < 1 || n_kv_heads < 1 || n_kv_heads > 65535 || max_seq > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    if (B == 0) return AWQ_OK;
+    if (!q || !k_cache || !v_cache || !out) return AWQ_ERR_NULL;
+    if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out)) return AWQ_ERR_BAD_ALIGNMENT;
+    return awq_launch_decode_attention(q, k_cache, v_cache, out, len_dev, (int)seq_len, (int)max_len, (int)B, (int)n_heads,
+                                       (int)n_kv_heads, (int)head_dim, (int)max_seq, scale, workspace, workspace_bytes,
+                                       static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,329 @@
+// decoder.hip -- the small kernels around the int4 Linears of a fused decoder block
+// (SURVEY.md 8f rank 2): RMSNorm (+ residual add), RoPE + KV-cache append, single-query attention
+// over the cache.  All HBM-bound byte movers; fp32 arithmetic, one rounding to fp16.
+//
+// What they replace in the reference (under /root/reference):
+//   awq_rmsnorm         awq_ext.layernorm_forward_cuda(x, weight, out, eps)   awq/modules/fused/norm.py:33-36
+//   awq_add_rmsnorm     `h = hidden_states + attn_output` + the next norm     awq/modules/fused/block.py:108-119
+//   awq_rope_kv_append  RoPE.forward + WindowedCache.update_kv                awq/modules/fused/attn.py:54-87,265-276, cache.py:40-45
+//   awq_decode_attention  flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, causal=True)  attn.py:291-302
+// (awq_ext / flash-attn sources are not in the reference tree: semantics from the call sites and
+// from the torch code around them.)
+#include "awq_device.h"
+#include "awq_internal.h"
+
+namespace {
+
+AWQ_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- RMSNorm (+ residual add)
+// One 256-thread block per row; thread t owns 16-byte chunks t, t+256, ... (H % 8 == 0).
+// y = fp16( x * rsqrt(mean(x^2) + eps) * w ), all in fp32, one rounding.
+// ADD: r = fp16(residual + x) is written back to `residual` first and is what gets normalised
+// (the fp16 rounding of the sum is what torch's `h = hidden_states + attn_output` hands the norm).
+template <bool ADD>
+__global__ __launch_bounds__(256) void awq_rmsnorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ residual,
+                                                         const half_t* __restrict__ w, half_t* __restrict__ out, int H,
+                                                         float eps) {
+    constexpr int MAXC = 4;  // chunks per thread kept in registers: H <= 8192
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int chunks = H >> 3;
+    half8_t v[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + 256 * i;
+        if (c < chunks) {
+            v[i] = *reinterpret_cast<const half8_t*>(x + (int64_t)row * H + 8 * c);
+            if constexpr (ADD) {
+                const half8_t r = *reinterpret_cast<const half8_t*>(residual + (int64_t)row * H + 8 * c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = (half_t)((float)v[i][e] + (float)r[e]);
+                *reinterpret_cast<half8_t*>(residual + (int64_t)row * H + 8 * c) = v[i];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += (float)v[i][e] * (float)v[i][e];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + 256 * i;
+        if (c < chunks) {
+            const half8_t g = *reinterpret_cast<const half8_t*>(w + 8 * c);
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)v[i][e] * inv * (float)g[e]);
+            *reinterpret_cast<half8_t*>(out + (int64_t)row * H + 8 * c) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- RoPE + KV append
+// qkv [tokens = B*S, (Hq + 2*Hkv) * D] fp16 as the fused qkv Linear writes it (q heads | k heads |
+// v heads).  One block per (token, head slot), D/2 threads; thread i rotates the pair
+// (i, i + rot/2) of a q or k head by the angle of position start + s (cos/sin tables
+// [max_pos, rot/2] fp32, built like RoPE.precompute_freqs_cis), passes dims >= rot through, and
+// writes q to q_out [B*S, Hq, D], k / v to the caches [B, Tmax, Hkv, D] at row start + s.
+__global__ __launch_bounds__(128) void awq_rope_kv_append_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ q_out,
+                                                                half_t* __restrict__ k_cache, half_t* __restrict__ v_cache,
+                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                                const int* __restrict__ pos_dev, int start_pos, int S, int Hq,
+                                                                int Hkv, int D, int rot, int Tmax) {
+    const int slot = blockIdx.x % (Hq + 2 * Hkv), tok = blockIdx.x / (Hq + 2 * Hkv);
+    const int b = tok / S, s = tok % S;
+    const int pos = (pos_dev ? *pos_dev : start_pos) + s;
+    const int i = threadIdx.x;  // 0 .. D/2-1
+    const half_t* src = qkv + (int64_t)tok * (Hq + 2 * Hkv) * D + (int64_t)slot * D;
+    half_t* dst;
+    if (slot < Hq) dst = q_out + ((int64_t)tok * Hq + slot) * D;
+    else if (slot < Hq + Hkv) dst = k_cache + (((int64_t)b * Tmax + pos) * Hkv + (slot - Hq)) * D;
+    else dst = v_cache + (((int64_t)b * Tmax + pos) * Hkv + (slot - Hq - Hkv)) * D;
+    const int half_rot = rot >> 1;
+    if (slot < Hq + Hkv && i < half_rot) {
+        const float c = cos_t[(int64_t)pos * half_rot + i], sn = sin_t[(int64_t)pos * half_rot + i];
+        const float a = (float)src[i], bb = (float)src[i + half_rot];
+        dst[i] = (half_t)(a * c - bb * sn);
+        dst[i + half_rot] = (half_t)(a * sn + bb * c);
+    } else if (slot < Hq + Hkv) {  // pass-through part of a partially rotated head: dims rot .. D-1
+        const int d0 = rot + 2 * (i - half_rot);
+        if (d0 < D) dst[d0] = src[d0];
+        if (d0 + 1 < D) dst[d0 + 1] = src[d0 + 1];
+    } else {
+        dst[2 * i] = src[2 * i];
+        dst[2 * i + 1] = src[2 * i + 1];
+    }
+}
+
+// ---------------------------------------------------------------- single-query attention over the cache
+// grid (splits, Hkv, B), 256 threads.  A block owns one KV head, the G = Hq/Hkv query heads that
+// share it and a contiguous chunk of the sequence.  Lane (r = lane >> 4, c = lane & 15) reads the
+// 16 bytes [8c, 8c+8) of cache row t0 + 4*(wave + 4*i) + r: a wave instruction covers four whole
+// 256-byte rows (D = 128).  Scores by 16-lane butterfly, online softmax per lane group, P*V into
+// 8 fp32 accumulators per query head; lane groups, waves and finally the splits are merged with
+// the usual (max, sum, acc) rule.  Partial results of a split go to `part` [B, Hq, splits, D + 2]
+// fp32 and a second tiny kernel finishes; with one split the block writes fp16 directly.
+template <int G>
+__global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ kc,
+                                                             const half_t* __restrict__ vc, half_t* __restrict__ out,
+                                                             float* __restrict__ part, const int* __restrict__ len_dev,
+                                                             int seq_len, int Hq, int Hkv, int Tmax, float scale,
+                                                             int chunk) {
+    constexpr int D = 128;
+    __shared__ float sm[4][G][D + 2];
+    const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 4, c = lane & 15;
+    const int T = len_dev ? *len_dev : seq_len;
+    const int t0 = split * chunk, t1 = min(T, t0 + chunk);
+
+    float qf[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const half8_t qv = *reinterpret_cast<const half8_t*>(q + ((int64_t)b * Hq + hk * G + g) * D + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[g][e] = (float)qv[e] * scale;
+    }
+    float m[G], l[G], o[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+    }
+    const int64_t rowstride = (int64_t)Hkv * D;
+    const half_t* kb = kc + ((int64_t)b * Tmax * Hkv + hk) * D + 8 * c;
+    const half_t* vb = vc + ((int64_t)b * Tmax * Hkv + hk) * D + 8 * c;
+    constexpr int U = 4;  // row sets requested before any is consumed: 8 loads of 16 bytes in flight per lane
+    for (int tb = t0 + 4 * wave; tb < t1; tb += 16 * U) {  // wave-uniform trip count
+        half8_t kv[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tb + 16 * u + r;
+            kv[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            vv[u] = kv[u];
+            if (t < t1) {
+                kv[u] = *reinterpret_cast<const half8_t*>(kb + (int64_t)t * rowstride);
+                vv[u] = *reinterpret_cast<const half8_t*>(vb + (int64_t)t * rowstride);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = tb + 16 * u + r < t1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += qf[g][e] * (float)kv[u][e];
+#pragma unroll
+                for (int x = 8; x > 0; x >>= 1) s += __shfl_xor(s, x, 64);  // sum over the 16 lanes of the row
+                if (live) {
+                    const float mn = fmaxf(m[g], s);
+                    const float corr = __expf(m[g] - mn), p = __expf(s - mn);
+                    l[g] = l[g] * corr + p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[g][e] = o[g][e] * corr + p * (float)vv[u][e];
+                    m[g] = mn;
+                }
+            }
+        }
+    }
+    // merge the four lane groups of the wave (lanes c, c+16, c+32, c+48 hold the same dims)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int x = 16; x <= 32; x <<= 1) {
+            const float mo = __shfl_xor(m[g], x, 64), lo = __shfl_xor(l[g], x, 64);
+            const float mn = fmaxf(m[g], mo);
+            const float ca = (m[g] == -INFINITY) ? 0.f : __expf(m[g] - mn), cb = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[g][e] = o[g][e] * ca + __shfl_xor(o[g][e], x, 64) * cb;
+            l[g] = l[g] * ca + lo * cb;
+            m[g] = mn;
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm[wave][g][8 * c + e] = o[g][e];
+            if (c == 0) {
+                sm[wave][g][D] = m[g];
+                sm[wave][g][D + 1] = l[g];
+            }
+        }
+    }
+    __syncthreads();
+    // merge the four waves: thread (g, d) for g < G, d < 128 -> G*128 threads (G <= 2) or a loop
+    const int nsplit = gridDim.x;
+    for (int idx = tid; idx < G * D; idx += 256) {
+        const int g = idx / D, d = idx % D;
+        float mn = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mn = fmaxf(mn, sm[w][g][D]);
+        float acc = 0.f, ls = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float cw = (sm[w][g][D] == -INFINITY) ? 0.f : __expf(sm[w][g][D] - mn);
+            acc += sm[w][g][d] * cw;
+            ls += sm[w][g][D + 1] * cw;
+        }
+        const int64_t head = (int64_t)b * Hq + hk * G + g;
+        if (nsplit == 1) {
+            out[head * D + d] = (half_t)(ls > 0.f ? acc / ls : 0.f);
+        } else {
+            float* pp = part + (head * nsplit + split) * (D + 2);
+            pp[d] = acc;
+            if (d == 0) {
+                pp[D] = mn;
+                pp[D + 1] = ls;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void awq_decode_attn_combine_kernel(const float* __restrict__ part, half_t* __restrict__ out,
+                                                                     int nsplit) {
+    constexpr int D = 128;
+    const int64_t head = blockIdx.x;
+    const int d = threadIdx.x;
+    const float* pp = part + head * nsplit * (D + 2);
+    float mn = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) mn = fmaxf(mn, pp[s * (D + 2) + D]);
+    float acc = 0.f, ls = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = pp[s * (D + 2) + D];
+        const float cw = (ms == -INFINITY) ? 0.f : __expf(ms - mn);
+        acc += pp[s * (D + 2) + d] * cw;
+        ls += pp[s * (D + 2) + D + 1] * cw;
+    }
+    out[head * D + d] = (half_t)(ls > 0.f ? acc / ls : 0.f);
+}
+
+}  // namespace
+
+int awq_launch_rmsnorm(const uint16_t* x, uint16_t* residual, const uint16_t* w, uint16_t* out, int64_t M, int64_t H,
+                       float eps, hipStream_t st) {
+    if (M < 0 || H <= 0 || H % 8 || H > 8192) return AWQ_ERR_BAD_SHAPE;
+    if (M == 0) return AWQ_OK;
+    if (residual)
+        hipLaunchKernelGGL(awq_rmsnorm_kernel<true>, dim3((unsigned)M), dim3(256), 0, st, reinterpret_cast<const half_t*>(x),
+                           reinterpret_cast<half_t*>(residual), reinterpret_cast<const half_t*>(w),
+                           reinterpret_cast<half_t*>(out), (int)H, eps);
+    else
+        hipLaunchKernelGGL(awq_rmsnorm_kernel<false>, dim3((unsigned)M), dim3(256), 0, st, reinterpret_cast<const half_t*>(x),
+                           nullptr, reinterpret_cast<const half_t*>(w), reinterpret_cast<half_t*>(out), (int)H, eps);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+int awq_launch_rope_kv_append(const uint16_t* qkv, uint16_t* q_out, uint16_t* k_cache, uint16_t* v_cache, const float* cos_t,
+                              const float* sin_t, const int32_t* pos_dev, int start_pos, int B, int S, int Hq, int Hkv, int D,
+                              int rot, int Tmax, hipStream_t st) {
+    if (B < 0 || S < 0 || Hq < 1 || Hkv < 1 || D < 2 || D % 2 || D > 256 || rot < 0 || rot > D || rot % 2)
+        return AWQ_ERR_BAD_SHAPE;
+    if (!pos_dev && (start_pos < 0 || start_pos + S > Tmax)) return AWQ_ERR_BAD_SHAPE;
+    if (B * S == 0) return AWQ_OK;
+    const unsigned blocks = (unsigned)((int64_t)B * S * (Hq + 2 * Hkv));
+    hipLaunchKernelGGL(awq_rope_kv_append_kernel, dim3(blocks), dim3(D / 2), 0, st, reinterpret_cast<const half_t*>(qkv),
+                       reinterpret_cast<half_t*>(q_out), reinterpret_cast<half_t*>(k_cache),
+                       reinterpret_cast<half_t*>(v_cache), cos_t, sin_t, pos_dev, start_pos, S, Hq, Hkv, D, rot, Tmax);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+size_t awq_decode_attention_workspace_bytes_impl(int B, int Hq, int max_splits) {
+    return (size_t)B * Hq * max_splits * (128 + 2) * sizeof(float);
+}
+
+template <int G>
+static void launch_attn(dim3 grid, hipStream_t st, const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out,
+                        float* part, const int32_t* len_dev, int seq_len, int Hq, int Hkv, int Tmax, float scale, int chunk) {
+    hipLaunchKernelGGL(awq_decode_attn_kernel<G>, grid, dim3(256), 0, st, reinterpret_cast<const half_t*>(q),
+                       reinterpret_cast<const half_t*>(kc), reinterpret_cast<const half_t*>(vc),
+                       reinterpret_cast<half_t*>(out), part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk);
+}
+
+int awq_launch_decode_attention(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out,
+                                const int32_t* len_dev, int seq_len, int max_len, int B, int Hq, int Hkv, int D, int Tmax,
+                                float scale, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (D != 128) return AWQ_ERR_UNSUPPORTED;
+    if (B < 0 || Hq < 1 || Hkv < 1 || Hq % Hkv || Tmax < 1) return AWQ_ERR_BAD_SHAPE;
+    const int G = Hq / Hkv;
+    if (!(G == 1 || G == 2 || G == 4 || G == 8)) return AWQ_ERR_UNSUPPORTED;
+    if (B == 0) return AWQ_OK;
+    // the split must not depend on a length that only the device knows: size it for max_len
+    const int len_for_split = len_dev ? max_len : seq_len;
+    if (len_for_split < 1 || len_for_split > Tmax) return AWQ_ERR_BAD_SHAPE;
+    // ~1024 blocks in flight, at least 64 rows per block
+    int splits = (1024 + B * Hkv - 1) / (B * Hkv);
+    const int max_by_rows = (len_for_split + 63) / 64;
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    if (splits > 1 && (!workspace || workspace_bytes < awq_decode_attention_workspace_bytes_impl(B, Hq, splits))) {
+        const size_t per = awq_decode_attention_workspace_bytes_impl(B, Hq, 1);
+        splits = workspace ? (int)(workspace_bytes / per) : 1;
+        if (splits < 1) splits = 1;
+    }
+    const int chunk = ((len_for_split + splits - 1) / splits + 15) / 16 * 16;
+    splits = (len_for_split + chunk - 1) / chunk;
+    const dim3 grid((unsigned)splits, (unsigned)Hkv, (unsigned)B);
+    float* part = static_cast<float*>(workspace);
+    switch (G) {
+        case 1: launch_attn<1>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk); break;
+        case 2: launch_attn<2>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk); break;
+        case 4: launch_attn<4>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk); break;
+        default: launch_attn<8>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk); break;
+    }
+    if (hipGetLastError() != hipSuccess) return AWQ_ERR_LAUNCH;
+    if (splits > 1) {
+        hipLaunchKernelGGL(awq_decode_attn_combine_kernel, dim3((unsigned)(B * Hq)), dim3(128), 0, st, part,
+                           reinterpret_cast<half_t*>(out), splits);
+        if (hipGetLastError() != hipSuccess) return AWQ_ERR_LAUNCH;
+    }
+    return AWQ_OK;
+}

@@ -1,0 +1,38 @@
+"""LlamaLikeBlock for MI355X (reference: awq/modules/fused/block.py:57-119): same constructor, same
+dataflow `h = x + attn(norm_1(x)); out = h + mlp(norm_2(h))`.  The first residual add and norm_2
+are one launch (`FasterTransformerRMSNorm.forward(x, residual=...)`); the sum lands in the buffer
+`o_proj` allocated, so the caller's `hidden_states` is never written."""
+import torch
+import torch.nn as nn
+
+from .attn import QuantAttentionFused
+from .norm import FasterTransformerRMSNorm
+
+
+class LlamaLikeBlock(nn.Module):
+    def __init__(self, hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, mlp, norm_1, norm_2, dev, max_seq_len,
+                 rope_theta=10000, partial_rotary_factor=1.0, use_alibi=False, head_dim=None):
+        super().__init__()
+        self.n_heads = n_heads
+        self.n_kv_heads = n_kv_heads
+        self.head_dim = head_dim if head_dim else hidden_size // n_heads
+        self.hidden_size = hidden_size
+        self.norm_1 = norm_1.to(dev)
+        self.attn = QuantAttentionFused(self.hidden_size, self.n_heads, self.n_kv_heads, qkv_layer, o_proj, dev=dev,
+                                        max_seq_len=max_seq_len, use_alibi=use_alibi, rope_theta=rope_theta,
+                                        partial_rotary_factor=partial_rotary_factor, head_dim=head_dim).to(dev)
+        self.norm_2 = norm_2.to(dev)
+        self.mlp = mlp.to(dev)
+        self.device = dev
+
+    def forward(self, hidden_states):
+        norm_out = self.norm_1(hidden_states)
+        attn_output, _, _ = self.attn.forward(hidden_states=norm_out)
+        if (isinstance(self.norm_2, FasterTransformerRMSNorm) and attn_output.dtype == hidden_states.dtype == torch.float16
+                and attn_output.is_contiguous() and hidden_states.is_contiguous()):
+            h = attn_output  # becomes hidden_states + attn_output, in place in o_proj's own output buffer
+            normed = self.norm_2(hidden_states, residual=h)
+        else:
+            h = hidden_states.to(attn_output.device) + attn_output
+            normed = self.norm_2(h)
+        return h + self.mlp.forward(normed)

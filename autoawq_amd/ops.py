@@ -316,3 +316,66 @@ def has_tiled_gemm():
 
 def last_kernel():
     return _lib.lib().awq_hip_last_kernel().decode()
+
+
+# ---- fused decoder block (csrc/decoder.hip)
+def rmsnorm(x, weight, eps, residual=None, out=None):
+    """out = rmsnorm(x) * weight (awq_rmsnorm_forward); with `residual` (same shape, updated in place):
+    residual += x, out = rmsnorm(residual) * weight."""
+    _require_gpu(x, weight, residual)
+    if x.dtype != torch.float16 or weight.dtype != torch.float16:
+        raise _lib.AwqHipError("rmsnorm expects fp16 tensors")
+    x = x.contiguous()
+    H = x.shape[-1]
+    M = x.numel() // H if H else 0
+    if out is None:
+        out = torch.empty_like(x)
+    if residual is not None and (not residual.is_contiguous() or residual.shape != x.shape or residual.dtype != x.dtype):
+        raise _lib.AwqHipError("rmsnorm: residual must be a contiguous fp16 tensor of x's shape")
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().awq_rmsnorm_forward(_ptr(x), _ptr(residual), _ptr(weight.contiguous()), _ptr(out), M, H,
+                                                  float(eps), _stream()), "awq_rmsnorm_forward")
+    return out
+
+
+def rope_kv_append(qkv, k_cache, v_cache, cos, sin, start_pos, n_heads, n_kv_heads, head_dim, rotary_dim, pos_dev=None):
+    """qkv [B, S, (Hq + 2 Hkv) * D] fp16 -> rotated q [B, S, Hq, D]; rotated k and v are written into
+    the caches [B, Tmax, Hkv, D] at rows start_pos .. start_pos + S - 1 (awq_rope_kv_append)."""
+    _require_gpu(qkv, k_cache, v_cache, cos, sin, pos_dev)
+    B, S = qkv.shape[0], qkv.shape[1]
+    qkv = qkv.contiguous()
+    q = torch.empty((B, S, n_heads, head_dim), dtype=torch.float16, device=qkv.device)
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()) or k_cache.shape[0] < B:
+        raise _lib.AwqHipError("rope_kv_append: caches must be contiguous [>=B, Tmax, Hkv, D]")
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.lib().awq_rope_kv_append(_ptr(qkv), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(cos), _ptr(sin),
+                                                 _ptr(pos_dev), int(start_pos), B, S, n_heads, n_kv_heads, head_dim,
+                                                 rotary_dim, k_cache.shape[1], _stream()), "awq_rope_kv_append")
+    return q
+
+
+_attn_workspaces = {}
+
+
+def decode_attention(q, k_cache, v_cache, seq_len, scale=None, len_dev=None, max_len=None):
+    """q [B, Hq, 128] fp16, caches [B, Tmax, Hkv, 128] -> [B, Hq, 128]: attention of ONE query token per
+    sequence over cache rows [0, seq_len) (awq_decode_attention)."""
+    _require_gpu(q, k_cache, v_cache, len_dev)
+    B, Hq, D = q.shape
+    Hkv, Tmax = k_cache.shape[2], k_cache.shape[1]
+    q = q.contiguous()
+    out = torch.empty_like(q)
+    L = _lib.lib()
+    key = (q.device.index if q.device.index is not None else torch.cuda.current_device(), _stream())
+    need = L.awq_decode_attention_workspace_bytes(B, Hq)
+    ws = _attn_workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        _attn_workspaces[key] = ws
+    if scale is None:
+        scale = D ** -0.5
+    with torch.cuda.device(q.device):
+        _lib.check(L.awq_decode_attention(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(len_dev), int(seq_len),
+                                          int(max_len if max_len is not None else seq_len), B, Hq, Hkv, D, Tmax,
+                                          float(scale), _ptr(ws), ws.numel(), _stream()), "awq_decode_attention")
+    return out

@@ -159,6 +159,40 @@ AWQ_EXPORT int awq_dequantize_weights_gemv_fast(const int16_t* qweight, const ui
                                                 const uint16_t* qzeros, uint16_t* out, int64_t K, int64_t N,
                                                 int64_t group_size, void* stream);
 
+/* ---- fused decoder block around the Linears ------------------------------- */
+
+/* Replaces awq_ext.layernorm_forward_cuda(x, weight, out, eps) (awq/modules/fused/norm.py:33-36):
+ * out [M, H] = fp16( x * rsqrt(mean(x^2) + eps) * weight ), fp32 arithmetic.  H % 8 == 0, H <= 8192.
+ * If `residual` is non-NULL it is first updated in place, residual = fp16(residual + x), and the
+ * updated row is what gets normalised (`h = hidden_states + attn_output` followed by the next norm,
+ * awq/modules/fused/block.py:108-119, in one launch). */
+AWQ_EXPORT int awq_rmsnorm_forward(const uint16_t* x, uint16_t* residual, const uint16_t* weight, uint16_t* out,
+                                   int64_t M, int64_t H, float eps, void* stream);
+
+/* RoPE.forward (awq/modules/fused/attn.py:54-87) + WindowedCache.update_kv (cache.py:40-45) on the
+ * fused qkv output: qkv [B*S, (n_heads + 2*n_kv_heads) * head_dim] fp16 (q heads | k heads | v heads).
+ * Rotates pairs (i, i + rotary_dim/2) of every q and k head by the angle of position start_pos + s
+ * (cos / sin [max_pos, rotary_dim/2] fp32, built like RoPE.precompute_freqs_cis), writes q to
+ * q_out [B*S, n_heads, head_dim] and k / v into k_cache / v_cache [B, max_seq, n_kv_heads, head_dim]
+ * at row start_pos + s.  If pos_dev is non-NULL the start position is read from it on the device
+ * (one hipGraph can then be replayed for every decode step). */
+AWQ_EXPORT int awq_rope_kv_append(const uint16_t* qkv, uint16_t* q_out, uint16_t* k_cache, uint16_t* v_cache,
+                                  const float* cos_table, const float* sin_table, const int32_t* pos_dev,
+                                  int64_t start_pos, int64_t B, int64_t S, int64_t n_heads, int64_t n_kv_heads,
+                                  int64_t head_dim, int64_t rotary_dim, int64_t max_seq, void* stream);
+
+/* Replaces flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, causal=True) for ONE query
+ * token per sequence (attn.py:286-302): out [B, n_heads, 128] = softmax(q k^T * scale) v over cache
+ * rows [0, seq_len).  head_dim = 128, n_heads / n_kv_heads in {1, 2, 4, 8}.  If len_dev is non-NULL
+ * the length is read on the device and max_len (>= the length, <= max_seq) sizes the launch.
+ * workspace: awq_decode_attention_workspace_bytes(B, n_heads) bytes of scratch (split-sequence
+ * partials), no state between calls. */
+AWQ_EXPORT size_t awq_decode_attention_workspace_bytes(int64_t B, int64_t n_heads);
+AWQ_EXPORT int awq_decode_attention(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out,
+                                    const int32_t* len_dev, int64_t seq_len, int64_t max_len, int64_t B,
+                                    int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq, float scale,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

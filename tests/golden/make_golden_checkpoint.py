@@ -42,7 +42,7 @@ G = 128
 
 def skeleton():
     cfg = LlamaConfig(vocab_size=64, hidden_size=256, intermediate_size=512, num_hidden_layers=1,
-                      num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=64,
+                      num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=64,
                       tie_word_embeddings=False)
     torch.manual_seed(0)
     return LlamaForCausalLM(cfg).half().eval()
@@ -80,3 +80,18 @@ for version, cls in (("gemm", WQLinear_GEMM), ("gemv", WQLinear_GEMV), ("gemv_fa
                             logits=logits.float().numpy(), h=h.numpy(), mlp_out=mlp_out.float().numpy(),
                             q_out=q_out.float().numpy())
     print(version, sorted(os.listdir(out)), sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)))
+
+# RoPE of the fused attention (awq/modules/fused/attn.py:27-87), run as the reference runs it
+from awq.modules.fused.attn import RoPE  # noqa: E402
+
+g = torch.Generator().manual_seed(5)
+cases = {}
+for name, (D, rot, start, S) in {"full": (128, 128, 3, 5), "partial": (128, 64, 0, 4), "late": (128, 128, 57, 1)}.items():
+    xq = torch.randn((2, S, 4, D), generator=g).half()
+    xk = torch.randn((2, S, 2, D), generator=g).half()
+    rope = RoPE(rot, 64, "cpu", 10000.0)
+    q, k = rope.forward(xq, xk, start, S, partial=rot < D)
+    cases.update({f"{name}_xq": xq.numpy(), f"{name}_xk": xk.numpy(), f"{name}_q": q.numpy(), f"{name}_k": k.numpy(),
+                  f"{name}_meta": np.array([D, rot, start, S])})
+np.savez_compressed(os.path.join(HERE, "rope_golden.npz"), **cases)
+print("rope golden", sorted(cases)[:4])

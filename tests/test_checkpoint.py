@@ -22,7 +22,7 @@ def skeleton():
     from transformers import LlamaConfig, LlamaForCausalLM
 
     cfg = LlamaConfig(vocab_size=64, hidden_size=256, intermediate_size=512, num_hidden_layers=1,
-                      num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=64,
+                      num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=64,
                       tie_word_embeddings=False)
     torch.manual_seed(0)
     return LlamaForCausalLM(cfg).half().eval()
@@ -134,7 +134,7 @@ def test_fuse_qkv_on_loaded_checkpoint(version):
     model, _ = load_quantized(skeleton(), ckpt(version))
     att = model.model.layers[0].self_attn
     fused = fuse_qkv(att, att.q_proj, att.k_proj, att.v_proj)
-    assert fused.in_features == 256 and fused.out_features == 256 + 128 + 128
+    assert fused.in_features == 256 and fused.out_features == 256 + 128 + 128  # 2 q heads + 1 k + 1 v of 128
     assert type(fused) is type(att.q_proj)
 
 

@@ -1,0 +1,232 @@
+"""Fused decoder block around the int4 Linears: RMSNorm (+ residual),
+RoPE + KV append, single-query attention, LlamaLikeBlock / LlamaLikeModel.
+
+CPU: the oracle's RoPE restatement against the reference's own RoPE class (tests/golden/
+rope_golden.npz), host logic of the cache / input-id handling.  GPU: each kernel against the
+oracle, then the whole fused model (prefill + token-by-token decode, eager and as a replayed
+hipGraph) against the logits the reference computed on CPU from the same checkpoint.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden
+from test_checkpoint import ckpt, skeleton
+
+
+def ulp16(a):
+    return np.maximum(np.abs(np.asarray(a, np.float64)), 2.0 ** -14) * 2.0 ** -10
+
+
+# ------------------------------------------------------------------ CPU
+
+@pytest.mark.parametrize("name", ["full", "partial", "late"])
+def test_oracle_rope_matches_reference_class(name):
+    from oracle import decoder_oracle
+
+    g = golden("rope_golden")
+    D, rot, start, S = [int(v) for v in g[f"{name}_meta"]]
+    q, k = decoder_oracle.rope_reference(torch.from_numpy(g[f"{name}_xq"]), torch.from_numpy(g[f"{name}_xk"]), start, rot, 64)
+    assert np.array_equal(q[..., :rot].numpy().view(np.uint16), g[f"{name}_q"].view(np.uint16))
+    assert np.array_equal(k[..., :rot].numpy().view(np.uint16), g[f"{name}_k"].view(np.uint16))
+    assert torch.equal(q[..., rot:], torch.from_numpy(g[f"{name}_xq"])[..., rot:])  # pass-through dims
+
+
+def test_oracle_rmsnorm_close_to_transformers_rmsnorm():
+    from oracle import decoder_oracle
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+
+    gen = torch.Generator().manual_seed(0)
+    x = (torch.randn((5, 256), generator=gen) * 3).half()
+    norm = LlamaRMSNorm(256, eps=1e-5).half()
+    norm.weight.data = (torch.rand(256, generator=gen) + 0.5).half()
+    want = norm(x).detach().numpy().astype(np.float64)
+    got = decoder_oracle.rmsnorm_reference(x.numpy(), norm.weight.detach().numpy(), 1e-5).astype(np.float64)
+    assert (np.abs(got - want) <= 2 * ulp16(want)).all()  # HF rounds twice, the fused form once
+
+
+def test_input_id_and_cache_bookkeeping():
+    from autoawq_amd.modules.fused.cache import WindowedCache
+    from autoawq_amd.modules.fused.model import prepare_input_ids
+
+    ids = torch.arange(10).reshape(1, 10)
+    out, n = prepare_input_ids(ids, 0)
+    assert out.shape[1] == 10 and n == 10
+    out, n = prepare_input_ids(torch.arange(11).reshape(1, 11), 10)  # transformers passes the whole context
+    assert out.shape[1] == 1 and int(out[0, 0]) == 10 and n == 11
+    out, n = prepare_input_ids(torch.tensor([[7]]), 11)
+    assert out.shape[1] == 1 and n == 12
+    c = WindowedCache(2, 4, 2, 8, 16, "cpu")
+    assert c.k.shape == (2, 16, 2, 8)
+    c.k[:, :, :, :] = torch.arange(16, dtype=torch.float16).reshape(1, 16, 1, 1)
+    c.v[:] = c.k
+    assert c.roll_kv_n_steps(12, n=5) == 7
+    assert float(c.k[0, 0, 0, 0]) == 5.0 and float(c.k[0, 10, 0, 0]) == 15.0 and float(c.k[0, 11, 0, 0]) == 0.0
+
+
+def test_fused_module_surfaces():
+    """Constructor signatures the reference's fusers use (awq/models/llama.py:100-175)."""
+    import inspect
+
+    from autoawq_amd.modules.fused.attn import QuantAttentionFused
+    from autoawq_amd.modules.fused.block import LlamaLikeBlock
+    from autoawq_amd.modules.fused.model import LlamaLikeModel
+    from autoawq_amd.modules.fused.norm import FasterTransformerRMSNorm
+
+    assert list(inspect.signature(LlamaLikeBlock.__init__).parameters)[1:12] == [
+        "hidden_size", "n_heads", "n_kv_heads", "qkv_layer", "o_proj", "mlp", "norm_1", "norm_2", "dev", "max_seq_len",
+        "rope_theta"]
+    assert list(inspect.signature(QuantAttentionFused.__init__).parameters)[1:8] == [
+        "hidden_size", "n_heads", "n_kv_heads", "qkv_layer", "o_proj", "dev", "max_seq_len"]
+    assert list(inspect.signature(LlamaLikeModel.__init__).parameters)[1:] == ["vocab_size", "blocks", "embedding", "norm"]
+    assert list(inspect.signature(FasterTransformerRMSNorm.__init__).parameters)[1:] == ["weight", "eps"]
+
+
+# ------------------------------------------------------------------ GPU kernels
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from autoawq_amd import _lib, ops as _ops
+
+    _lib.lib()
+    return _ops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,H", [(1, 4096), (3, 256), (17, 5120), (2, 8192), (4, 136)])
+def test_rmsnorm_vs_oracle(ops, M, H):
+    from oracle import decoder_oracle
+
+    gen = torch.Generator().manual_seed(M * 1000 + H)
+    x = (torch.randn((M, H), generator=gen) * 2).half()
+    w = (torch.rand(H, generator=gen) + 0.5).half()
+    want = decoder_oracle.rmsnorm_reference(x.numpy(), w.numpy(), 1e-5).astype(np.float64)
+    got = ops.rmsnorm(x.cuda(), w.cuda(), 1e-5).cpu().numpy().astype(np.float64)
+    assert (np.abs(got - want) <= ulp16(want)).all()
+    # residual form: r <- fp16(r + x) bit for bit, and the norm of that
+    r = torch.randn((M, H), generator=gen).half()
+    rd = r.cuda()
+    got2 = ops.rmsnorm(x.cuda(), w.cuda(), 1e-5, residual=rd).cpu().numpy().astype(np.float64)
+    rsum = (x.float() + r.float()).half()
+    assert torch.equal(rd.cpu(), rsum)
+    want2 = decoder_oracle.rmsnorm_reference(rsum.numpy(), w.numpy(), 1e-5).astype(np.float64)
+    assert (np.abs(got2 - want2) <= ulp16(want2)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["full", "partial", "late"])
+def test_rope_kv_append_vs_reference_rope(ops, name):
+    """q, and the cache rows written, equal the reference RoPE class's output (<= 1 fp16 ulp: the
+    complex multiply may or may not contract into an fma); untouched cache rows stay as they were;
+    device-side start position gives the same result."""
+    from autoawq_amd.modules.fused.attn import RoPE
+
+    g = golden("rope_golden")
+    D, rot, start, S = [int(v) for v in g[f"{name}_meta"]]
+    xq, xk = torch.from_numpy(g[f"{name}_xq"]), torch.from_numpy(g[f"{name}_xk"])
+    B, _, Hq, _ = xq.shape
+    Hkv = xk.shape[2]
+    xv = torch.randn((B, S, Hkv, D), generator=torch.Generator().manual_seed(1)).half()
+    qkv = torch.cat([xq.reshape(B, S, -1), xk.reshape(B, S, -1), xv.reshape(B, S, -1)], dim=-1).cuda()
+    rope = RoPE(rot, 64, "cuda", 10000.0)
+    for use_dev in (False, True):
+        kc = torch.full((B, 64, Hkv, D), 7.0, dtype=torch.float16, device="cuda")
+        vc = torch.full((B, 64, Hkv, D), 9.0, dtype=torch.float16, device="cuda")
+        pos = torch.tensor([start], dtype=torch.int32, device="cuda") if use_dev else None
+        q = ops.rope_kv_append(qkv, kc, vc, rope.cos, rope.sin, 0 if use_dev else start, Hq, Hkv, D, rot, pos_dev=pos)
+        qn, kn = q.cpu().numpy().astype(np.float64), kc[:, start:start + S].cpu().numpy().astype(np.float64)
+        assert (np.abs(qn[..., :rot] - g[f"{name}_q"]) <= ulp16(g[f"{name}_q"])).all()
+        assert (np.abs(kn[..., :rot] - g[f"{name}_k"]) <= ulp16(g[f"{name}_k"])).all()
+        assert torch.equal(q[..., rot:].cpu(), xq[..., rot:]) and torch.equal(kc[:, start:start + S, :, rot:].cpu(), xk[..., rot:])
+        assert torch.equal(vc[:, start:start + S].cpu(), xv)
+        assert bool((kc[:, :start] == 7.0).all()) and bool((kc[:, start + S:] == 7.0).all())
+        assert bool((vc[:, :start] == 9.0).all()) and bool((vc[:, start + S:] == 9.0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Hq,Hkv,T", [(1, 32, 32, 1), (1, 32, 32, 77), (2, 8, 4, 300), (1, 32, 8, 2048), (3, 16, 2, 129),
+                                       (1, 32, 32, 4096), (2, 4, 4, 16)])
+def test_decode_attention_vs_oracle(ops, B, Hq, Hkv, T):
+    from oracle import decoder_oracle
+
+    gen = torch.Generator().manual_seed(B * 7 + Hq + T)
+    Tmax = max(T + 5, 64)
+    q = torch.randn((B, Hq, 128), generator=gen).half()
+    kc = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    vc = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    kc[:, T:] = 100.0  # rows past the length must not be read
+    vc[:, T:] = 100.0
+    want = decoder_oracle.attention_reference(q.numpy(), kc.numpy(), vc.numpy(), T)
+    got = ops.decode_attention(q.cuda(), kc.cuda(), vc.cuda(), T).cpu().numpy().astype(np.float64)
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 2 ** -11
+    ln = torch.tensor([T], dtype=torch.int32, device="cuda")  # device-side length, launch sized for the whole cache
+    got2 = ops.decode_attention(q.cuda(), kc.cuda(), vc.cuda(), 1, len_dev=ln, max_len=Tmax).cpu().numpy().astype(np.float64)
+    assert np.abs(got2 - want).max() <= 2e-3 * np.abs(want).max() + 2 ** -11
+
+
+# ------------------------------------------------------------------ GPU: the fused model
+
+def _fused(version, max_seq_len=32):
+    from autoawq_amd.checkpoint import load_quantized
+    from autoawq_amd.fuser import fuse_llama
+
+    model, _ = load_quantized(skeleton(), ckpt(version), device="cuda")
+    return fuse_llama(model, max_seq_len=max_seq_len)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", ["gemm", "gemv"])
+def test_fused_model_prefill_then_decode_matches_reference_logits(version):
+    """8 context tokens in one forward, then 4 tokens one at a time through the KV cache: the logits
+    of every position equal the reference's full-sequence logits (causal attention: the same numbers)."""
+    g = golden("tiny_llama_awq_gemm_outputs")
+    ref = g["logits"]
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    lm = _fused(version)
+    rng = np.abs(ref).max()
+    out = lm(ids[:, :8]).float().cpu().numpy()
+    assert np.abs(out - ref[:, :8]).max() <= 2e-2 * rng
+    for t in range(8, 12):
+        step = lm(ids[:, t:t + 1]).float().cpu().numpy()
+        assert step.shape == (2, 1, 64)
+        assert np.abs(step[:, 0] - ref[:, t]).max() <= 2e-2 * rng, t
+    assert lm.model.blocks[0].attn.start_pos == 12
+
+
+@pytest.mark.gpu
+def test_fused_decode_step_replayed_as_one_hipgraph():
+    """Positions live in device tensors: ONE captured decode step is replayed for four tokens."""
+    g = golden("tiny_llama_awq_gemm_outputs")
+    ref = g["logits"]
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    lm = _fused("gemm")
+    lm(ids[:, :8])
+    pos = torch.tensor([8], dtype=torch.int32, device="cuda")
+    ln = torch.tensor([9], dtype=torch.int32, device="cuda")
+    for blk in lm.model.blocks:
+        blk.attn.use_device_positions(pos, ln)
+    tok = ids[:, 8:9].clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        lm(tok)  # warm-up (eager), then rewind
+        for blk in lm.model.blocks:
+            blk.attn.start_pos = 8
+        lm.model.last_forward_num_tokens = 8
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            logits = lm(tok)
+            pos.add_(1)
+            ln.add_(1)
+    pos.fill_(8)
+    ln.fill_(9)
+    rng = np.abs(ref).max()
+    for t in range(8, 12):
+        tok.copy_(ids[:, t:t + 1])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.abs(logits.float().cpu().numpy()[:, 0] - ref[:, t]).max() <= 2e-2 * rng, t
+    assert int(pos.item()) == 12
