@@ -19,6 +19,7 @@ struct AwqGemmArgs {
     const uint16_t* bias;    // [N] or null
     uint16_t* y;             // [M, N]
     int M, K, N, g;
+    int x_gated = 0;  // x is [M, 2K] = [gate | up]; the kernel stages silu(gate) * up (decode kernel only)
     int* counters;   // control words (word 0 = error flag), zero on entry
     float* exchange;  // in-launch split-K exchange region: all-ones sentinel on entry AND on exit
     size_t exchange_bytes;

@@ -107,7 +107,10 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
         a.partial_floats = half / sizeof(float);
     }
 
+    a.x_gated = (flags & AWQ_GEMM_FLAG_X_GATED_SILU) ? 1 : 0;
+    if (a.x_gated && (M > 16 || !awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2))) return AWQ_ERR_UNSUPPORTED;
     unsigned kern = AWQ_GEMM_FLAG_KERNEL(flags);
+    if (a.x_gated && kern != AWQ_GEMM_KERNEL_AUTO && kern != AWQ_GEMM_KERNEL_MFMA_GEMV) return AWQ_ERR_UNSUPPORTED;
     int nlog = (int)AWQ_GEMM_FLAG_NLOG(flags);
     int splitk = (int)AWQ_GEMM_FLAG_SPLITK(flags);
     const int waves = (int)AWQ_GEMM_FLAG_WAVES(flags);
@@ -123,6 +126,7 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
                 return rc;
             }
         }
+        if (a.x_gated) return AWQ_ERR_UNSUPPORTED;
         if (M > 16 && awq_gemm_tiled_supports(a.M, a.K, a.N, a.g)) kern = AWQ_GEMM_KERNEL_TILED;
         else kern = AWQ_GEMM_KERNEL_NAIVE;  // odd shapes
     }

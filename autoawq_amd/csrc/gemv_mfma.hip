@@ -47,6 +47,7 @@ struct GemvMfmaParams {
     const uint32_t* qzeros;
     const half_t* scales;
     const half_t* x;
+    int x_gated;              // x rows are [gate | up] of 2K halves: stage silu(gate) * up
     const half_t* bias;
     half_t* y;
     float* slabs;    // in-launch exchange region [S-1][tiles][M][CW] fp32: all-ones sentinel on entry and on exit
@@ -133,7 +134,9 @@ __device__ unsigned long long* g_awq_trace = nullptr;
 // NREG: live D registers per lane (2 when M == 1, else 4).  UNIT: 16-row sets a wave streams per
 // loop iteration (4*UNIT loads per lane in flight); FOLDS: group folds per unit (UNIT*16/FOLDS
 // rows each: a divisor of g, <= 128).
-template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool NT, bool MOE = false>
+// GATED: x rows are [gate | up] of 2K halves and silu(gate) * up is applied while staging (a template
+// parameter, not a runtime flag: the plain instantiations must not carry the extra registers).
+template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool NT, bool MOE = false, bool GATED = false>
 __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaParams p) {
     typedef typename Words<WPL>::T WV;
     constexpr int CPL = 8 * WPL;         // columns per lane
@@ -188,8 +191,18 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     constexpr int SC = CW / 8;   // 16-byte chunks of scales per group row of the tile
     const int xchunks = RS >> 3;  // 16-byte chunks per activation row
     const bool reg_staged = (M + 1) * xchunks <= NTHR && ng * SC <= NTHR;
-    u32x4 st_x = {0u, 0u, 0u, 0u}, st_q = st_x, st_s = st_x;
-    auto x_chunk = [&](int c) -> u32x4 {
+    u32x4 st_x = {0u, 0u, 0u, 0u}, st_q = st_x, st_s = st_x, st_u = st_x;
+    auto silu_mul = [](u32x4 gate, u32x4 upv) -> u32x4 {  // fp32, one rounding: == awq_silu_and_mul_kernel
+        const half8_t gt = __builtin_bit_cast(half8_t, gate), uu = __builtin_bit_cast(half8_t, upv);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xv = (float)gt[e];
+            o[e] = (half_t)((xv / (1.0f + expf(-xv))) * (float)uu[e]);
+        }
+        return __builtin_bit_cast(u32x4, o);
+    };
+    auto x_chunk = [&](int c, bool up = false) -> u32x4 {
         const int m = c / xchunks, cc = c % xchunks;
         const int row = r0 + 8 * cc;
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -201,7 +214,8 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                 ok = pid < p.num_pairs;
                 xrow = pid / p.x_div;
             }
-            if (ok) v = *reinterpret_cast<const u32x4*>(p.x + xrow * p.K + row);
+            // x_gated (fused-MLP down projection): rows are [gate | up] of 2K halves; `up` selects the half
+            if (ok) v = *reinterpret_cast<const u32x4*>(p.x + xrow * (GATED ? 2 * p.K : p.K) + (up ? p.K : 0) + row);
         }
         return v;
     };
@@ -224,11 +238,14 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     auto s_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(zsc + (c / SC) * CW + 8 * (c % SC)) = v; };
     constexpr bool LATE = NREG == 4;  // batch > 1 (the M = 1 instantiations keep their register budget)
     if (reg_staged) {
-        if (tid < (M + 1) * xchunks) st_x = x_chunk(tid);
+        if (tid < (M + 1) * xchunks) {
+            st_x = x_chunk(tid);
+            if (GATED) st_u = x_chunk(tid, true);  // the activation itself waits until the weights are requested
+        }
         if (tid < ng * QC) st_q = q_chunk(tid);
         if (tid < ng * SC) st_s = s_chunk(tid);
     } else if (!LATE) {
-        for (int c = tid; c < (M + 1) * xchunks; c += NTHR) x_store(c, x_chunk(c));
+        for (int c = tid; c < (M + 1) * xchunks; c += NTHR) x_store(c, GATED ? silu_mul(x_chunk(c), x_chunk(c, true)) : x_chunk(c));
         for (int c = tid; c < ng * QC; c += NTHR) q_store(c, q_chunk(c));
         for (int c = tid; c < ng * SC; c += NTHR) s_store(c, s_chunk(c));
     }
@@ -238,11 +255,11 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     // which also brought the M > 8 instantiations back to two waves per SIMD).
     auto finish_staging = [&]() {
         if (reg_staged) {
-            if (tid < (M + 1) * xchunks) x_store(tid, st_x);
+            if (tid < (M + 1) * xchunks) x_store(tid, GATED ? silu_mul(st_x, st_u) : st_x);
             if (tid < ng * QC) q_store(tid, st_q);
             if (tid < ng * SC) s_store(tid, st_s);
         } else if (LATE) {
-            for (int c = tid; c < (M + 1) * xchunks; c += NTHR) x_store(c, x_chunk(c));
+            for (int c = tid; c < (M + 1) * xchunks; c += NTHR) x_store(c, GATED ? silu_mul(x_chunk(c), x_chunk(c, true)) : x_chunk(c));
             for (int c = tid; c < ng * QC; c += NTHR) q_store(c, q_chunk(c));
             for (int c = tid; c < ng * SC; c += NTHR) s_store(c, s_chunk(c));
         }
@@ -516,22 +533,34 @@ __global__ __launch_bounds__(256) void awq_gemv_mfma_reduce_kernel(const float* 
     *reinterpret_cast<half4_t*>(y + i4) = o;
 }
 
-template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS>
+template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool GATED = false>
 void launch6(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
     // dynamic LDS above 64 KiB needs the opt-in once per kernel (host-side attribute, no sync)
     static const bool lds_opt_in = [] {
         (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true>),
+            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true, false, GATED>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)lds_opt_in;
-    hipLaunchKernelGGL((awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true>), grid, dim3(NWAVES * 64), lds, st, p);
+    hipLaunchKernelGGL((awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true, false, GATED>), grid,
+                       dim3(NWAVES * 64), lds, st, p);
 }
 
 template <int WPL, int NWAVES, int UNIT>
 bool launch3(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
     constexpr int UROWS = 16 * UNIT;
+    if (p.x_gated) {  // instantiated for the configurations the dispatcher picks by itself
+        if constexpr (WPL == 2 && NWAVES >= 4 && UNIT <= 4) {
+            if (p.g % UROWS) return false;
+            if (p.M == 1) launch6<WPL, NWAVES, UNIT, true, 2, 1, true>(p, grid, lds, st);
+            else if (p.M <= 8) launch6<WPL, NWAVES, UNIT, true, 4, 1, true>(p, grid, lds, st);
+            else if constexpr (NWAVES <= 4) launch6<WPL, NWAVES, UNIT, false, 4, 1, true>(p, grid, lds, st);
+            else return false;
+            return true;
+        }
+        return false;
+    }
     if (p.g % UROWS == 0) {  // a unit lies inside one group: one fold per unit
         if (p.M == 1) launch6<WPL, NWAVES, UNIT, true, 2, 1>(p, grid, lds, st);
         else if (p.M <= 8) launch6<WPL, NWAVES, UNIT, true, 4, 1>(p, grid, lds, st);
@@ -707,6 +736,7 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     p.qzeros = reinterpret_cast<const uint32_t*>(a.qzeros);
     p.scales = reinterpret_cast<const half_t*>(a.scales);
     p.x = reinterpret_cast<const half_t*>(a.x);
+    p.x_gated = a.x_gated;
     p.bias = nullptr;
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
@@ -748,6 +778,7 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
     p.qzeros = reinterpret_cast<const uint32_t*>(a.qzeros);
     p.scales = reinterpret_cast<const half_t*>(a.scales);
     p.x = reinterpret_cast<const half_t*>(a.x);
+    p.x_gated = a.x_gated;
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;

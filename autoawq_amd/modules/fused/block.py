@@ -36,3 +36,13 @@ class LlamaLikeBlock(nn.Module):
             h = hidden_states.to(attn_output.device) + attn_output
             normed = self.norm_2(h)
         return h + self.mlp.forward(normed)
+
+    def forward_stream(self, x, h):
+        """Residual stream kept by the caller (LlamaLikeModel): `h` is the stream, `x` the previous
+        block's MLP output that has not been added yet (None for the first block).  Both residual
+        adds ride on the norms -- two fused add+norm launches per block, no separate add -- and the
+        pair (mlp output, stream) goes to the next block."""
+        norm_out = self.norm_1(h) if x is None else self.norm_1(x, residual=h)
+        attn_output, _, _ = self.attn.forward(hidden_states=norm_out)
+        normed = self.norm_2(attn_output, residual=h)
+        return self.mlp.forward(normed), h

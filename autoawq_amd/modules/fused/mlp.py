@@ -17,6 +17,8 @@ from ..linear.gemv import WQLinear_GEMV
 
 
 class QuantFusedMLP(nn.Module):
+    FUSE_ACTIVATION_INTO_DOWN = True  # decode-sized batches, GEMM layout
+
     def __init__(self, gate_proj, down_proj, up_proj, activation=F.silu):
         super().__init__()
         self.register_buffer("gate_proj_qweight", gate_proj.qweight)
@@ -58,6 +60,16 @@ class QuantFusedMLP(nn.Module):
             gate_up = ops.gemv_forward(x, qw, sc, qz, self.group_size)
         else:
             gate_up = ops.gemm_forward(x, qw, sc, qz)
+        if (self.activation is F.silu and not self.gemv_layout and gate_up.shape[0] <= 16 and in_dtype == torch.float16
+                and isinstance(self.down_proj, WQLinear_GEMM) and self.FUSE_ACTIVATION_INTO_DOWN):
+            # decode: silu(gate) * up is applied by the down projection while it stages its activations
+            # (AWQ_GEMM_FLAG_X_GATED_SILU): one launch less, bit-identical to the separate kernel
+            d = self.down_proj
+            out = ops.gemm_forward(gate_up, d.qweight, d.scales, d.qzeros, d.bias, flags=ops.X_GATED_SILU)
+            out = out.reshape(out_shape[:-1] + (self.out_features,))
+            if routing_weights is not None:
+                out = routing_weights * out
+            return out
         if self.activation is F.silu:
             h = ops.silu_and_mul(gate_up)
         else:

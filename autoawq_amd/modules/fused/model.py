@@ -45,15 +45,29 @@ class LlamaLikeModel(nn.Module):
     def layers(self):
         return self.blocks
 
+    def _stream_mode(self, h):
+        from .block import LlamaLikeBlock
+        from .norm import FasterTransformerRMSNorm
+
+        return (h.dtype == torch.float16 and h.is_contiguous() and isinstance(self.norm, FasterTransformerRMSNorm)
+                and all(isinstance(b, LlamaLikeBlock) and isinstance(b.norm_1, FasterTransformerRMSNorm)
+                        and isinstance(b.norm_2, FasterTransformerRMSNorm) for b in self.blocks))
+
     @torch.inference_mode()
     def forward(self, input_ids, *args, **kwargs):
         input_ids, self.last_forward_num_tokens = prepare_input_ids(input_ids, self.last_forward_num_tokens)
         _bsz, seqlen = input_ids.shape
         prepare_cache(self.blocks, seqlen)
         h = self.embedding(input_ids)
-        for layer in self.blocks:
-            h = layer(h)
-        h = self.norm(h)
+        if self._stream_mode(h):
+            x = None
+            for layer in self.blocks:  # the residual adds ride on the next norm (block.forward_stream)
+                x, h = layer.forward_stream(x, h)
+            h = self.norm(x, residual=h) if x is not None else self.norm(h)
+        else:
+            for layer in self.blocks:
+                h = layer(h)
+            h = self.norm(h)
         try:
             from transformers.modeling_outputs import BaseModelOutputWithPast
 

@@ -98,13 +98,20 @@ def dequantize_weights(qweight, scales, qzeros):
     return out
 
 
+X_GATED_SILU = 1 << 18  # AWQ_GEMM_FLAG_X_GATED_SILU
+
+
 def gemm_forward(x2d, qweight, scales, qzeros, bias=None, flags=0):
-    """y [M, N] fp16 = x2d [M, K] fp16 @ dequant(GEMM-layout buffers) (+ bias) (awq_gemm_forward)."""
+    """y [M, N] fp16 = x2d [M, K] fp16 @ dequant(GEMM-layout buffers) (+ bias) (awq_gemm_forward).
+    With flags | X_GATED_SILU, x2d is [M, 2K] = [gate | up] and the kernel applies silu(gate) * up
+    while staging (M <= 16)."""
     _require_gpu(x2d, qweight, scales, qzeros, bias)
     if x2d.dtype != torch.float16:
         raise _lib.AwqHipError("gemm_forward expects fp16 activations")
     x2d, qweight, scales, qzeros = x2d.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
     M, K = x2d.shape
+    if flags & X_GATED_SILU:
+        K //= 2
     N = qweight.shape[1] * 8
     G = qzeros.shape[0]
     if qweight.shape[0] != K or G == 0 or K % G:

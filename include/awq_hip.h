@@ -90,6 +90,11 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
 #define AWQ_GEMM_FLAG_SPLITK(f) (((f) >> 8) & 0xFFu) /* 0 = auto */
 #define AWQ_GEMM_FLAG_TWO_PASS (1u << 16) /* MFMA_GEMV: split-K reduce in a second kernel instead of in-launch */
 #define AWQ_GEMM_FLAG_NO_NT (1u << 17)    /* plain (temporal) weight loads */
+/* x is [M, 2K] = [gate | up] and the kernel multiplies silu(gate) * up (fp32, one rounding -- exactly
+ * awq_silu_and_mul) while it stages the activations: the down projection of a fused MLP
+ * (awq/modules/fused/mlp.py:46-70) without the separate elementwise launch.  M <= 16 only
+ * (AWQ_ERR_UNSUPPORTED otherwise: run awq_silu_and_mul first). */
+#define AWQ_GEMM_FLAG_X_GATED_SILU (1u << 18)
 #define AWQ_GEMM_FLAG_UNIT(f) (((f) >> 20) & 0xFu)  /* MFMA_GEMV: 16-row sets per wave iteration (2|4|8), 0 = auto */
 #define AWQ_GEMM_FLAG_WAVES(f) (((f) >> 24) & 0xFu) /* MFMA_GEMV: waves per block (2|4|8), 0 = auto */
 

@@ -562,6 +562,29 @@ def test_quant_fused_mlp_vs_oracle(ops, oracle, layout):
     assert (err <= 4e-3 * np.abs(y32) + 4e-3 * rms).all(), err.max() / rms
     rw = torch.tensor([[0.25], [0.5], [1.0]], dtype=torch.float16, device="cuda")
     assert torch.equal(mlp(x.cuda()[0], routing_weights=rw), rw * mlp(x.cuda()[0]))
+    if layout == "gemm":  # the activation fused into the down projection == the separate silu_and_mul launch, bit for bit
+        assert mlp.FUSE_ACTIVATION_INTO_DOWN
+        mlp.FUSE_ACTIVATION_INTO_DOWN = False
+        unfused = mlp(x.cuda())
+        mlp.FUSE_ACTIVATION_INTO_DOWN = True
+        assert torch.equal(out, unfused)
+
+
+@pytest.mark.parametrize("M", [1, 2, 8, 9, 16])
+@pytest.mark.parametrize("K,N", [(512, 256), (11008, 4096), (1408, 4096)])
+def test_gated_silu_staging_equals_separate_kernel(ops, M, K, N):
+    """AWQ_GEMM_FLAG_X_GATED_SILU: x = [gate | up]; staging silu(gate) * up inside the decode kernel gives
+    the result of awq_silu_and_mul followed by the plain call, bitwise (same fp32 formula, one rounding)."""
+    qw, qz, s, _, bias = fullrange_case(K, N, 128, 1, seed=K + M, realistic=True)
+    gen = torch.Generator().manual_seed(M)
+    gu = (torch.randn((M, 2 * K), generator=gen) * 2).half().cuda()
+    dq, ds, dz, db = qw.cuda(), s.cuda(), qz.cuda(), bias.cuda()
+    want = ops.gemm_forward(ops.silu_and_mul(gu), dq, ds, dz, db)
+    got = ops.gemm_forward(gu, dq, ds, dz, db, flags=ops.X_GATED_SILU)
+    assert ops.last_kernel() == "gemv_mfma"
+    assert torch.equal(got, want)
+    with pytest.raises(Exception):
+        ops.gemm_forward(torch.zeros((17, 2 * K), dtype=torch.float16, device="cuda"), dq, ds, dz, flags=ops.X_GATED_SILU)
 
 
 # ------------------------------------------------------------------ GEMVFast layout (WQLinear_GEMVFast)
