@@ -1,85 +1,97 @@
 #!/usr/bin/env python3
 """Whole-model decode on synthetic Llama-2-7B-shape weights: 32 fused blocks
 (norm -> fused qkv int4 GEMV -> RoPE + KV append -> single-query attention -> o_proj -> add + norm ->
-gate|up int4 GEMV -> silu*mul -> down), final norm, fp16 lm_head; ONE hipGraph per decode step,
-positions in device tensors.  Prints tokens/s at several context lengths (the number comparable
-with the reference's README decode tables, which are whole-model numbers)."""
-import argparse, os, sys, time
+gate|up int4 GEMV -> down with silu*mul applied while staging), final norm, fp16 lm_head; ONE hipGraph
+per decode step, positions in device tensors.  Prints tokens/s at several context lengths (the number
+comparable with the reference's README decode tables, which are whole-model numbers)."""
+import argparse, os, sys
 import torch
 import torch.nn as nn
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from autoawq_amd.modules.fused.block import LlamaLikeBlock
-from autoawq_amd.modules.fused.mlp import QuantFusedMLP
-from autoawq_amd.modules.fused.model import LlamaLikeModel
-from autoawq_amd.modules.fused.norm import FasterTransformerRMSNorm
-from autoawq_amd.modules.linear import WQLinear_GEMM
-from autoawq_amd.fuser import FusedCausalLM
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--layers", type=int, default=32)
-ap.add_argument("--contexts", default="64,512,2048")
-ap.add_argument("--batch", type=int, default=1)
-ap.add_argument("--steps", type=int, default=64)
-a = ap.parse_args()
 H, I, V, HEADS, G = 4096, 11008, 32000, 32, 128
-dev = torch.device("cuda")
-gen = torch.Generator(device=dev).manual_seed(0)
-lim = 0x7FFFFFFF
 
 
-def rand_linear(K, N):
-    m = WQLinear_GEMM(4, G, K, N, False, dev)
-    m.qweight = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, device=dev, generator=gen)
-    m.qzeros = torch.randint(-lim - 1, lim, (K // G, N // 8), dtype=torch.int32, device=dev, generator=gen)
-    m.scales = (torch.rand((K // G, N), device=dev, generator=gen) * 0.004 + 0.001).half()
-    return m
+def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbose=True):
+    """Returns {context: ms_per_token}."""
+    from autoawq_amd.fuser import FusedCausalLM
+    from autoawq_amd.modules.fused.block import LlamaLikeBlock
+    from autoawq_amd.modules.fused.mlp import QuantFusedMLP
+    from autoawq_amd.modules.fused.model import LlamaLikeModel
+    from autoawq_amd.modules.fused.norm import FasterTransformerRMSNorm
+    from autoawq_amd.modules.linear import WQLinear_GEMM
 
+    dev = dev or torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(0)
+    lim = 0x7FFFFFFF
 
-max_ctx = max(int(c) for c in a.contexts.split(",")) + a.steps + 8
-blocks = []
-for _ in range(a.layers):
-    mlp = QuantFusedMLP(rand_linear(H, I), rand_linear(I, H), rand_linear(H, I))
-    n1 = FasterTransformerRMSNorm(torch.ones(H, dtype=torch.float16, device=dev), 1e-5)
-    n2 = FasterTransformerRMSNorm(torch.ones(H, dtype=torch.float16, device=dev), 1e-5)
-    blocks.append(LlamaLikeBlock(H, HEADS, HEADS, rand_linear(H, 3 * H), rand_linear(H, H), mlp, n1, n2, dev, max_ctx))
-emb = nn.Embedding(V, H).half().to(dev)
-head = nn.Linear(H, V, bias=False).half().to(dev)
-lm = FusedCausalLM(LlamaLikeModel(V, blocks, emb, FasterTransformerRMSNorm(torch.ones(H, dtype=torch.float16, device=dev), 1e-5)), head)
-B = a.batch
-for blk in blocks:
-    blk.attn._resize_cache(B)
-pos = torch.zeros(1, dtype=torch.int32, device=dev)
-ln = torch.ones(1, dtype=torch.int32, device=dev)
-for blk in blocks:
-    blk.attn.use_device_positions(pos, ln)
-tok = torch.randint(0, V, (B, 1), device=dev, generator=gen)
-s = torch.cuda.Stream()
-with torch.cuda.stream(s):
-    for blk in blocks:  # pretend a context is cached: random K / V rows
-        blk.attn.cache.k.normal_(generator=gen)
-        blk.attn.cache.v.normal_(generator=gen)
-    lm(tok)
-    s.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=s):
-        logits = lm(tok)
-        pos.add_(1)
-        ln.add_(1)
-    for ctx in [int(c) for c in a.contexts.split(",")]:
-        pos.fill_(ctx)
-        ln.fill_(ctx + 1)
-        for _ in range(4):
-            graph.replay()
-        pos.fill_(ctx)
-        ln.fill_(ctx + 1)
+    def rand_linear(K, N):
+        m = WQLinear_GEMM(4, G, K, N, False, dev)
+        m.qweight = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        m.qzeros = torch.randint(-lim - 1, lim, (K // G, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        m.scales = (torch.rand((K // G, N), device=dev, generator=gen) * 0.004 + 0.001).half()
+        return m
+
+    max_ctx = max(contexts) + steps + 8
+    ones = lambda: torch.ones(H, dtype=torch.float16, device=dev)
+    blocks = []
+    for _ in range(layers):
+        mlp = QuantFusedMLP(rand_linear(H, I), rand_linear(I, H), rand_linear(H, I))
+        blocks.append(LlamaLikeBlock(H, HEADS, HEADS, rand_linear(H, 3 * H), rand_linear(H, H), mlp,
+                                     FasterTransformerRMSNorm(ones(), 1e-5), FasterTransformerRMSNorm(ones(), 1e-5), dev, max_ctx))
+    emb = nn.Embedding(V, H).half().to(dev)
+    head = nn.Linear(H, V, bias=False).half().to(dev)
+    lm = FusedCausalLM(LlamaLikeModel(V, blocks, emb, FasterTransformerRMSNorm(ones(), 1e-5)), head)
+    for blk in blocks:
+        blk.attn._resize_cache(batch)
+    pos = torch.zeros(1, dtype=torch.int32, device=dev)
+    ln = torch.ones(1, dtype=torch.int32, device=dev)
+    for blk in blocks:
+        blk.attn.use_device_positions(pos, ln)
+    tok = torch.randint(0, V, (batch, 1), device=dev, generator=gen)
+    out = {}
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        for blk in blocks:  # pretend a context is cached: random K / V rows
+            blk.attn.cache.k.normal_(generator=gen)
+            blk.attn.cache.v.normal_(generator=gen)
+        lm(tok)
         s.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(s)
-        for _ in range(a.steps):
-            graph.replay()
-        e1.record(s)
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / a.steps
-        print(f"7B-shape whole-model decode, {a.layers} layers, batch {B}, context {ctx}: {ms:.3f} ms/token = "
-              f"{B * 1000.0 / ms:.1f} tok/s (one hipGraph per step)", flush=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            lm(tok)
+            pos.add_(1)
+            ln.add_(1)
+        for ctx in contexts:
+            pos.fill_(ctx)
+            ln.fill_(ctx + 1)
+            for _ in range(4):
+                graph.replay()
+            pos.fill_(ctx)
+            ln.fill_(ctx + 1)
+            s.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            for _ in range(steps):
+                graph.replay()
+            e1.record(s)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            out[ctx] = ms
+            if verbose:
+                print(f"7B-shape whole-model decode, {layers} layers, batch {batch}, context {ctx}: {ms:.3f} ms/token = "
+                      f"{batch * 1000.0 / ms:.1f} tok/s (one hipGraph per step)", flush=True)
+    del graph, lm, blocks
+    torch.cuda.empty_cache()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--contexts", default="64,512,2048")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    a = ap.parse_args()
+    run(a.layers, tuple(int(c) for c in a.contexts.split(",")), a.batch, a.steps)
