@@ -49,3 +49,8 @@ def moe_alig_block_size(topk_ids, num_experts, block_size, sorted_ids, expert_id
     sorted_ids.copy_(s)
     expert_ids.copy_(e)
     num_tokens_post_pad.copy_(n)
+
+
+def layernorm_forward_cuda(x, weight, out, eps):
+    """awq/modules/fused/norm.py:33-36: RMSNorm into the caller-allocated `out`."""
+    ops.rmsnorm(x, weight, eps, out=out)
