@@ -24,6 +24,8 @@
 //     the A fragment uses the same K-slot order, so no data is ever transposed by the VALU.
 //   * one barrier per K step: tile t+1 is fetched into registers before tile t is multiplied and
 //     stored into the other LDS buffer afterwards.
+#include <cstdlib>
+
 #include "awq_device.h"
 #include "awq_internal.h"
 
@@ -47,8 +49,7 @@ struct TiledParams {
 typedef short short4_t __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-constexpr int BK = 64;
-constexpr int APITCH = BK + 8;  // halfs per A row in LDS (144 bytes)
+constexpr int BK_DEFAULT = 64;  // K step of every tile except the large-M 128 x 256 one (32: two blocks fit a CU)
 constexpr uint32_t OOB = 0x80000000u;
 
 AWQ_DEV rsrc_t mk_rsrc(const void* base, uint32_t bytes) {
@@ -73,9 +74,11 @@ __device__ unsigned long long* g_awq_trace_tiled = nullptr;
 #define AWQ_TSTAMP(slot) do { } while (0)
 #endif
 
-template <int BM, int BN, bool SPLITK>
+template <int BM, int BN, bool SPLITK, int BK = BK_DEFAULT>
 __global__ __launch_bounds__((BM >= 128 ? 2 : 1) * (BN >= 256 ? 4 : (BM >= 128 ? 2 : 4)) * 64)
 void awq_gemm_tiled_kernel(TiledParams p) {
+    constexpr int APITCH = BK + 8;  // halfs per A row in LDS (144 / 80 bytes)
+    constexpr int CPR = BK / 8;     // 16-byte activation chunks per row of a K step
     constexpr int WGM = BM >= 128 ? 2 : 1;                     // waves along M
     constexpr int WGN = BN >= 256 ? 4 : (BM >= 128 ? 2 : 4);   // waves along N
     constexpr int NTHR = WGM * WGN * 64;
@@ -83,8 +86,10 @@ void awq_gemm_tiled_kernel(TiledParams p) {
     constexpr int MI = WM / 16;             // 16-row MFMA tiles per wave
     constexpr int WN = BN / WGN;            // columns per wave
     constexpr int NT = WN / 16;             // 16-column MFMA tiles per wave
-    constexpr int ACH = BM * 8 / NTHR;      // 16-byte activation chunks per thread per K step
-    constexpr int WPT = (BN / 8) * 16 / NTHR;  // (word column, 4-row group) assignments per thread
+    constexpr int ACH = BM * CPR / NTHR;    // 16-byte activation chunks per thread per K step
+    constexpr int BASSIGN = (BN / 8) * (BK / 4);  // (word column, 4-row group) assignments per K step
+    constexpr int WPT = BASSIGN >= NTHR ? BASSIGN / NTHR : 1;  // per thread (threads past BASSIGN idle in the B staging)
+    static_assert(ACH >= 1 && BM * CPR % NTHR == 0, "activation chunks must divide evenly");
     constexpr int A_BYTES = BM * APITCH * 2;
     constexpr int B_BYTES = BK * BN * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][A | B]
@@ -111,7 +116,7 @@ void awq_gemm_tiled_kernel(TiledParams p) {
     int a_lds[ACH];
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
-        const int c = tid + NTHR * i, row = c >> 3, kc = c & 7;
+        const int c = tid + NTHR * i, row = c / CPR, kc = c % CPR;
         a_voff[i] = (m0 + row < p.M) ? (uint32_t)(((int64_t)(m0 + row) * p.K + 8 * kc) * 2) : OOB;
         a_lds[i] = (row * APITCH + 8 * kc) * 2;
     }
@@ -122,9 +127,9 @@ void awq_gemm_tiled_kernel(TiledParams p) {
     for (int i = 0; i < WPT; ++i) {
         const int idx = tid + NTHR * i;
         b_wc[i] = idx % (BN / 8);
-        b_rg[i] = idx / (BN / 8);  // 0..15
+        b_rg[i] = idx / (BN / 8);  // 0 .. BK/4 - 1
         const int w = (n0 >> 3) + b_wc[i];
-        const bool ok = w < NW;
+        const bool ok = w < NW && idx < BASSIGN;
         b_voff[i] = ok ? (uint32_t)(((int64_t)(4 * b_rg[i]) * NW + w) * 4) : OOB;
         z_voff[i] = ok ? (uint32_t)w * 4u : OOB;
         s_voff[i] = ok ? (uint32_t)w * 16u : OOB;
@@ -161,6 +166,7 @@ void awq_gemm_tiled_kernel(TiledParams p) {
         unsigned char* B = A + A_BYTES;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(A + a_lds[i]) = R.a[i];
+        if (BASSIGN < NTHR && tid >= BASSIGN) return;  // wave-uniform: this thread has no word of the B tile
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const uint32_t qz = R.z[i];
@@ -199,7 +205,7 @@ void awq_gemm_tiled_kernel(TiledParams p) {
         const unsigned char* A = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* B = A + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             half8_t bf[NT];
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn) {
@@ -367,20 +373,20 @@ void awq_gemm_tiled_kernel(TiledParams p) {
     AWQ_TSTAMP(6);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK = BK_DEFAULT>
 void launch_tiled(const TiledParams& p, unsigned grid, hipStream_t st) {
-    constexpr size_t lds = 2 * (BM * APITCH * 2 + BK * BN * 2);
+    constexpr size_t lds = 2 * (BM * (BK + 8) * 2 + BK * BN * 2);
     static const bool lds_opt_in = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, false, BK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, true, BK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)lds_opt_in;
     constexpr int NTHR = (BM >= 128 ? 2 : 1) * (BN >= 256 ? 4 : (BM >= 128 ? 2 : 4)) * 64;
-    if (p.S > 1) hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, true>), dim3(grid), dim3(NTHR), lds, st, p);
-    else hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false>), dim3(grid), dim3(NTHR), lds, st, p);
+    if (p.S > 1) hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, true, BK>), dim3(grid), dim3(NTHR), lds, st, p);
+    else hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false, BK>), dim3(grid), dim3(NTHR), lds, st, p);
 }
 
 }  // namespace
@@ -390,6 +396,8 @@ extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_tiled
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_awq_trace_tiled), &dev_buf, sizeof(void*));
 }
 #endif
+
+static const bool g_bk32 = [] { const char* e = getenv("AWQ_TILED_BK32"); return !(e && e[0] == '0'); }();  // tuning switch
 
 bool awq_gemm_tiled_supports(int M, int K, int N, int g) {
     if (M < 1) return false;
@@ -418,7 +426,10 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + bn - 1) / bn;
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
-    const int T = a.K / BK;
+    // 128 x 256 tiles of a grid that fills the chip by itself step K by 32: 53 KB of LDS instead of 102,
+    // so two 8-wave blocks share a CU and cover each other's barriers and global round trips
+    const int BKsel = (BM == 128 && bn == 256 && splitk <= 1 && tiles >= 512 && g_bk32) ? 32 : BK_DEFAULT;
+    const int T = a.K / BKsel;
     // split K until ~2 blocks per CU are in the grid (small M: few output tiles, long K loops)
     int S = splitk > 0 ? splitk : (int)((512 + tiles - 1) / tiles);
     if (S > 16) S = 16;
@@ -440,6 +451,7 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     if (BM == 32) launch_tiled<32, 128>(p, grid, a.stream);
     else if (BM == 64) launch_tiled<64, 128>(p, grid, a.stream);
     else if (bn == 128) launch_tiled<128, 128>(p, grid, a.stream);
+    else if (BKsel == 32) launch_tiled<128, 256, 32>(p, grid, a.stream);
     else launch_tiled<128, 256>(p, grid, a.stream);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

@@ -222,6 +222,24 @@ def test_tiled_splitk_more_blocks_than_cus(ops):
     assert ops.workspace_is_clean(dq.device)
 
 
+def test_tiled_large_grid_k32_tile(ops):
+    """Grids of >= 512 tiles of 128 x 256 take the K-step-32 instantiation (two blocks per CU):
+    same numerics as every other tile -- exact fp16 weights, fp32 accumulation -- checked against
+    the dequantised-weights product and, row-exact, with one-hot activations."""
+    K, N, M = 384, 8192, 2048
+    qw, qz, s, x, bias = fullrange_case(K, N, 128, M, seed=5, realistic=True)
+    dq, ds, dz = qw.cuda(), s.cuda(), qz.cuda()
+    W = ops.dequantize_weights(dq, ds, dz)
+    y = ops.gemm_forward(x.cuda(), dq, ds, dz, bias.cuda(), flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2))
+    ref = x.cuda().float() @ W.float() + bias.cuda().float()
+    err = (y.float() - ref).abs()
+    assert bool((err <= 2e-3 * ref.abs() + 2e-3 * ref.abs().mean()).all()), float(err.max())
+    ks = (torch.arange(M, device="cuda") * 5 + 1) % K
+    e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    assert torch.equal(ops.gemm_forward(e, dq, ds, dz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2)), W[ks])
+
+
 def test_auto_dispatch_by_m(ops):
     qw, qz, s, x, _ = fullrange_case(512, 256, 128, 40, seed=9, realistic=True)
     dq, dz, ds = qw.cuda(), qz.cuda(), s.cuda()
