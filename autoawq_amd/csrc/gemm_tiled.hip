@@ -217,15 +217,20 @@ void awq_gemm_tiled_kernel(TiledParams p) {
                 const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
                 bf[jn] = __builtin_bit_cast(half8_t, u32x4{l2[0], l2[1], h2[0], h2[1]});
             }
+            half8_t af[MI];  // every fragment of the K slab is requested before the first MFMA: with one shared
+                             // A register set each of the MI groups waited out an LDS round trip of its own
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const unsigned char* ap = A + a_frag + (16 * i * APITCH + kk * 32) * 2;
                 const u32x2 lo = *reinterpret_cast<const u32x2*>(ap);
                 const u32x2 hi = *reinterpret_cast<const u32x2*>(ap + 32);
-                const half8_t af = __builtin_bit_cast(half8_t, u32x4{lo[0], lo[1], hi[0], hi[1]});
-#pragma unroll
-                for (int jn = 0; jn < NT; ++jn) acc[i][jn] = mfma16(af, bf[jn], acc[i][jn]);
+                af[i] = __builtin_bit_cast(half8_t, u32x4{lo[0], lo[1], hi[0], hi[1]});
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) acc[i][jn] = mfma16(af[i], bf[jn], acc[i][jn]);
         }
     };
 
@@ -431,8 +436,11 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     const int BKsel = (BM == 128 && bn == 256 && splitk <= 1 && tiles >= 512 && g_bk32) ? 32 : BK_DEFAULT;
     const int T = a.K / BKsel;
     // split K until ~2 blocks per CU are in the grid (small M: few output tiles, long K loops)
-    int S = splitk > 0 ? splitk : (int)((512 + tiles - 1) / tiles);
-    if (S > 16) S = 16;
+    // r69 / r92 sweeps: every slice of a 128-row tile ships 64 KB through the exchange, so those split
+    // less (~320 blocks); nothing gains past 8 slices
+    int S = splitk > 0 ? splitk : (BM == 128 ? (int)((320 + tiles / 2) / tiles) : (int)((512 + tiles - 1) / tiles));
+    if (S > (splitk > 0 ? 16 : 8)) S = splitk > 0 ? 16 : 8;
+    if (S < 1) S = 1;
     if (S > T / 4) S = T / 4 > 0 ? T / 4 : 1;  // at least 4 K steps per block
     const size_t tile_bytes = (size_t)BM * bn * sizeof(float);
     if (S > 1) {
