@@ -73,6 +73,7 @@ int awq_launch_rope_kv_append(const uint16_t* qkv, uint16_t* q_out, uint16_t* k_
                               const float* sin_t, const int32_t* pos_dev, int start_pos, int B, int S, int Hq, int Hkv, int D,
                               int rot, int Tmax, hipStream_t st);
 size_t awq_decode_attention_workspace_bytes_impl(int B, int Hq, int max_splits);
-int awq_launch_decode_attention(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out,
+int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* v_cache, uint16_t* out,
                                 const int32_t* len_dev, int seq_len, int max_len, int B, int Hq, int Hkv, int D, int Tmax,
-                                float scale, void* workspace, size_t workspace_bytes, hipStream_t st);
+                                float scale, void* workspace, size_t workspace_bytes, const float* cos_t,
+                                const float* sin_t, hipStream_t st);

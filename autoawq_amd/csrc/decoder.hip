@@ -111,26 +111,67 @@ __global__ __launch_bounds__(128) void awq_rope_kv_append_kernel(const half_t* _
 // 8 fp32 accumulators per query head; lane groups, waves and finally the splits are merged with
 // the usual (max, sum, acc) rule.  Partial results of a split go to `part` [B, Hq, splits, D + 2]
 // fp32 and a second tiny kernel finishes; with one split the block writes fp16 directly.
-template <int G>
-__global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ kc,
-                                                             const half_t* __restrict__ vc, half_t* __restrict__ out,
+// FUSED (awq_decode_attention_rope): `q` is the raw fused-qkv row [B, (Hq + 2 Hkv) * D]; the kernel
+// rotates its query heads itself (partner dims d +- 64 live in lane c ^ 8), takes the NEW token's
+// rotated k and its v straight from that row -- cache row `pos` is not read by anybody in this
+// launch -- and the one block whose chunk holds `pos` appends them to the caches.  len_dev then
+// holds the POSITION (length - 1).  Same roundings as awq_rope_kv_append followed by the plain
+// kernel: rotated values pass through fp16.
+template <int G, bool FUSED>
+__global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __restrict__ q, half_t* __restrict__ kc,
+                                                             half_t* __restrict__ vc, half_t* __restrict__ out,
                                                              float* __restrict__ part, const int* __restrict__ len_dev,
                                                              int seq_len, int Hq, int Hkv, int Tmax, float scale,
-                                                             int chunk) {
+                                                             int chunk, const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t) {
     constexpr int D = 128;
     __shared__ float sm[4][G][D + 2];
     const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 4, c = lane & 15;
-    const int T = len_dev ? *len_dev : seq_len;
+    const int T = (len_dev ? *len_dev : seq_len) + (FUSED ? 1 : 0);
+    const int pos = T - 1;  // FUSED: the new token's position
     const int t0 = split * chunk, t1 = min(T, t0 + chunk);
 
     float qf[G][8];
+    half8_t k_new = {0, 0, 0, 0, 0, 0, 0, 0}, v_new = k_new;
+    if constexpr (FUSED) {
+        const half_t* row = q + (int64_t)b * (Hq + 2 * Hkv) * D;
+        float cs[8], sn[8];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const half8_t qv = *reinterpret_cast<const half8_t*>(q + ((int64_t)b * Hq + hk * G + g) * D + 8 * c);
+        for (int e = 0; e < 8; ++e) {
+            const int i = (8 * c + e) & 63;
+            cs[e] = cos_t[(int64_t)pos * 64 + i];
+            sn[e] = sin_t[(int64_t)pos * 64 + i];
+        }
+        auto rotate = [&](half8_t x) -> half8_t {
+            half8_t o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qf[g][e] = (float)qv[e] * scale;
+            for (int e = 0; e < 8; ++e) {
+                const float mine = (float)x[e], other = __shfl_xor(mine, 8, 64);  // dims d and d +- 64
+                o[e] = (c < 8) ? (half_t)(mine * cs[e] - other * sn[e]) : (half_t)(other * sn[e] + mine * cs[e]);
+            }
+            return o;
+        };
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const half8_t qr = rotate(*reinterpret_cast<const half8_t*>(row + (int64_t)(hk * G + g) * D + 8 * c));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[g][e] = (float)qr[e] * scale;
+        }
+        k_new = rotate(*reinterpret_cast<const half8_t*>(row + (int64_t)(Hq + hk) * D + 8 * c));
+        v_new = *reinterpret_cast<const half8_t*>(row + (int64_t)(Hq + Hkv + hk) * D + 8 * c);
+        if (pos >= t0 && pos < t1 && wave == 0 && r == 0) {  // append: one block, 16 lanes x 16 bytes per cache
+            *reinterpret_cast<half8_t*>(kc + (((int64_t)b * Tmax + pos) * Hkv + hk) * D + 8 * c) = k_new;
+            *reinterpret_cast<half8_t*>(vc + (((int64_t)b * Tmax + pos) * Hkv + hk) * D + 8 * c) = v_new;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const half8_t qv = *reinterpret_cast<const half8_t*>(q + ((int64_t)b * Hq + hk * G + g) * D + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[g][e] = (float)qv[e] * scale;
+        }
     }
     float m[G], l[G], o[G][8];
 #pragma unroll
@@ -151,7 +192,10 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
             const int t = tb + 16 * u + r;
             kv[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
             vv[u] = kv[u];
-            if (t < t1) {
+            if (FUSED && t == pos) {  // the new token: from the qkv row, not from the cache
+                kv[u] = k_new;
+                vv[u] = v_new;
+            } else if (t < t1) {
                 kv[u] = *reinterpret_cast<const half8_t*>(kb + (int64_t)t * rowstride);
                 vv[u] = *reinterpret_cast<const half8_t*>(vb + (int64_t)t * rowstride);
             }
@@ -291,24 +335,29 @@ size_t awq_decode_attention_workspace_bytes_impl(int B, int Hq, int max_splits) 
     return (size_t)B * Hq * max_splits * (128 + 2) * sizeof(float);
 }
 
-template <int G>
-static void launch_attn(dim3 grid, hipStream_t st, const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out,
-                        float* part, const int32_t* len_dev, int seq_len, int Hq, int Hkv, int Tmax, float scale, int chunk) {
-    hipLaunchKernelGGL(awq_decode_attn_kernel<G>, grid, dim3(256), 0, st, reinterpret_cast<const half_t*>(q),
-                       reinterpret_cast<const half_t*>(kc), reinterpret_cast<const half_t*>(vc),
-                       reinterpret_cast<half_t*>(out), part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk);
+template <int G, bool FUSED>
+static void launch_attn(dim3 grid, hipStream_t st, const uint16_t* q, uint16_t* kc, uint16_t* vc, uint16_t* out, float* part,
+                        const int32_t* len_dev, int seq_len, int Hq, int Hkv, int Tmax, float scale, int chunk,
+                        const float* cos_t, const float* sin_t) {
+    hipLaunchKernelGGL((awq_decode_attn_kernel<G, FUSED>), grid, dim3(256), 0, st, reinterpret_cast<const half_t*>(q),
+                       reinterpret_cast<half_t*>(kc), reinterpret_cast<half_t*>(vc), reinterpret_cast<half_t*>(out), part,
+                       len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk, cos_t, sin_t);
 }
 
-int awq_launch_decode_attention(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out,
+// cos_t == nullptr: plain form (q [B, Hq, D], rows [0, len) of the caches).  Otherwise the fused form:
+// q = raw qkv rows, `len_dev` / `seq_len` carry the POSITION of the new token.
+int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* v_cache, uint16_t* out,
                                 const int32_t* len_dev, int seq_len, int max_len, int B, int Hq, int Hkv, int D, int Tmax,
-                                float scale, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                                float scale, void* workspace, size_t workspace_bytes, const float* cos_t,
+                                const float* sin_t, hipStream_t st) {
     if (D != 128) return AWQ_ERR_UNSUPPORTED;
     if (B < 0 || Hq < 1 || Hkv < 1 || Hq % Hkv || Tmax < 1) return AWQ_ERR_BAD_SHAPE;
     const int G = Hq / Hkv;
     if (!(G == 1 || G == 2 || G == 4 || G == 8)) return AWQ_ERR_UNSUPPORTED;
     if (B == 0) return AWQ_OK;
+    const bool fused = cos_t != nullptr;
     // the split must not depend on a length that only the device knows: size it for max_len
-    const int len_for_split = len_dev ? max_len : seq_len;
+    const int len_for_split = len_dev ? max_len : seq_len + (fused ? 1 : 0);
     if (len_for_split < 1 || len_for_split > Tmax) return AWQ_ERR_BAD_SHAPE;
     // ~1024 blocks in flight, at least 64 rows per block
     int splits = (1024 + B * Hkv - 1) / (B * Hkv);
@@ -325,12 +374,21 @@ int awq_launch_decode_attention(const uint16_t* q, const uint16_t* k_cache, cons
     splits = (len_for_split + chunk - 1) / chunk;
     const dim3 grid((unsigned)splits, (unsigned)Hkv, (unsigned)B);
     float* part = static_cast<float*>(workspace);
+#define AWQ_ATTN_CASE(GG)                                                                                                  \
+    case GG:                                                                                                               \
+        if (fused) launch_attn<GG, true>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, \
+                                         chunk, cos_t, sin_t);                                                             \
+        else launch_attn<GG, false>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale,      \
+                                    chunk, nullptr, nullptr);                                                              \
+        break;
     switch (G) {
-        case 1: launch_attn<1>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk); break;
-        case 2: launch_attn<2>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk); break;
-        case 4: launch_attn<4>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk); break;
-        default: launch_attn<8>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk); break;
+        AWQ_ATTN_CASE(1)
+        AWQ_ATTN_CASE(2)
+        AWQ_ATTN_CASE(4)
+        default:
+        AWQ_ATTN_CASE(8)
     }
+#undef AWQ_ATTN_CASE
     if (hipGetLastError() != hipSuccess) return AWQ_ERR_LAUNCH;
     if (splits > 1) {
         hipLaunchKernelGGL(awq_decode_attn_combine_kernel, dim3((unsigned)(B * Hq)), dim3(128), 0, st, part,

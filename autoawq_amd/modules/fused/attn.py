@@ -39,6 +39,8 @@ class RoPE(nn.Module):
 
 
 class QuantAttentionFused(nn.Module):
+    FUSE_ROPE_INTO_ATTENTION = True  # decode steps, head_dim 128, full rotary
+
     def __init__(self, hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, dev, max_seq_len=2048, use_alibi=False,
                  attention_shapes=None, rope_theta=10000, partial_rotary_factor=1.0, head_dim=None,
                  attn_logit_softcapping=0.0, q_norm=None, k_norm=None, **kwargs):
@@ -91,6 +93,15 @@ class QuantAttentionFused(nn.Module):
         if xqkv.dtype != torch.float16:
             xqkv = xqkv.half()
         device_pos = self._pos_dev is not None and seqlen == 1
+        if seqlen == 1 and self.head_dim == 128 and self.rotary_dim == 128 and self.FUSE_ROPE_INTO_ATTENTION:
+            # decode: rotation, cache append and attention in ONE launch (awq_decode_attention_rope)
+            out = ops.decode_attention_rope(xqkv, self.cache.k, self.cache.v, self.rope.cos, self.rope.sin, self.start_pos,
+                                            self.n_heads, self.n_kv_heads, pos_dev=self._pos_dev if device_pos else None,
+                                            max_len=self.max_seq_len if device_pos else None)
+            attention_weight = out.reshape(bsz, 1, -1)
+            attn_output = self.o_proj(attention_weight)
+            self.start_pos += 1
+            return attn_output, attention_weight, [torch.zeros(1, 1, self.start_pos, 1)]
         xq = ops.rope_kv_append(xqkv, self.cache.k, self.cache.v, self.rope.cos, self.rope.sin, self.start_pos,
                                 self.n_heads, self.n_kv_heads, self.head_dim, self.rotary_dim,
                                 pos_dev=self._pos_dev if device_pos else None)

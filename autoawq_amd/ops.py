@@ -386,3 +386,31 @@ def decode_attention(q, k_cache, v_cache, seq_len, scale=None, len_dev=None, max
                                           int(max_len if max_len is not None else seq_len), B, Hq, Hkv, D, Tmax,
                                           float(scale), _ptr(ws), ws.numel(), _stream()), "awq_decode_attention")
     return out
+
+
+def decode_attention_rope(qkv, k_cache, v_cache, cos, sin, start_pos, n_heads, n_kv_heads, pos_dev=None, max_len=None,
+                          scale=None):
+    """One launch for a decode step: qkv [B, 1, (Hq + 2 Hkv) * 128] (or [B, ...]) -> attention output
+    [B, Hq, 128]; rotates q / k, appends k / v at row start_pos and attends over rows [0, start_pos]
+    (awq_decode_attention_rope; bit-identical to rope_kv_append + decode_attention)."""
+    _require_gpu(qkv, k_cache, v_cache, cos, sin, pos_dev)
+    B = qkv.shape[0]
+    D = k_cache.shape[3]
+    qkv = qkv.contiguous()
+    out = torch.empty((B, n_heads, D), dtype=torch.float16, device=qkv.device)
+    L = _lib.lib()
+    key = (qkv.device.index if qkv.device.index is not None else torch.cuda.current_device(), _stream())
+    need = L.awq_decode_attention_workspace_bytes(B, n_heads)
+    ws = _attn_workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+        _attn_workspaces[key] = ws
+    if scale is None:
+        scale = D ** -0.5
+    with torch.cuda.device(qkv.device):
+        _lib.check(L.awq_decode_attention_rope(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(cos), _ptr(sin), _ptr(out),
+                                               _ptr(pos_dev), int(start_pos),
+                                               int(max_len if max_len is not None else start_pos + 1), B, n_heads,
+                                               n_kv_heads, D, k_cache.shape[1], float(scale), _ptr(ws), ws.numel(),
+                                               _stream()), "awq_decode_attention_rope")
+    return out

@@ -198,6 +198,18 @@ AWQ_EXPORT int awq_decode_attention(const uint16_t* q, const uint16_t* k_cache, 
                                     int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq, float scale,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* awq_rope_kv_append + awq_decode_attention in ONE launch for a decode step (S = 1, full rotary,
+ * head_dim = 128): qkv [B, (n_heads + 2*n_kv_heads) * 128] is the fused projection's output; query
+ * heads are rotated in registers, the new token's rotated k and its v are used from registers and
+ * appended to the caches at row start_pos (read from pos_dev when non-NULL; max_len then sizes
+ * the launch, >= position + 1).  Cache rows bit-identical to awq_rope_kv_append; output equal to the
+ * two separate calls up to fp32 contraction order. */
+AWQ_EXPORT int awq_decode_attention_rope(const uint16_t* qkv, uint16_t* k_cache, uint16_t* v_cache,
+                                         const float* cos_table, const float* sin_table, uint16_t* out,
+                                         const int32_t* pos_dev, int64_t start_pos, int64_t max_len, int64_t B,
+                                         int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq,
+                                         float scale, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

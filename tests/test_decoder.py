@@ -167,6 +167,33 @@ def test_decode_attention_vs_oracle(ops, B, Hq, Hkv, T):
     assert np.abs(got2 - want).max() <= 2e-3 * np.abs(want).max() + 2 ** -11
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Hq,Hkv,pos", [(1, 32, 32, 0), (1, 32, 32, 300), (2, 8, 2, 63), (1, 32, 8, 2047), (3, 4, 4, 17)])
+def test_fused_rope_append_attention_equals_the_two_kernels(ops, B, Hq, Hkv, pos):
+    """awq_decode_attention_rope == awq_rope_kv_append followed by awq_decode_attention: the appended
+    cache rows are bit-identical and nothing else in the caches is touched; the attention output agrees to
+    the kernel tolerance (the two instantiations contract their fp32 multiply-adds differently); also with
+    the position on the device."""
+    from autoawq_amd.modules.fused.attn import RoPE
+
+    gen = torch.Generator().manual_seed(pos + B)
+    Tmax = 2048 + 8
+    qkv = torch.randn((B, 1, (Hq + 2 * Hkv) * 128), generator=gen).half().cuda()
+    base_k = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    base_v = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    rope = RoPE(128, Tmax, "cuda", 10000.0)
+    k1, v1 = base_k.cuda(), base_v.cuda()
+    q = ops.rope_kv_append(qkv, k1, v1, rope.cos, rope.sin, pos, Hq, Hkv, 128, 128)
+    want = ops.decode_attention(q[:, 0], k1, v1, pos + 1)
+    for use_dev in (False, True):
+        k2, v2 = base_k.cuda(), base_v.cuda()
+        pd = torch.tensor([pos], dtype=torch.int32, device="cuda") if use_dev else None
+        got = ops.decode_attention_rope(qkv, k2, v2, rope.cos, rope.sin, 0 if use_dev else pos, Hq, Hkv, pos_dev=pd,
+                                        max_len=Tmax if use_dev else None)
+        assert torch.equal(k2, k1) and torch.equal(v2, v1)
+        assert (got.float() - want.float()).abs().max() <= 2e-3 * want.float().abs().max() + 2 ** -11
+
+
 # ------------------------------------------------------------------ GPU: the fused model
 
 def _fused(version, max_seq_len=32):
