@@ -27,6 +27,8 @@ SIGNATURES = {
     "awq_gemm_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
     "awq_gemm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_void_p, c_size_t, c_uint32, c_void_p]),
+    "awq_gemm_forward_normed": (c_int, [c_void_p] * 4 + [c_float] + [c_void_p] * 5 + [c_int64] * 4 +
+                                [c_void_p, c_size_t, c_uint32, c_void_p]),
     "awq_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "awq_rmsnorm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
     "awq_rope_kv_append": (c_int, [c_void_p] * 7 + [c_int64] * 8 + [c_void_p]),

@@ -19,7 +19,11 @@ struct AwqGemmArgs {
     const uint16_t* bias;    // [N] or null
     uint16_t* y;             // [M, N]
     int M, K, N, g;
-    int x_gated = 0;  // x is [M, 2K] = [gate | up]; the kernel stages silu(gate) * up (decode kernel only)
+    int x_gated = 0;  // decode kernel only: 1 = x is [M, 2K] = [gate | up], stage silu(gate) * up; 2 = stage rmsnorm(x + res_in)
+    const uint16_t* res_in = nullptr;   // mode 2: optional residual rows [M, K]
+    uint16_t* res_out = nullptr;        // mode 2: fp16(x + res_in) is written here (must not alias res_in)
+    const uint16_t* norm_w = nullptr;   // mode 2: norm weight [K]
+    float norm_eps = 0.f;
     int* counters;   // control words (word 0 = error flag), zero on entry
     float* exchange;  // in-launch split-K exchange region: all-ones sentinel on entry AND on exit
     size_t exchange_bytes;

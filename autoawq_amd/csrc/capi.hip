@@ -81,9 +81,44 @@ int awq_gemm_workspace_init(void* workspace, size_t workspace_bytes, void* strea
     return AWQ_OK;
 }
 
+namespace {
+struct NormArgs {
+    const uint16_t* res_in;
+    uint16_t* res_out;
+    const uint16_t* weight;
+    float eps;
+};
+int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                      const uint16_t* bias, uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size,
+                      void* workspace, size_t workspace_bytes, uint32_t flags, void* stream, const NormArgs* nrm);
+}  // namespace
+
 int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                      const uint16_t* bias, uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size,
                      void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+    return gemm_forward_impl(x, qweight, scales, qzeros, bias, y, M, K, N, group_size, workspace, workspace_bytes, flags,
+                             stream, nullptr);
+}
+
+int awq_gemm_forward_normed(const uint16_t* x, const uint16_t* residual_in, uint16_t* residual_out,
+                            const uint16_t* norm_weight, float eps, const int32_t* qweight, const uint16_t* scales,
+                            const int32_t* qzeros, const uint16_t* bias, uint16_t* y, int64_t M, int64_t K, int64_t N,
+                            int64_t group_size, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+    if (!norm_weight) return AWQ_ERR_NULL;
+    if ((residual_in == nullptr) != (residual_out == nullptr)) return AWQ_ERR_NULL;
+    if (residual_in && residual_in == residual_out) return AWQ_ERR_BAD_ALIGNMENT;  // every block reads it, one block writes
+    if (!aligned16(norm_weight) || (residual_in && (!aligned16(residual_in) || !aligned16(residual_out))))
+        return AWQ_ERR_BAD_ALIGNMENT;
+    if (M > 4 || (flags & AWQ_GEMM_FLAG_X_GATED_SILU)) return AWQ_ERR_UNSUPPORTED;
+    const NormArgs nrm{residual_in, residual_out, norm_weight, eps};
+    return gemm_forward_impl(x, qweight, scales, qzeros, bias, y, M, K, N, group_size, workspace, workspace_bytes, flags,
+                             stream, &nrm);
+}
+
+namespace {
+int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                      const uint16_t* bias, uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size,
+                      void* workspace, size_t workspace_bytes, uint32_t flags, void* stream, const NormArgs* nrm) {
     int rc = check_gemm_layout(K, N, group_size);
     if (rc) return rc;
     if (M < 0 || M > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
@@ -108,6 +143,10 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     }
 
     a.x_gated = (flags & AWQ_GEMM_FLAG_X_GATED_SILU) ? 1 : 0;
+    if (nrm) {
+        a.x_gated = 2;
+        a.res_in = nrm->res_in; a.res_out = nrm->res_out; a.norm_w = nrm->weight; a.norm_eps = nrm->eps;
+    }
     if (a.x_gated && (M > 16 || !awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2))) return AWQ_ERR_UNSUPPORTED;
     unsigned kern = AWQ_GEMM_FLAG_KERNEL(flags);
     if (a.x_gated && kern != AWQ_GEMM_KERNEL_AUTO && kern != AWQ_GEMM_KERNEL_MFMA_GEMV) return AWQ_ERR_UNSUPPORTED;
@@ -154,6 +193,8 @@ int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
             return AWQ_ERR_UNSUPPORTED;
     }
 }
+
+}  // namespace
 
 /* ---- fused MLP / MoE ------------------------------------------------------------------- */
 

@@ -29,7 +29,7 @@ template <bool ADD>
 __global__ __launch_bounds__(256) void awq_rmsnorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ residual,
                                                          const half_t* __restrict__ w, half_t* __restrict__ out, int H,
                                                          float eps) {
-    constexpr int MAXC = 4;  // chunks per thread kept in registers: H <= 8192
+    constexpr int MAXC = 8;  // chunks per thread kept in registers: H <= 16384
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int chunks = H >> 3;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(128) void awq_decode_attn_combine_kernel(const floa
 
 int awq_launch_rmsnorm(const uint16_t* x, uint16_t* residual, const uint16_t* w, uint16_t* out, int64_t M, int64_t H,
                        float eps, hipStream_t st) {
-    if (M < 0 || H <= 0 || H % 8 || H > 8192) return AWQ_ERR_BAD_SHAPE;
+    if (M < 0 || H <= 0 || H % 8 || H > 16384) return AWQ_ERR_BAD_SHAPE;
     if (M == 0) return AWQ_OK;
     if (residual)
         hipLaunchKernelGGL(awq_rmsnorm_kernel<true>, dim3((unsigned)M), dim3(256), 0, st, reinterpret_cast<const half_t*>(x),

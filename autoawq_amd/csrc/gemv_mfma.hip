@@ -47,7 +47,11 @@ struct GemvMfmaParams {
     const uint32_t* qzeros;
     const half_t* scales;
     const half_t* x;
-    int x_gated;              // x rows are [gate | up] of 2K halves: stage silu(gate) * up
+    int x_gated;              // activation mode: 0 plain, 1 rows are [gate | up] (stage silu(gate) * up), 2 RMSNorm
+    const half_t* res_in;     // mode 2: optional residual rows added to x before the norm ...
+    half_t* res_out;          // ... and where fp16(x + residual) is written (by ONE block; must not alias res_in)
+    const half_t* norm_w;     // mode 2: norm weight [K]
+    float norm_eps;
     const half_t* bias;
     half_t* y;
     float* slabs;    // in-launch exchange region [S-1][tiles][M][CW] fp32: all-ones sentinel on entry and on exit
@@ -134,10 +138,13 @@ __device__ unsigned long long* g_awq_trace = nullptr;
 // NREG: live D registers per lane (2 when M == 1, else 4).  UNIT: 16-row sets a wave streams per
 // loop iteration (4*UNIT loads per lane in flight); FOLDS: group folds per unit (UNIT*16/FOLDS
 // rows each: a divisor of g, <= 128).
-// GATED: x rows are [gate | up] of 2K halves and silu(gate) * up is applied while staging (a template
-// parameter, not a runtime flag: the plain instantiations must not carry the extra registers).
-template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool NT, bool MOE = false, bool GATED = false>
+// XMODE (a template parameter, not a runtime flag: the plain instantiations must not carry the extra
+// registers): 1 = x rows are [gate | up] of 2K halves and silu(gate) * up is applied while staging;
+// 2 = x (+ residual) is RMS-normalised while staging -- every block recomputes the row statistic from
+// the (L2-resident) row, M <= 4 -- and block (tile 0, slice 0) writes fp16(x + residual) out.
+template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool NT, bool MOE = false, int XMODE = 0>
 __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaParams p) {
+    constexpr bool GATED = XMODE == 1, NORM = XMODE == 2;
     typedef typename Words<WPL>::T WV;
     constexpr int CPL = 8 * WPL;         // columns per lane
     constexpr int CW = 16 * CPL;         // columns per wave == per block tile
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     constexpr int QC = CW / 32;  // 16-byte chunks of packed zeros per group row of the tile
     constexpr int SC = CW / 8;   // 16-byte chunks of scales per group row of the tile
     const int xchunks = RS >> 3;  // 16-byte chunks per activation row
-    const bool reg_staged = (M + 1) * xchunks <= NTHR && ng * SC <= NTHR;
+    const bool reg_staged = !NORM && (M + 1) * xchunks <= NTHR && ng * SC <= NTHR;
     u32x4 st_x = {0u, 0u, 0u, 0u}, st_q = st_x, st_s = st_x, st_u = st_x;
     auto silu_mul = [](u32x4 gate, u32x4 upv) -> u32x4 {  // fp32, one rounding: == awq_silu_and_mul_kernel
         const half8_t gt = __builtin_bit_cast(half8_t, gate), uu = __builtin_bit_cast(half8_t, upv);
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     auto x_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(xs + (size_t)(c / xchunks) * RS + 8 * (c % xchunks)) = v; };
     auto q_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(zq + (c / QC) * (CW / 8) + 4 * (c % QC)) = v; };
     auto s_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(zsc + (c / SC) * CW + 8 * (c % SC)) = v; };
-    constexpr bool LATE = NREG == 4;  // batch > 1 (the M = 1 instantiations keep their register budget)
+    constexpr bool LATE = NREG == 4 || NORM;  // batch > 1 (the plain M = 1 instantiations keep their register budget)
     if (reg_staged) {
         if (tid < (M + 1) * xchunks) {
             st_x = x_chunk(tid);
@@ -259,7 +266,56 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
             if (tid < ng * QC) q_store(tid, st_q);
             if (tid < ng * SC) s_store(tid, st_s);
         } else if (LATE) {
-            for (int c = tid; c < (M + 1) * xchunks; c += NTHR) x_store(c, GATED ? silu_mul(x_chunk(c), x_chunk(c, true)) : x_chunk(c));
+            if constexpr (NORM) {
+                __shared__ float nrm_part[4][8];  // [row][wave]
+                __shared__ float nrm_inv[4];
+                auto load_h = [&](int m, int col) -> half8_t {  // fp16(x + residual), the value the stream carries
+                    half8_t h = *reinterpret_cast<const half8_t*>(p.x + (int64_t)m * p.K + col);
+                    if (p.res_in) {
+                        const half8_t rr = *reinterpret_cast<const half8_t*>(p.res_in + (int64_t)m * p.K + col);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (half_t)((float)h[e] + (float)rr[e]);
+                    }
+                    return h;
+                };
+                const bool writer = p.res_out != nullptr && tile == 0 && slice == 0;
+                const int kch = p.K >> 3;
+                for (int m = 0; m < M; ++m) {  // M <= 4: the row statistic, recomputed by every block
+                    float ss = 0.f;
+                    for (int c = tid; c < kch; c += NTHR) {
+                        const half8_t h = load_h(m, 8 * c);
+                        if (writer) *reinterpret_cast<half8_t*>(p.res_out + (int64_t)m * p.K + 8 * c) = h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss += (float)h[e] * (float)h[e];
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                    if (lane == 0) nrm_part[m][wave] = ss;
+                }
+                __syncthreads();
+                if (tid < M) {
+                    float tot = 0.f;
+                    for (int w = 0; w < NWAVES; ++w) tot += nrm_part[tid][w];
+                    nrm_inv[tid] = rsqrtf(tot / (float)p.K + p.norm_eps);
+                }
+                __syncthreads();
+                for (int c = tid; c < (M + 1) * xchunks; c += NTHR) {
+                    const int m = c / xchunks, row = r0 + 8 * (c % xchunks);
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (m < M && row < r1) {
+                        const half8_t h = load_h(m, row);
+                        const half8_t gw = *reinterpret_cast<const half8_t*>(p.norm_w + row);
+                        const float inv = nrm_inv[m];
+                        half8_t o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)h[e] * inv * (float)gw[e]);  // == awq_rmsnorm_kernel
+                        v = __builtin_bit_cast(u32x4, o);
+                    }
+                    x_store(c, v);
+                }
+            } else {
+                for (int c = tid; c < (M + 1) * xchunks; c += NTHR) x_store(c, GATED ? silu_mul(x_chunk(c), x_chunk(c, true)) : x_chunk(c));
+            }
             for (int c = tid; c < ng * QC; c += NTHR) q_store(c, q_chunk(c));
             for (int c = tid; c < ng * SC; c += NTHR) s_store(c, s_chunk(c));
         }
@@ -533,13 +589,14 @@ __global__ __launch_bounds__(256) void awq_gemv_mfma_reduce_kernel(const float* 
     *reinterpret_cast<half4_t*>(y + i4) = o;
 }
 
-template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, bool GATED = false>
+template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, int GATED = 0>
 void launch6(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
     // dynamic LDS above 64 KiB needs the opt-in once per kernel (host-side attribute, no sync)
     static const bool lds_opt_in = [] {
         (void)hipFuncSetAttribute(
             reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true, false, GATED>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncAttributeMaxDynamicSharedMemorySize, (160 - (GATED == 2 ? 1 : 0)) * 1024);  // mode 2 has 144 static bytes
+        (void)hipGetLastError();
         return true;
     }();
     (void)lds_opt_in;
@@ -553,9 +610,15 @@ bool launch3(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
     if (p.x_gated) {  // instantiated for the configurations the dispatcher picks by itself
         if constexpr (WPL == 2 && NWAVES >= 4 && UNIT <= 4) {
             if (p.g % UROWS) return false;
-            if (p.M == 1) launch6<WPL, NWAVES, UNIT, true, 2, 1, true>(p, grid, lds, st);
-            else if (p.M <= 8) launch6<WPL, NWAVES, UNIT, true, 4, 1, true>(p, grid, lds, st);
-            else if constexpr (NWAVES <= 4) launch6<WPL, NWAVES, UNIT, false, 4, 1, true>(p, grid, lds, st);
+            if (p.x_gated == 2) {  // RMSNorm staging: decode batches only
+                if (p.M == 1) launch6<WPL, NWAVES, UNIT, true, 2, 1, 2>(p, grid, lds, st);
+                else if (p.M <= 4) launch6<WPL, NWAVES, UNIT, true, 4, 1, 2>(p, grid, lds, st);
+                else return false;
+                return true;
+            }
+            if (p.M == 1) launch6<WPL, NWAVES, UNIT, true, 2, 1, 1>(p, grid, lds, st);
+            else if (p.M <= 8) launch6<WPL, NWAVES, UNIT, true, 4, 1, 1>(p, grid, lds, st);
+            else if constexpr (NWAVES <= 4) launch6<WPL, NWAVES, UNIT, false, 4, 1, 1>(p, grid, lds, st);
             else return false;
             return true;
         }
@@ -737,6 +800,10 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     p.scales = reinterpret_cast<const half_t*>(a.scales);
     p.x = reinterpret_cast<const half_t*>(a.x);
     p.x_gated = a.x_gated;
+    p.res_in = reinterpret_cast<const half_t*>(a.res_in);
+    p.res_out = reinterpret_cast<half_t*>(a.res_out);
+    p.norm_w = reinterpret_cast<const half_t*>(a.norm_w);
+    p.norm_eps = a.norm_eps;
     p.bias = nullptr;
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
@@ -779,6 +846,10 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
     p.scales = reinterpret_cast<const half_t*>(a.scales);
     p.x = reinterpret_cast<const half_t*>(a.x);
     p.x_gated = a.x_gated;
+    p.res_in = reinterpret_cast<const half_t*>(a.res_in);
+    p.res_out = reinterpret_cast<half_t*>(a.res_out);
+    p.norm_w = reinterpret_cast<const half_t*>(a.norm_w);
+    p.norm_eps = a.norm_eps;
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;

@@ -92,6 +92,13 @@ class QuantAttentionFused(nn.Module):
         xqkv = self.qkv_proj(hidden_states)
         if xqkv.dtype != torch.float16:
             xqkv = xqkv.half()
+        return self.forward_qkv(xqkv)
+
+    def forward_qkv(self, xqkv):
+        """Everything after the qkv projection (the caller may have produced `xqkv` [B, S, (Hq + 2 Hkv) D]
+        with the norm folded into the projection)."""
+        bsz, seqlen, _ = xqkv.shape
+        self._resize_cache(bsz)
         device_pos = self._pos_dev is not None and seqlen == 1
         if seqlen == 1 and self.head_dim == 128 and self.rotary_dim == 128 and self.FUSE_ROPE_INTO_ATTENTION:
             # decode: rotation, cache append and attention in ONE launch (awq_decode_attention_rope)

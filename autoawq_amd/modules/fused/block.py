@@ -5,6 +5,7 @@ are one launch (`FasterTransformerRMSNorm.forward(x, residual=...)`); the sum la
 import torch
 import torch.nn as nn
 
+from ... import ops
 from .attn import QuantAttentionFused
 from .norm import FasterTransformerRMSNorm
 
@@ -37,11 +38,39 @@ class LlamaLikeBlock(nn.Module):
             normed = self.norm_2(h)
         return h + self.mlp.forward(normed)
 
+    FOLD_NORMS_INTO_PROJECTIONS = True  # decode batches (rows <= 4), GEMM-layout qkv and gate|up
+
+    def _can_fold(self, h):
+        from ..linear.gemm import WQLinear_GEMM
+        from .mlp import QuantFusedMLP
+
+        rows = h.numel() // h.shape[-1]
+        return (self.FOLD_NORMS_INTO_PROJECTIONS and rows <= 4 and h.shape[1] == 1 and h.dtype == torch.float16
+                and isinstance(self.attn.qkv_proj, WQLinear_GEMM) and isinstance(self.mlp, QuantFusedMLP)
+                and not self.mlp.gemv_layout and self.attn.qkv_proj.in_features % 32 == 0)
+
     def forward_stream(self, x, h):
         """Residual stream kept by the caller (LlamaLikeModel): `h` is the stream, `x` the previous
         block's MLP output that has not been added yet (None for the first block).  Both residual
-        adds ride on the norms -- two fused add+norm launches per block, no separate add -- and the
-        pair (mlp output, stream) goes to the next block."""
+        adds ride on the norms -- and for decode batches the norms themselves ride on the projections
+        that follow them (`awq_gemm_forward_normed`): a block is qkv, attention, o_proj, gate|up, down --
+        five launches.  Returns (mlp output, stream)."""
+        if self._can_fold(h):
+            B, S, H = h.shape
+            q = self.attn.qkv_proj
+            if x is None:
+                xqkv, _ = ops.gemm_forward_normed(h.reshape(B * S, H), self.norm_1.weight, self.norm_1.variance_epsilon,
+                                                  q.qweight, q.scales, q.qzeros, q.bias)
+            else:
+                xqkv, hn = ops.gemm_forward_normed(x.reshape(B * S, H), self.norm_1.weight, self.norm_1.variance_epsilon,
+                                                   q.qweight, q.scales, q.qzeros, q.bias, residual=h.reshape(B * S, H))
+                h = hn.reshape(B, S, H)
+            attn_output, _, _ = self.attn.forward_qkv(xqkv.reshape(B, S, -1))
+            qw, sc, qz = self.mlp._gate_up_fused()
+            gate_up, hn = ops.gemm_forward_normed(attn_output.reshape(B * S, H), self.norm_2.weight,
+                                                  self.norm_2.variance_epsilon, qw, sc, qz, residual=h.reshape(B * S, H))
+            h = hn.reshape(B, S, H)
+            return self.mlp.forward(attn_output, gate_up=gate_up), h
         norm_out = self.norm_1(h) if x is None else self.norm_1(x, residual=h)
         attn_output, _, _ = self.attn.forward(hidden_states=norm_out)
         normed = self.norm_2(attn_output, residual=h)

@@ -49,17 +49,20 @@ class QuantFusedMLP(nn.Module):
                            torch.cat([self.gate_proj_qzeros, self.up_proj_qzeros], dim=dim).contiguous())
         return self._fused[1:]
 
-    def forward(self, x, routing_weights=None):
+    def forward(self, x, routing_weights=None, gate_up=None):
+        """`gate_up` [rows, 2 * intermediate]: the fused gate|up projection already computed by the caller
+        (LlamaLikeBlock folds the preceding norm into it); `x` then only provides shape and dtype."""
         out_shape = x.shape[:-1] + (self.intermediate_size,)
         x = x.reshape(-1, x.shape[-1])
         in_dtype = x.dtype
         if in_dtype != torch.float16:
             x = x.half()
-        qw, sc, qz = self._gate_up_fused()
-        if self.gemv_layout:
-            gate_up = ops.gemv_forward(x, qw, sc, qz, self.group_size)
-        else:
-            gate_up = ops.gemm_forward(x, qw, sc, qz)
+        if gate_up is None:
+            qw, sc, qz = self._gate_up_fused()
+            if self.gemv_layout:
+                gate_up = ops.gemv_forward(x, qw, sc, qz, self.group_size)
+            else:
+                gate_up = ops.gemm_forward(x, qw, sc, qz)
         if (self.activation is F.silu and not self.gemv_layout and gate_up.shape[0] <= 16 and in_dtype == torch.float16
                 and isinstance(self.down_proj, WQLinear_GEMM) and self.FUSE_ACTIVATION_INTO_DOWN):
             # decode: silu(gate) * up is applied by the down projection while it stages its activations

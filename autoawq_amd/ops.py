@@ -414,3 +414,30 @@ def decode_attention_rope(qkv, k_cache, v_cache, cos, sin, start_pos, n_heads, n
                                                n_kv_heads, D, k_cache.shape[1], float(scale), _ptr(ws), ws.numel(),
                                                _stream()), "awq_decode_attention_rope")
     return out
+
+
+def gemm_forward_normed(x2d, norm_weight, eps, qweight, scales, qzeros, bias=None, residual=None, flags=0):
+    """(y, stream) with y [M, N] = rmsnorm(x2d (+ residual)) * norm_weight @ W and stream = fp16(x2d + residual)
+    (None without a residual): awq_gemm_forward_normed, decode batches (M <= 4) of GEMM-layout weights."""
+    _require_gpu(x2d, norm_weight, qweight, scales, qzeros, bias, residual)
+    x2d, qweight, scales, qzeros = x2d.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    M, K = x2d.shape
+    N = qweight.shape[1] * 8
+    G = qzeros.shape[0]
+    if x2d.dtype != torch.float16 or qweight.shape[0] != K or G == 0 or K % G or norm_weight.numel() != K:
+        raise _lib.AwqHipError("gemm_forward_normed: fp16 x [M, K], norm weight [K], GEMM-layout buffers expected")
+    y = torch.empty((M, N), dtype=torch.float16, device=x2d.device)
+    res_out = None
+    if residual is not None:
+        if residual.shape != x2d.shape or residual.dtype != torch.float16 or not residual.is_contiguous():
+            raise _lib.AwqHipError("gemm_forward_normed: residual must be a contiguous fp16 tensor of x's shape")
+        res_out = torch.empty_like(residual)
+    L = _lib.lib()
+    with torch.cuda.device(x2d.device):
+        need = L.awq_gemm_workspace_bytes(M, K, N, K // G)
+        ws = workspace(x2d.device, need)
+        rc = L.awq_gemm_forward_normed(_ptr(x2d), _ptr(residual), _ptr(res_out), _ptr(norm_weight.contiguous()), float(eps),
+                                       _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(bias), _ptr(y), M, K, N, K // G,
+                                       _ptr(ws), ws.numel(), flags, _stream())
+    _lib.check(rc, "awq_gemm_forward_normed")
+    return y, res_out

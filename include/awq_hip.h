@@ -167,7 +167,7 @@ AWQ_EXPORT int awq_dequantize_weights_gemv_fast(const int16_t* qweight, const ui
 /* ---- fused decoder block around the Linears ------------------------------- */
 
 /* Replaces awq_ext.layernorm_forward_cuda(x, weight, out, eps) (awq/modules/fused/norm.py:33-36):
- * out [M, H] = fp16( x * rsqrt(mean(x^2) + eps) * weight ), fp32 arithmetic.  H % 8 == 0, H <= 8192.
+ * out [M, H] = fp16( x * rsqrt(mean(x^2) + eps) * weight ), fp32 arithmetic.  H % 8 == 0, H <= 16384.
  * If `residual` is non-NULL it is first updated in place, residual = fp16(residual + x), and the
  * updated row is what gets normalised (`h = hidden_states + attn_output` followed by the next norm,
  * awq/modules/fused/block.py:108-119, in one launch). */
@@ -197,6 +197,19 @@ AWQ_EXPORT int awq_decode_attention(const uint16_t* q, const uint16_t* k_cache, 
                                     const int32_t* len_dev, int64_t seq_len, int64_t max_len, int64_t B,
                                     int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq, float scale,
                                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* awq_rmsnorm_forward folded into the projection that follows it (decode, M <= 4, GEMM layout):
+ * y = rmsnorm(x (+ residual_in)) * norm_weight @ W.  Every block of the decode kernel recomputes the
+ * row statistic from the L2-resident row while its first weight requests are in flight and normalises
+ * its K slice as it stages it; if residual_in is given, fp16(x + residual_in) -- the residual stream --
+ * is written to residual_out (a DIFFERENT buffer: all blocks read residual_in, one writes).
+ * Same formulas and roundings as awq_rmsnorm_forward + awq_gemm_forward; the fp32 sum of squares is
+ * reduced in a different order.  AWQ_ERR_UNSUPPORTED for M > 4 or shapes the decode kernel does not take. */
+AWQ_EXPORT int awq_gemm_forward_normed(const uint16_t* x, const uint16_t* residual_in, uint16_t* residual_out,
+                                       const uint16_t* norm_weight, float eps, const int32_t* qweight,
+                                       const uint16_t* scales, const int32_t* qzeros, const uint16_t* bias, uint16_t* y,
+                                       int64_t M, int64_t K, int64_t N, int64_t group_size, void* workspace,
+                                       size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* awq_rope_kv_append + awq_decode_attention in ONE launch for a decode step (S = 1, full rotary,
  * head_dim = 128): qkv [B, (n_heads + 2*n_kv_heads) * 128] is the fused projection's output; query

@@ -194,6 +194,36 @@ def test_fused_rope_append_attention_equals_the_two_kernels(ops, B, Hq, Hkv, pos
         assert (got.float() - want.float()).abs().max() <= 2e-3 * want.float().abs().max() + 2 ** -11
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("K,N", [(4096, 12288), (512, 256), (11008, 4096)])
+def test_norm_folded_into_projection(ops, M, K, N):
+    """awq_gemm_forward_normed == awq_rmsnorm_forward (with residual add) + awq_gemm_forward: the residual
+    stream bit for bit, the product to the kernel tolerance (the sum of squares is reduced in another order)."""
+    from test_gpu_parity import fullrange_case
+
+    qw, qz, s, _, _ = fullrange_case(K, N, 128, 1, seed=K + M, realistic=True)
+    gen = torch.Generator().manual_seed(M + N)
+    x = torch.randn((M, K), generator=gen).half().cuda()
+    res = (torch.randn((M, K), generator=gen) * 2).half().cuda()
+    w = (torch.rand(K, generator=gen) + 0.5).half().cuda()
+    dq, ds, dz = qw.cuda(), s.cuda(), qz.cuda()
+    for residual in (None, res):
+        r2 = None if residual is None else residual.clone()
+        normed = ops.rmsnorm(x, w, 1e-5, residual=r2)
+        want = ops.gemm_forward(normed, dq, ds, dz).float()
+        got, stream = ops.gemm_forward_normed(x, w, 1e-5, dq, ds, dz, residual=residual)
+        assert ops.last_kernel() == "gemv_mfma"
+        if residual is None:
+            assert stream is None
+        else:
+            assert torch.equal(stream, r2) and torch.equal(residual, res)  # the input stream is not written
+        err = (got.float() - want).abs()
+        assert float(err.max()) <= 2e-3 * float(want.abs().max()) + 1e-3, float(err.max())
+    with pytest.raises(Exception):
+        ops.gemm_forward_normed(torch.zeros((5, K), dtype=torch.float16, device="cuda"), w, 1e-5, dq, ds, dz)
+
+
 # ------------------------------------------------------------------ GPU: the fused model
 
 def _fused(version, max_seq_len=32):
