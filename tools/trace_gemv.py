@@ -41,12 +41,14 @@ if __name__ == "__main__":
     L.awq_debug_set_trace.argtypes = [ctypes.c_void_p]
     dev = torch.device("cuda")
     gen = torch.Generator(device=dev).manual_seed(0)
-    cases = [(4096, 4096, 0, 0, 0), (4096, 4096, 16, 8, 2), (4096, 22016, 8, 4, 4), (11008, 4096, 16, 8, 4)]
-    for (K, N, sk, wv, un) in cases:
+    cases = [(4096, 4096, 0, 0, 0, 1), (4096, 4096, 16, 8, 2, 1), (4096, 22016, 8, 4, 4, 1), (11008, 4096, 16, 8, 4, 1)]
+    if os.environ.get("CASES"):  # "K,N,splitk,waves,unit,M;..."
+        cases = [tuple(int(v) for v in c.split(",")) for c in os.environ["CASES"].split(";")]
+    for (K, N, sk, wv, un, MM) in cases:
         per = K * N // 2
         nsets = max(4, min(40, (600 << 20) // per))
         sets = [rand_packed(K, N, 128, dev, gen) for _ in range(nsets)]
-        x = torch.randn((1, K), device=dev, generator=gen).half()
+        x = torch.randn((MM, K), device=dev, generator=gen).half()
         trace = torch.zeros(8192 * 8 * 16, dtype=torch.int64, device=dev)
         flags = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, splitk=sk, waves=wv, unit=un)
         L.awq_debug_set_trace(None)
@@ -69,7 +71,7 @@ if __name__ == "__main__":
             if a.size == 0:
                 return "   (none)"
             return " ".join(f"{v:6.2f}" for v in np.percentile(a, [0, 10, 50, 90, 100])) + f"   n={a.size}"
-        print(f"\n=== K{K} N{N} splitk={sk} waves={wv} unit={un}: {nw} waves traced; kernel span {np.nanmax(t):.2f} us")
+        print(f"\n=== K{K} N{N} M{MM} splitk={sk} waves={wv} unit={un}: {nw} waves traced; kernel span {np.nanmax(t):.2f} us")
         print("  wave start                (p0 p10 p50 p90 p100):", q(t[:, 0]))
         print("  +staging loads->LDS stores issued              :", q(t[:, 7] - t[:, 0]))
         print("  +first unit's weight loads issued              :", q(t[:, 1] - t[:, 7]))
