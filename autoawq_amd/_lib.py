@@ -15,6 +15,16 @@ _lib = None
 c_void_p, c_int, c_int64, c_size_t, c_uint32, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                            ctypes.c_size_t, ctypes.c_uint32, ctypes.c_float)
 
+class AwqGemmEx(ctypes.Structure):
+    """struct AwqGemmEx of include/awq_hip.h (same field order)."""
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("x", c_void_p), ("qweight", c_void_p), ("scales", c_void_p), ("qzeros", c_void_p), ("bias", c_void_p),
+                ("y", c_void_p), ("M", c_int64), ("K", c_int64), ("N", c_int64), ("group_size", c_int64),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("stream", c_void_p),
+                ("norm_weight", c_void_p), ("norm_eps", c_float), ("residual_in", c_void_p), ("residual_out", c_void_p),
+                ("ssq_in", c_void_p), ("ssq_in_tiles", c_int64), ("add_residual", c_void_p), ("ssq_out", c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/awq_hip.h declares
 # (tests/test_boundary.py cross-checks this table against the header and the .so).
 SIGNATURES = {
@@ -29,6 +39,8 @@ SIGNATURES = {
                                  c_int64, c_int64, c_void_p, c_size_t, c_uint32, c_void_p]),
     "awq_gemm_forward_normed": (c_int, [c_void_p] * 4 + [c_float] + [c_void_p] * 5 + [c_int64] * 4 +
                                 [c_void_p, c_size_t, c_uint32, c_void_p]),
+    "awq_gemm_ex_ssq_tiles": (c_int64, [c_int64]),
+    "awq_gemm_forward_ex": (c_int, [ctypes.POINTER(AwqGemmEx)]),
     "awq_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "awq_rmsnorm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
     "awq_rope_kv_append": (c_int, [c_void_p] * 7 + [c_int64] * 8 + [c_void_p]),

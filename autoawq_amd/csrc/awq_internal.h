@@ -24,6 +24,10 @@ struct AwqGemmArgs {
     uint16_t* res_out = nullptr;        // mode 2: fp16(x + res_in) is written here (must not alias res_in)
     const uint16_t* norm_w = nullptr;   // mode 2: norm weight [K]
     float norm_eps = 0.f;
+    const float* ssq_in = nullptr;      // mode 2: [M, ssq_in_tiles] row sums of squares from the producing call
+    int ssq_in_tiles = 0;
+    const uint16_t* add_res = nullptr;  // epilogue (decode kernel, M <= 4): y = fp16(fp16(x W + bias) + add_res)
+    float* ssq_out = nullptr;           // epilogue: [M, ceil(N / 256)] sums of squares of y per 256-column tile
     int* counters;   // control words (word 0 = error flag), zero on entry
     float* exchange;  // in-launch split-K exchange region: all-ones sentinel on entry AND on exit
     size_t exchange_bytes;

@@ -82,11 +82,15 @@ int awq_gemm_workspace_init(void* workspace, size_t workspace_bytes, void* strea
 }
 
 namespace {
-struct NormArgs {
+struct NormArgs {  // prologue / epilogue extras of awq_gemm_forward_normed / _ex
     const uint16_t* res_in;
     uint16_t* res_out;
-    const uint16_t* weight;
+    const uint16_t* weight;  // NULL: no norm prologue
     float eps;
+    const float* ssq_in = nullptr;
+    int ssq_in_tiles = 0;
+    const uint16_t* add_res = nullptr;
+    float* ssq_out = nullptr;
 };
 int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                       const uint16_t* bias, uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size,
@@ -113,6 +117,24 @@ int awq_gemm_forward_normed(const uint16_t* x, const uint16_t* residual_in, uint
     const NormArgs nrm{residual_in, residual_out, norm_weight, eps};
     return gemm_forward_impl(x, qweight, scales, qzeros, bias, y, M, K, N, group_size, workspace, workspace_bytes, flags,
                              stream, &nrm);
+}
+
+int64_t awq_gemm_ex_ssq_tiles(int64_t N) { return N > 0 ? (N + 255) / 256 : 0; }
+
+int awq_gemm_forward_ex(const AwqGemmEx* e) {
+    if (!e) return AWQ_ERR_NULL;
+    if (e->struct_bytes != sizeof(AwqGemmEx)) return AWQ_ERR_BAD_SHAPE;
+    NormArgs n{e->residual_in, e->residual_out, e->norm_weight, e->norm_eps};
+    n.ssq_in = e->ssq_in; n.ssq_in_tiles = (int)e->ssq_in_tiles; n.add_res = e->add_residual; n.ssq_out = e->ssq_out;
+    if ((e->residual_in == nullptr) != (e->residual_out == nullptr)) return AWQ_ERR_NULL;
+    if (e->residual_in && (!e->norm_weight || e->residual_in == e->residual_out)) return AWQ_ERR_BAD_SHAPE;
+    if (e->ssq_in && (!e->norm_weight || e->residual_in || e->ssq_in_tiles < 1 || e->ssq_in_tiles > 64)) return AWQ_ERR_BAD_SHAPE;
+    if (e->add_residual && e->add_residual == e->y) return AWQ_ERR_BAD_SHAPE;  // other tiles' blocks may still read it
+    const uint16_t* ptrs[] = {e->norm_weight, e->residual_in, e->residual_out, e->add_residual};
+    for (const uint16_t* q : ptrs)
+        if (q && !aligned16(q)) return AWQ_ERR_BAD_ALIGNMENT;
+    return gemm_forward_impl(e->x, e->qweight, e->scales, e->qzeros, e->bias, e->y, e->M, e->K, e->N, e->group_size,
+                             e->workspace, e->workspace_bytes, e->flags, e->stream, &n);
 }
 
 namespace {
@@ -144,12 +166,20 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
 
     a.x_gated = (flags & AWQ_GEMM_FLAG_X_GATED_SILU) ? 1 : 0;
     if (nrm) {
-        a.x_gated = 2;
-        a.res_in = nrm->res_in; a.res_out = nrm->res_out; a.norm_w = nrm->weight; a.norm_eps = nrm->eps;
+        if (nrm->weight) {
+            if (a.x_gated) return AWQ_ERR_UNSUPPORTED;
+            a.x_gated = 2;
+            a.res_in = nrm->res_in; a.res_out = nrm->res_out; a.norm_w = nrm->weight; a.norm_eps = nrm->eps;
+            a.ssq_in = nrm->ssq_in; a.ssq_in_tiles = nrm->ssq_in_tiles;
+        }
+        a.add_res = nrm->add_res; a.ssq_out = nrm->ssq_out;
     }
-    if (a.x_gated && (M > 16 || !awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2))) return AWQ_ERR_UNSUPPORTED;
+    const bool extras = nrm != nullptr;  // decode kernel only, in-launch combine only
+    if ((a.x_gated || extras) && (M > 16 || !awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2))) return AWQ_ERR_UNSUPPORTED;
+    if (extras && (M > 4 || (flags & AWQ_GEMM_FLAG_TWO_PASS))) return AWQ_ERR_UNSUPPORTED;
     unsigned kern = AWQ_GEMM_FLAG_KERNEL(flags);
-    if (a.x_gated && kern != AWQ_GEMM_KERNEL_AUTO && kern != AWQ_GEMM_KERNEL_MFMA_GEMV) return AWQ_ERR_UNSUPPORTED;
+    if ((a.x_gated || extras) && kern != AWQ_GEMM_KERNEL_AUTO && kern != AWQ_GEMM_KERNEL_MFMA_GEMV) return AWQ_ERR_UNSUPPORTED;
+    if (extras && AWQ_GEMM_FLAG_NLOG(flags) == 4) return AWQ_ERR_UNSUPPORTED;  // the epilogue assumes 256-column tiles
     int nlog = (int)AWQ_GEMM_FLAG_NLOG(flags);
     int splitk = (int)AWQ_GEMM_FLAG_SPLITK(flags);
     const int waves = (int)AWQ_GEMM_FLAG_WAVES(flags);
@@ -165,7 +195,7 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
                 return rc;
             }
         }
-        if (a.x_gated) return AWQ_ERR_UNSUPPORTED;
+        if (a.x_gated || extras) return AWQ_ERR_UNSUPPORTED;
         if (M > 16 && awq_gemm_tiled_supports(a.M, a.K, a.N, a.g)) kern = AWQ_GEMM_KERNEL_TILED;
         else kern = AWQ_GEMM_KERNEL_NAIVE;  // odd shapes
     }

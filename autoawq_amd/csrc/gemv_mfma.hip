@@ -52,6 +52,10 @@ struct GemvMfmaParams {
     half_t* res_out;          // ... and where fp16(x + residual) is written (by ONE block; must not alias res_in)
     const half_t* norm_w;     // mode 2: norm weight [K]
     float norm_eps;
+    const float* ssq_in;      // mode 2: [M, ssq_in_tiles] partial row sums of squares handed over by the producer
+    int ssq_in_tiles;         //         (replaces the statistic pass; x already is the stream)
+    const half_t* add_res;    // epilogue: y = fp16(fp16(x W + bias) + add_res)   [M, N]
+    float* ssq_out;           // epilogue: [M, tiles] sums of squares of the y values of each 256-column tile
     const half_t* bias;
     half_t* y;
     float* slabs;    // in-launch exchange region [S-1][tiles][M][CW] fp32: all-ones sentinel on entry and on exit
@@ -280,6 +284,14 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                 };
                 const bool writer = p.res_out != nullptr && tile == 0 && slice == 0;
                 const int kch = p.K >> 3;
+                if (p.ssq_in) {  // the producing projection handed the statistic over: wave m sums row m's tile partials
+                    if (wave < M) {
+                        float part = lane < p.ssq_in_tiles ? p.ssq_in[wave * p.ssq_in_tiles + lane] : 0.f;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                        if (lane == 0) nrm_part[wave][0] = part;
+                    }
+                } else
                 for (int m = 0; m < M; ++m) {  // M <= 4: the row statistic, recomputed by every block
                     float ss = 0.f;
                     for (int c = tid; c < kch; c += NTHR) {
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                 __syncthreads();
                 if (tid < M) {
                     float tot = 0.f;
-                    for (int w = 0; w < NWAVES; ++w) tot += nrm_part[tid][w];
+                    for (int w = 0; w < (p.ssq_in ? 1 : NWAVES); ++w) tot += nrm_part[tid][w];
                     nrm_inv[tid] = rsqrtf(tot / (float)p.K + p.norm_eps);
                 }
                 __syncthreads();
@@ -468,14 +480,14 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         }
         return s;
     };
-    auto emit4 = [&](int qd, float4_t s) {
+    auto emit4 = [&](int qd, float4_t s) -> float {  // returns the sum of squares of the four stored values
         const int m = qd / (CW / 4), c4 = (qd % (CW / 4)) * 4;
         const int col = col0 + c4;
-        if (col >= p.N) return;  // N % 8 == 0: a quad is all in or all out
+        if (col >= p.N) return 0.f;  // N % 8 == 0: a quad is all in or all out
         int64_t orow = m;
         if constexpr (MOE) {  // scatter to the pair's row, optionally scaled by its routing weight
             const int pid = p.sorted_ids[p.M * tblk + m];
-            if (pid >= p.num_pairs) return;
+            if (pid >= p.num_pairs) return 0.f;
             orow = pid;
             if (p.pair_weights) s *= p.pair_weights[pid];
         }
@@ -483,13 +495,30 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
             const half4_t b4 = *reinterpret_cast<const half4_t*>(p.bias + col);
             s += float4_t{(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
         }
-        const half4_t o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
+        half4_t o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
+        if (p.add_res) {  // the residual stream: fp16(fp16(projection) + residual), the two roundings torch makes
+            const half4_t r4 = *reinterpret_cast<const half4_t*>(p.add_res + orow * p.N + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)o[e] + (float)r4[e]);
+        }
         *reinterpret_cast<half4_t*>(p.y + orow * p.N + col) = o;
+        return (float)o[0] * (float)o[0] + (float)o[1] * (float)o[1] + (float)o[2] * (float)o[2] + (float)o[3] * (float)o[3];
+    };
+    // ssq_out (M <= 4, 256-column tiles): quads of row m are threads 64 m .. 64 m + 63 = wave m, so one
+    // butterfly per wave gives the tile's partial sum of squares of that row in a fixed order
+    auto emit_ssq = [&](float ss) {
+        if (p.ssq_out) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            if (lane == 0 && wave < M) p.ssq_out[wave * p.tiles + tile] = ss;
+        }
     };
 
     const int S = p.S;
     if (S == 1) {
-        for (int qd = tid; qd < quads; qd += NWAVES * 64) emit4(qd, block_sum4(qd));
+        float ss = 0.f;
+        for (int qd = tid; qd < quads; qd += NWAVES * 64) ss += emit4(qd, block_sum4(qd));
+        emit_ssq(ss);
         return;
     }
     if (p.two_pass) {  // plain fp32 slabs [S][M][N]; a second kernel reduces
@@ -528,6 +557,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         return;
     }
     const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+    float ssq_acc = 0.f;
     for (int qd = tid; qd < quads; qd += NWAVES * 64) {
         const float4_t own = block_sum4(qd);
         float4_t s = {0.f, 0.f, 0.f, 0.f};
@@ -558,8 +588,9 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                     __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, (uint32_t)qd * 16u + (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes,
                                                            0, 16);
         }
-        emit4(qd, s + own);
+        ssq_acc += emit4(qd, s + own);
     }
+    emit_ssq(ssq_acc);
     AWQ_STAMP(5);
 }
 
@@ -804,6 +835,9 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     p.res_out = reinterpret_cast<half_t*>(a.res_out);
     p.norm_w = reinterpret_cast<const half_t*>(a.norm_w);
     p.norm_eps = a.norm_eps;
+    p.ssq_in = a.ssq_in; p.ssq_in_tiles = a.ssq_in_tiles;
+    p.add_res = reinterpret_cast<const half_t*>(a.add_res);
+    p.ssq_out = a.ssq_out;
     p.bias = nullptr;
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
@@ -850,6 +884,9 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
     p.res_out = reinterpret_cast<half_t*>(a.res_out);
     p.norm_w = reinterpret_cast<const half_t*>(a.norm_w);
     p.norm_eps = a.norm_eps;
+    p.ssq_in = a.ssq_in; p.ssq_in_tiles = a.ssq_in_tiles;
+    p.add_res = reinterpret_cast<const half_t*>(a.add_res);
+    p.ssq_out = a.ssq_out;
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;

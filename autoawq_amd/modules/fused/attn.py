@@ -94,9 +94,10 @@ class QuantAttentionFused(nn.Module):
             xqkv = xqkv.half()
         return self.forward_qkv(xqkv)
 
-    def forward_qkv(self, xqkv):
+    def forward_qkv(self, xqkv, apply_o_proj=True):
         """Everything after the qkv projection (the caller may have produced `xqkv` [B, S, (Hq + 2 Hkv) D]
-        with the norm folded into the projection)."""
+        with the norm folded into the projection).  apply_o_proj=False returns the attention heads' output
+        in place of attn_output (the caller runs o_proj with the residual add in its epilogue)."""
         bsz, seqlen, _ = xqkv.shape
         self._resize_cache(bsz)
         device_pos = self._pos_dev is not None and seqlen == 1
@@ -106,7 +107,7 @@ class QuantAttentionFused(nn.Module):
                                             self.n_heads, self.n_kv_heads, pos_dev=self._pos_dev if device_pos else None,
                                             max_len=self.max_seq_len if device_pos else None)
             attention_weight = out.reshape(bsz, 1, -1)
-            attn_output = self.o_proj(attention_weight)
+            attn_output = self.o_proj(attention_weight) if apply_o_proj else attention_weight
             self.start_pos += 1
             return attn_output, attention_weight, [torch.zeros(1, 1, self.start_pos, 1)]
         xq = ops.rope_kv_append(xqkv, self.cache.k, self.cache.v, self.rope.cos, self.rope.sin, self.start_pos,
@@ -139,7 +140,7 @@ class QuantAttentionFused(nn.Module):
                                            len_dev=self._len_dev if device_pos else None, max_len=self.max_seq_len)
                 output = out.reshape(bsz, 1, -1)
         attention_weight = output
-        attn_output = self.o_proj(attention_weight)
+        attn_output = self.o_proj(attention_weight) if apply_o_proj else attention_weight
         self.start_pos += seqlen
         past_key_value = [torch.zeros(1, 1, self.start_pos, 1)]
         return attn_output, attention_weight, past_key_value

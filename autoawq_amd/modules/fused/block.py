@@ -49,29 +49,45 @@ class LlamaLikeBlock(nn.Module):
                 and isinstance(self.attn.qkv_proj, WQLinear_GEMM) and isinstance(self.mlp, QuantFusedMLP)
                 and not self.mlp.gemv_layout and self.attn.qkv_proj.in_features % 32 == 0)
 
-    def forward_stream(self, x, h):
-        """Residual stream kept by the caller (LlamaLikeModel): `h` is the stream, `x` the previous
-        block's MLP output that has not been added yet (None for the first block).  Both residual
-        adds ride on the norms -- and for decode batches the norms themselves ride on the projections
-        that follow them (`awq_gemm_forward_normed`): a block is qkv, attention, o_proj, gate|up, down --
-        five launches.  Returns (mlp output, stream)."""
+    def forward_stream(self, x, h, ssq=None):
+        """Residual stream kept by the caller (LlamaLikeModel): `h` is the stream, `x` a previous MLP output
+        that has not been added yet (or None), `ssq` the per-tile sums of squares of `h` if the projection
+        that produced it handed them over.  Decode batches run FIVE launches per block: qkv (norm folded
+        into its staging), attention (RoPE + cache append inside), o_proj (residual add + sums of squares in
+        its epilogue), gate|up (norm from those sums), down (silu*mul while staging, residual add + sums of
+        squares for the next block).  Returns (pending x | None, stream, ssq | None)."""
         if self._can_fold(h):
             B, S, H = h.shape
-            q = self.attn.qkv_proj
-            if x is None:
-                xqkv, _ = ops.gemm_forward_normed(h.reshape(B * S, H), self.norm_1.weight, self.norm_1.variance_epsilon,
-                                                  q.qweight, q.scales, q.qzeros, q.bias)
+            q, o, d = self.attn.qkv_proj, self.attn.o_proj, self.mlp.down_proj
+            n1, n2 = self.norm_1, self.norm_2
+            if ssq is not None and x is None:
+                xqkv, _ = ops.gemm_forward_ex(h.reshape(B * S, H), q.qweight, q.scales, q.qzeros, q.bias,
+                                              norm_weight=n1.weight, norm_eps=n1.variance_epsilon, ssq_in=ssq)
+            elif x is None:
+                xqkv, _ = ops.gemm_forward_normed(h.reshape(B * S, H), n1.weight, n1.variance_epsilon, q.qweight, q.scales,
+                                                  q.qzeros, q.bias)
             else:
-                xqkv, hn = ops.gemm_forward_normed(x.reshape(B * S, H), self.norm_1.weight, self.norm_1.variance_epsilon,
-                                                   q.qweight, q.scales, q.qzeros, q.bias, residual=h.reshape(B * S, H))
+                xqkv, hn = ops.gemm_forward_normed(x.reshape(B * S, H), n1.weight, n1.variance_epsilon, q.qweight, q.scales,
+                                                   q.qzeros, q.bias, residual=h.reshape(B * S, H))
                 h = hn.reshape(B, S, H)
+            from ..linear.gemm import WQLinear_GEMM
+
+            chain = isinstance(o, WQLinear_GEMM) and isinstance(d, WQLinear_GEMM) and self.mlp.activation is torch.nn.functional.silu
+            if chain:
+                heads, _, _ = self.attn.forward_qkv(xqkv.reshape(B, S, -1), apply_o_proj=False)
+                h1, ssq1 = ops.gemm_forward_ex(heads.reshape(B * S, -1), o.qweight, o.scales, o.qzeros, o.bias,
+                                               add_residual=h.reshape(B * S, H), want_ssq=True)
+                qw, sc, qz = self.mlp._gate_up_fused()
+                gate_up, _ = ops.gemm_forward_ex(h1, qw, sc, qz, norm_weight=n2.weight, norm_eps=n2.variance_epsilon, ssq_in=ssq1)
+                h2, ssq2 = ops.gemm_forward_ex(gate_up, d.qweight, d.scales, d.qzeros, d.bias, flags=ops.X_GATED_SILU,
+                                               add_residual=h1, want_ssq=True)
+                return None, h2.reshape(B, S, H), ssq2
             attn_output, _, _ = self.attn.forward_qkv(xqkv.reshape(B, S, -1))
             qw, sc, qz = self.mlp._gate_up_fused()
-            gate_up, hn = ops.gemm_forward_normed(attn_output.reshape(B * S, H), self.norm_2.weight,
-                                                  self.norm_2.variance_epsilon, qw, sc, qz, residual=h.reshape(B * S, H))
-            h = hn.reshape(B, S, H)
-            return self.mlp.forward(attn_output, gate_up=gate_up), h
+            gate_up, hn = ops.gemm_forward_normed(attn_output.reshape(B * S, H), n2.weight, n2.variance_epsilon, qw, sc, qz,
+                                                  residual=h.reshape(B * S, H))
+            return self.mlp.forward(attn_output, gate_up=gate_up), hn.reshape(B, S, H), None
         norm_out = self.norm_1(h) if x is None else self.norm_1(x, residual=h)
         attn_output, _, _ = self.attn.forward(hidden_states=norm_out)
         normed = self.norm_2(attn_output, residual=h)
-        return self.mlp.forward(normed), h
+        return self.mlp.forward(normed), h, None

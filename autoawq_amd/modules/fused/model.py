@@ -60,9 +60,9 @@ class LlamaLikeModel(nn.Module):
         prepare_cache(self.blocks, seqlen)
         h = self.embedding(input_ids)
         if self._stream_mode(h):
-            x = None
-            for layer in self.blocks:  # the residual adds ride on the next norm (block.forward_stream)
-                x, h = layer.forward_stream(x, h)
+            x, ssq = None, None
+            for layer in self.blocks:  # residual adds and norms ride on the projections (block.forward_stream)
+                x, h, ssq = layer.forward_stream(x, h, ssq)
             h = self.norm(x, residual=h) if x is not None else self.norm(h)
         else:
             for layer in self.blocks:

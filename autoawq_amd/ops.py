@@ -3,6 +3,8 @@
 PyTorch is plumbing here (device memory, current stream); every computation is a hand-written
 gfx950 kernel reached through the C ABI of include/awq_hip.h.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -441,3 +443,47 @@ def gemm_forward_normed(x2d, norm_weight, eps, qweight, scales, qzeros, bias=Non
                                        _ptr(ws), ws.numel(), flags, _stream())
     _lib.check(rc, "awq_gemm_forward_normed")
     return y, res_out
+
+
+def gemm_forward_ex(x2d, qweight, scales, qzeros, bias=None, flags=0, norm_weight=None, norm_eps=0.0, ssq_in=None,
+                    add_residual=None, want_ssq=False):
+    """Decode-sized projection with the decoder block's prologue / epilogue (awq_gemm_forward_ex):
+    norm_weight (+ ssq_in [M, tiles] from the producing call, else a statistic pass) normalises x while
+    staging; add_residual stores y = fp16(fp16(x W + bias) + add_residual); want_ssq returns the per-tile
+    sums of squares of y.  Returns (y, ssq | None)."""
+    _require_gpu(x2d, qweight, scales, qzeros, bias, norm_weight, ssq_in, add_residual)
+    x2d, qweight, scales, qzeros = x2d.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    M, K = x2d.shape
+    if flags & X_GATED_SILU:
+        K //= 2
+    N = qweight.shape[1] * 8
+    G = qzeros.shape[0]
+    if x2d.dtype != torch.float16 or qweight.shape[0] != K or G == 0 or K % G:
+        raise _lib.AwqHipError("gemm_forward_ex: fp16 x [M, K] and GEMM-layout buffers expected")
+    L = _lib.lib()
+    y = torch.empty((M, N), dtype=torch.float16, device=x2d.device)
+    ssq = torch.empty((M, L.awq_gemm_ex_ssq_tiles(N)), dtype=torch.float32, device=x2d.device) if want_ssq else None
+    if add_residual is not None and (add_residual.shape != y.shape or add_residual.dtype != torch.float16
+                                     or not add_residual.is_contiguous()):
+        raise _lib.AwqHipError("gemm_forward_ex: add_residual must be a contiguous fp16 [M, N] tensor")
+    if ssq_in is not None and (ssq_in.dtype != torch.float32 or ssq_in.shape[0] != M or not ssq_in.is_contiguous()):
+        raise _lib.AwqHipError("gemm_forward_ex: ssq_in must be a contiguous fp32 [M, tiles] tensor")
+    with torch.cuda.device(x2d.device):
+        need = L.awq_gemm_workspace_bytes(M, K, N, K // G)
+        ws = workspace(x2d.device, need)
+        e = _lib.AwqGemmEx()
+        e.struct_bytes = ctypes.sizeof(_lib.AwqGemmEx)
+        e.flags = flags
+        e.x, e.qweight, e.scales, e.qzeros, e.bias, e.y = _ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(bias), _ptr(y)
+        e.M, e.K, e.N, e.group_size = M, K, N, K // G
+        e.workspace, e.workspace_bytes, e.stream = _ptr(ws), ws.numel(), _stream()
+        e.norm_weight = _ptr(norm_weight.contiguous()) if norm_weight is not None else None
+        e.norm_eps = float(norm_eps)
+        e.residual_in = e.residual_out = None
+        e.ssq_in = _ptr(ssq_in)
+        e.ssq_in_tiles = ssq_in.shape[1] if ssq_in is not None else 0
+        e.add_residual = _ptr(add_residual)
+        e.ssq_out = _ptr(ssq)
+        rc = L.awq_gemm_forward_ex(ctypes.byref(e))
+    _lib.check(rc, "awq_gemm_forward_ex")
+    return y, ssq

@@ -211,6 +211,41 @@ AWQ_EXPORT int awq_gemm_forward_normed(const uint16_t* x, const uint16_t* residu
                                        int64_t M, int64_t K, int64_t N, int64_t group_size, void* workspace,
                                        size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* awq_gemm_forward with the prologue / epilogue a decoder block wants around a decode-sized projection
+ * (M <= 4, GEMM layout, shapes the decode kernel takes; AWQ_ERR_UNSUPPORTED otherwise).  Unused fields
+ * are 0 / NULL.  Prologue: norm_weight != NULL normalises x while staging (RMSNorm, fp32, the
+ * roundings of awq_rmsnorm_forward); the row statistic comes either from ssq_in -- [M, ssq_in_tiles]
+ * partial sums of squares written by the PRODUCING call's ssq_out, no statistic pass at all -- or, if
+ * ssq_in is NULL, from a pass over x (+ residual_in, written to residual_out: the
+ * awq_gemm_forward_normed form).  Epilogue: add_residual != NULL stores
+ * y = fp16(fp16(x W + bias) + add_residual) -- the two roundings of `h + proj(x)` in torch;
+ * ssq_out != NULL receives [M, awq_gemm_ex_ssq_tiles(N)] sums of squares of the stored y values, one
+ * per 256-column tile (fixed summation order).  flags as for awq_gemm_forward. */
+typedef struct AwqGemmEx {
+    uint32_t struct_bytes; /* sizeof(AwqGemmEx) */
+    uint32_t flags;
+    const uint16_t* x;
+    const int32_t* qweight;
+    const uint16_t* scales;
+    const int32_t* qzeros;
+    const uint16_t* bias;
+    uint16_t* y;
+    int64_t M, K, N, group_size;
+    void* workspace;
+    size_t workspace_bytes;
+    void* stream;
+    const uint16_t* norm_weight;
+    float norm_eps;
+    const uint16_t* residual_in;
+    uint16_t* residual_out;
+    const float* ssq_in;
+    int64_t ssq_in_tiles;
+    const uint16_t* add_residual;
+    float* ssq_out;
+} AwqGemmEx;
+AWQ_EXPORT int64_t awq_gemm_ex_ssq_tiles(int64_t N);
+AWQ_EXPORT int awq_gemm_forward_ex(const AwqGemmEx* args);
+
 /* awq_rope_kv_append + awq_decode_attention in ONE launch for a decode step (S = 1, full rotary,
  * head_dim = 128): qkv [B, (n_heads + 2*n_kv_heads) * 128] is the fused projection's output; query
  * heads are rotated in registers, the new token's rotated k and its v are used from registers and

@@ -224,6 +224,42 @@ def test_norm_folded_into_projection(ops, M, K, N):
         ops.gemm_forward_normed(torch.zeros((5, K), dtype=torch.float16, device="cuda"), w, 1e-5, dq, ds, dz)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 3, 4])
+@pytest.mark.parametrize("H,I", [(4096, 11008), (512, 1024)])
+def test_residual_epilogue_hands_the_statistic_to_the_next_projection(ops, M, H, I):
+    """awq_gemm_forward_ex: a row-parallel projection (o_proj / down) adds the residual stream in its
+    epilogue and emits per-tile sums of squares; the next projection normalises from them without a
+    statistic pass.  Stream: bit-identical to `h + proj(x)` in torch (two fp16 roundings); the partial
+    sums match the stored values; the normed product matches rmsnorm + gemm within the kernel tolerance."""
+    from test_gpu_parity import fullrange_case
+
+    qw1, qz1, s1, _, _ = fullrange_case(I, H, 128, 1, seed=H + M, realistic=True)      # down: I -> H
+    qw2, qz2, s2, _, _ = fullrange_case(H, 2 * I, 128, 1, seed=H + M + 1, realistic=True)  # next gate|up: H -> 2I
+    gen = torch.Generator().manual_seed(M)
+    gate_up = torch.randn((M, 2 * I), generator=gen).half().cuda()
+    h = (torch.randn((M, H), generator=gen) * 2).half().cuda()
+    w = (torch.rand(H, generator=gen) + 0.5).half().cuda()
+    d1 = (qw1.cuda(), s1.cuda(), qz1.cuda())
+    d2 = (qw2.cuda(), s2.cuda(), qz2.cuda())
+    # reference chain with the separate kernels
+    proj = ops.gemm_forward(gate_up, *d1, flags=ops.X_GATED_SILU)
+    stream_ref = (proj.float() + h.float()).half()
+    next_ref = ops.gemm_forward(ops.rmsnorm(stream_ref, w, 1e-5), *d2).float()
+    # fused chain
+    stream, ssq = ops.gemm_forward_ex(gate_up, *d1, flags=ops.X_GATED_SILU, add_residual=h, want_ssq=True)
+    assert torch.equal(stream, stream_ref)
+    tiles = (H + 255) // 256
+    assert ssq.shape == (M, tiles)
+    want_ssq = (stream.float() ** 2).reshape(M, tiles, -1).sum(-1)
+    assert torch.allclose(ssq, want_ssq, rtol=1e-5, atol=1e-6)
+    nxt, none = ops.gemm_forward_ex(stream, *d2, norm_weight=w, norm_eps=1e-5, ssq_in=ssq)
+    assert none is None
+    err = (nxt.float() - next_ref).abs()
+    assert float(err.max()) <= 2e-3 * float(next_ref.abs().max()) + 1e-3, float(err.max())
+    assert ops.workspace_is_clean(h.device)
+
+
 # ------------------------------------------------------------------ GPU: the fused model
 
 def _fused(version, max_seq_len=32):
