@@ -74,13 +74,15 @@ __device__ unsigned long long* g_awq_trace_tiled = nullptr;
 #define AWQ_TSTAMP(slot) do { } while (0)
 #endif
 
-template <int BM, int BN, bool SPLITK, int BK = BK_DEFAULT>
-__global__ __launch_bounds__((BM >= 128 ? 2 : 1) * (BN >= 256 ? 4 : (BM >= 128 ? 2 : 4)) * 64)
+// FAT: the 128 x 256 tile on FOUR waves of 64 x 128 (instead of eight of 64 x 64): a quarter fewer LDS
+// fragment bytes per MFMA (12 fragments feed 32 MFMAs instead of 8 feeding 16), 128 accumulator registers.
+template <int BM, int BN, bool SPLITK, int BK = BK_DEFAULT, bool FAT = false>
+__global__ __launch_bounds__((BM >= 128 ? 2 : 1) * (BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4)) * 64, FAT ? 2 : 1)
 void awq_gemm_tiled_kernel(TiledParams p) {
     constexpr int APITCH = BK + 8;  // halfs per A row in LDS (144 / 80 bytes)
     constexpr int CPR = BK / 8;     // 16-byte activation chunks per row of a K step
     constexpr int WGM = BM >= 128 ? 2 : 1;                     // waves along M
-    constexpr int WGN = BN >= 256 ? 4 : (BM >= 128 ? 2 : 4);   // waves along N
+    constexpr int WGN = BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4);   // waves along N
     constexpr int NTHR = WGM * WGN * 64;
     constexpr int WM = BM / WGM;            // rows per wave
     constexpr int MI = WM / 16;             // 16-row MFMA tiles per wave
@@ -378,20 +380,25 @@ void awq_gemm_tiled_kernel(TiledParams p) {
     AWQ_TSTAMP(6);
 }
 
-template <int BM, int BN, int BK = BK_DEFAULT>
+template <int BM, int BN, int BK = BK_DEFAULT, bool FAT = false>
 void launch_tiled(const TiledParams& p, unsigned grid, hipStream_t st) {
     constexpr size_t lds = 2 * (BM * (BK + 8) * 2 + BK * BN * 2);
     static const bool lds_opt_in = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, false, BK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, false, BK, FAT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, true, BK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (!FAT)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, true, BK, FAT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)lds_opt_in;
-    constexpr int NTHR = (BM >= 128 ? 2 : 1) * (BN >= 256 ? 4 : (BM >= 128 ? 2 : 4)) * 64;
-    if (p.S > 1) hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, true, BK>), dim3(grid), dim3(NTHR), lds, st, p);
-    else hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false, BK>), dim3(grid), dim3(NTHR), lds, st, p);
+    constexpr int NTHR = (BM >= 128 ? 2 : 1) * (BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4)) * 64;
+    if constexpr (FAT) {  // chip-filling grids only: never split (its split-K form would spill)
+        hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false, BK, FAT>), dim3(grid), dim3(NTHR), lds, st, p);
+    } else {
+        if (p.S > 1) hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, true, BK, FAT>), dim3(grid), dim3(NTHR), lds, st, p);
+        else hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false, BK, FAT>), dim3(grid), dim3(NTHR), lds, st, p);
+    }
 }
 
 }  // namespace
@@ -402,6 +409,7 @@ extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_tiled
 }
 #endif
 
+static const bool g_fat = [] { const char* e = getenv("AWQ_TILED_FAT"); return !(e && e[0] == '0'); }();  // tuning switch
 static const bool g_bk32 = [] { const char* e = getenv("AWQ_TILED_BK32"); return !(e && e[0] == '0'); }();  // tuning switch
 
 bool awq_gemm_tiled_supports(int M, int K, int N, int g) {
@@ -459,6 +467,7 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     if (BM == 32) launch_tiled<32, 128>(p, grid, a.stream);
     else if (BM == 64) launch_tiled<64, 128>(p, grid, a.stream);
     else if (bn == 128) launch_tiled<128, 128>(p, grid, a.stream);
+    else if (BKsel == 32 && g_fat) launch_tiled<128, 256, 32, true>(p, grid, a.stream);
     else if (BKsel == 32) launch_tiled<128, 256, 32>(p, grid, a.stream);
     else launch_tiled<128, 256>(p, grid, a.stream);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
