@@ -77,11 +77,11 @@ __device__ unsigned long long* g_awq_trace_tiled = nullptr;
 // FAT: the 128 x 256 tile on FOUR waves of 64 x 128 (instead of eight of 64 x 64): a quarter fewer LDS
 // fragment bytes per MFMA (12 fragments feed 32 MFMAs instead of 8 feeding 16), 128 accumulator registers.
 template <int BM, int BN, bool SPLITK, int BK = BK_DEFAULT, bool FAT = false>
-__global__ __launch_bounds__((BM >= 128 ? 2 : 1) * (BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4)) * 64, FAT ? 2 : 1)
+__global__ __launch_bounds__((FAT ? BM / 64 : (BM >= 128 ? 2 : 1)) * (BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4)) * 64, (FAT && BM == 128) ? 2 : 1)
 void awq_gemm_tiled_kernel(TiledParams p) {
     constexpr int APITCH = BK + 8;  // halfs per A row in LDS (144 / 80 bytes)
     constexpr int CPR = BK / 8;     // 16-byte activation chunks per row of a K step
-    constexpr int WGM = BM >= 128 ? 2 : 1;                     // waves along M
+    constexpr int WGM = FAT ? BM / 64 : (BM >= 128 ? 2 : 1);   // waves along M
     constexpr int WGN = BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4);   // waves along N
     constexpr int NTHR = WGM * WGN * 64;
     constexpr int WM = BM / WGM;            // rows per wave
@@ -392,7 +392,7 @@ void launch_tiled(const TiledParams& p, unsigned grid, hipStream_t st) {
         return true;
     }();
     (void)lds_opt_in;
-    constexpr int NTHR = (BM >= 128 ? 2 : 1) * (BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4)) * 64;
+    constexpr int NTHR = (FAT ? BM / 64 : (BM >= 128 ? 2 : 1)) * (BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4)) * 64;
     if constexpr (FAT) {  // chip-filling grids only: never split (its split-K form would spill)
         hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false, BK, FAT>), dim3(grid), dim3(NTHR), lds, st, p);
     } else {
@@ -409,6 +409,7 @@ extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_tiled
 }
 #endif
 
+static const bool g_bm256 = [] { const char* e = getenv("AWQ_TILED_BM256"); return !(e && e[0] == '0'); }();  // tuning switch
 static const bool g_fat = [] { const char* e = getenv("AWQ_TILED_FAT"); return !(e && e[0] == '0'); }();  // tuning switch
 static const bool g_bk32 = [] { const char* e = getenv("AWQ_TILED_BK32"); return !(e && e[0] == '0'); }();  // tuning switch
 
@@ -434,14 +435,17 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
     p.g_magic = (uint32_t)((((uint64_t)1 << 32) / (uint64_t)a.g) + 1);
-    const int BM = a.M <= 32 ? 32 : (a.M <= 64 ? 64 : 128);  // smallest tile that holds the batch: less split-K exchange
+    int BM = a.M <= 32 ? 32 : (a.M <= 64 ? 64 : 128);  // smallest tile that holds the batch: less split-K exchange
+    // grids that fill the chip even with 256-row tiles take the 256 x 256 tile (eight 64 x 128 waves): the B decode
+    // and its LDS writes are amortised over twice the rows (851 -> 901 TF at M = 16384, 4096 x 11008)
+    if (g_bm256 && g_fat && g_bk32 && bn == 256 && splitk <= 1 && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 512) BM = 256;
     if (BM < 128) bn = 128;  // (32|64) x 256 with four tiles in flight drops to one wave per SIMD: 22 -> 27 us at M = 32
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + bn - 1) / bn;
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
     // 128 x 256 tiles of a grid that fills the chip by itself step K by 32: 53 KB of LDS instead of 102,
     // so two 8-wave blocks share a CU and cover each other's barriers and global round trips
-    const int BKsel = (BM == 128 && bn == 256 && splitk <= 1 && tiles >= 512 && g_bk32) ? 32 : BK_DEFAULT;
+    const int BKsel = (BM >= 128 && bn == 256 && splitk <= 1 && tiles >= 512 && g_bk32) ? 32 : BK_DEFAULT;
     const int T = a.K / BKsel;
     // split K until ~2 blocks per CU are in the grid (small M: few output tiles, long K loops)
     // r69 / r92 sweeps: every slice of a 128-row tile ships 64 KB through the exchange, so those split
@@ -467,6 +471,7 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     if (BM == 32) launch_tiled<32, 128>(p, grid, a.stream);
     else if (BM == 64) launch_tiled<64, 128>(p, grid, a.stream);
     else if (bn == 128) launch_tiled<128, 128>(p, grid, a.stream);
+    else if (BKsel == 32 && g_fat && BM == 256) launch_tiled<256, 256, 32, true>(p, grid, a.stream);
     else if (BKsel == 32 && g_fat) launch_tiled<128, 256, 32, true>(p, grid, a.stream);
     else if (BKsel == 32) launch_tiled<128, 256, 32>(p, grid, a.stream);
     else launch_tiled<128, 256>(p, grid, a.stream);

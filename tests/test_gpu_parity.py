@@ -222,11 +222,13 @@ def test_tiled_splitk_more_blocks_than_cus(ops):
     assert ops.workspace_is_clean(dq.device)
 
 
-def test_tiled_large_grid_k32_tile(ops):
-    """Grids of >= 512 tiles of 128 x 256 take the K-step-32 instantiation (two blocks per CU):
-    same numerics as every other tile -- exact fp16 weights, fp32 accumulation -- checked against
+@pytest.mark.parametrize("M", [2048, 4300])
+def test_tiled_large_grid_k32_tile(ops, M):
+    """Grids of >= 512 tiles take the K-step-32 instantiations -- 128 x 256 on four 64 x 128 waves
+    (M = 2048 here) or, when 256-row tiles still fill the chip, 256 x 256 on eight (M = 4300: ragged last
+    tile): same numerics as every other tile -- exact fp16 weights, fp32 accumulation -- checked against
     the dequantised-weights product and, row-exact, with one-hot activations."""
-    K, N, M = 384, 8192, 2048
+    K, N = 384, 8192
     qw, qz, s, x, bias = fullrange_case(K, N, 128, M, seed=5, realistic=True)
     dq, ds, dz = qw.cuda(), s.cuda(), qz.cuda()
     W = ops.dequantize_weights(dq, ds, dz)
