@@ -49,7 +49,7 @@ struct TiledParams {
 typedef short short4_t __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-constexpr int BK_DEFAULT = 64;  // K step of every tile except the large-M 128 x 256 one (32: two blocks fit a CU)
+constexpr int BK_DEFAULT = 64;  // K step of every tile except the four-wave 128 x 256 one (32: two blocks fit a CU)
 constexpr uint32_t OOB = 0x80000000u;
 
 AWQ_DEV rsrc_t mk_rsrc(const void* base, uint32_t bytes) {
@@ -409,9 +409,8 @@ extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_tiled
 }
 #endif
 
-static const bool g_bm256 = [] { const char* e = getenv("AWQ_TILED_BM256"); return !(e && e[0] == '0'); }();  // tuning switch
-static const bool g_fat = [] { const char* e = getenv("AWQ_TILED_FAT"); return !(e && e[0] == '0'); }();  // tuning switch
-static const bool g_bk32 = [] { const char* e = getenv("AWQ_TILED_BK32"); return !(e && e[0] == '0'); }();  // tuning switch
+// AWQ_TILED_FAT=0 falls back to the 8-wave 64 x 64-per-wave tiles everywhere (A/B measurements)
+static const bool g_fat = [] { const char* e = getenv("AWQ_TILED_FAT"); return !(e && e[0] == '0'); }();
 
 bool awq_gemm_tiled_supports(int M, int K, int N, int g) {
     if (M < 1) return false;
@@ -436,17 +435,20 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
     p.g_magic = (uint32_t)((((uint64_t)1 << 32) / (uint64_t)a.g) + 1);
     int BM = a.M <= 32 ? 32 : (a.M <= 64 ? 64 : 128);  // smallest tile that holds the batch: less split-K exchange
-    // grids that fill the chip even with 256-row tiles take the 256 x 256 tile (eight 64 x 128 waves): the B decode
-    // and its LDS writes are amortised over twice the rows (851 -> 901 TF at M = 16384, 4096 x 11008)
-    if (g_bm256 && g_fat && g_bk32 && bn == 256 && splitk <= 1 && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 512) BM = 256;
+    // Chip-filling grids (>= 512 blocks, no K split) run fat-wave tiles -- each wave owns 64 x 128, 12 LDS
+    // fragments feed 32 MFMAs: 256 x 256 / K step 64 on eight waves if 256-row tiles still fill the chip (the B
+    // decode amortised over twice the rows: 1 block of 139 KB per CU), else 128 x 256 / K step 32 on four waves
+    // (53 KB, two blocks per CU).  profiles/r01_gemm_tiled_vs_two_pass.txt: 739 -> 981-1020 TF at M = 16384.
+    int fat = 0;  // 0: regular tiles, 1: 128 x 256 x 32, 2: 256 x 256 x 64
+    if (g_fat && bn == 256 && splitk <= 1 && BM == 128) {
+        if ((int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 512) { fat = 2; BM = 256; }
+        else if ((int64_t)((a.M + 127) / 128) * ((a.N + 255) / 256) >= 512) fat = 1;
+    }
     if (BM < 128) bn = 128;  // (32|64) x 256 with four tiles in flight drops to one wave per SIMD: 22 -> 27 us at M = 32
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + bn - 1) / bn;
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
-    // 128 x 256 tiles of a grid that fills the chip by itself step K by 32: 53 KB of LDS instead of 102,
-    // so two 8-wave blocks share a CU and cover each other's barriers and global round trips
-    const int BKsel = (BM >= 128 && bn == 256 && splitk <= 1 && tiles >= 512 && g_bk32) ? 32 : BK_DEFAULT;
-    const int T = a.K / BKsel;
+    const int T = a.K / (fat == 1 ? 32 : BK_DEFAULT);
     // split K until ~2 blocks per CU are in the grid (small M: few output tiles, long K loops)
     // r69 / r92 sweeps: every slice of a 128-row tile ships 64 KB through the exchange, so those split
     // less (~320 blocks); nothing gains past 8 slices
@@ -471,9 +473,8 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk) {
     if (BM == 32) launch_tiled<32, 128>(p, grid, a.stream);
     else if (BM == 64) launch_tiled<64, 128>(p, grid, a.stream);
     else if (bn == 128) launch_tiled<128, 128>(p, grid, a.stream);
-    else if (BKsel == 32 && g_fat && BM == 256) launch_tiled<256, 256, 32, true>(p, grid, a.stream);
-    else if (BKsel == 32 && g_fat) launch_tiled<128, 256, 32, true>(p, grid, a.stream);
-    else if (BKsel == 32) launch_tiled<128, 256, 32>(p, grid, a.stream);
+    else if (fat == 2) launch_tiled<256, 256, 64, true>(p, grid, a.stream);
+    else if (fat == 1) launch_tiled<128, 256, 32, true>(p, grid, a.stream);
     else launch_tiled<128, 256>(p, grid, a.stream);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
