@@ -20,10 +20,10 @@ from ...utils.packing import pack_rows_int4, quantize_int_weights_kn
 
 # Dispatch by token count M (measured on MI355X, profiles/r01_gemm_tiled_vs_two_pass.txt and
 # profiles/r01_small_m.txt):  M <= 16 decode kernel (csrc/gemv_mfma.hip);  17..128 fused dequant +
-# MFMA GEMM with split-K (csrc/gemm_tiled.hip: 23-50 us vs 42-57 us for the two-pass route at
+# MFMA GEMM with split-K (csrc/gemm_tiled.hip: 21-37 us vs 42-53 us for the two-pass route at
 # 4096x11008);  above that dequant (bit-exact HIP kernel) + vendor fp16 GEMM -- the reference's own
-# large-batch route (awq/modules/linear/gemm.py:48-54, there from 1024 tokens), which hipBLASLt
-# still wins at MFMA-bound sizes (1125 vs 672 TF at M = 16384).  PREFILL_IMPL forces a route.
+# large-batch route (awq/modules/linear/gemm.py:48-54, there from 1024 tokens), which the vendor GEMM
+# still wins at MFMA-bound sizes (1170-1340 vs 980-1030 TF at M = 16384).  PREFILL_IMPL forces a route.
 TWO_PASS_MIN_TOKENS = 129
 PREFILL_IMPL = "auto"  # "auto" | "fused" | "two_pass"
 
