@@ -47,6 +47,24 @@ def test_oracle_rmsnorm_close_to_transformers_rmsnorm():
     assert (np.abs(got - want) <= 2 * ulp16(want)).all()  # HF rounds twice, the fused form once
 
 
+def test_oracle_attention_matches_torch_sdpa():
+    """The attention restatement against torch's own scaled_dot_product_attention (CPU, fp32) on a GQA
+    case with a cache longer than the sequence: the definition flash_attn_with_kvcache implements."""
+    from oracle import decoder_oracle
+    import torch.nn.functional as F
+
+    gen = torch.Generator().manual_seed(3)
+    B, Hq, Hkv, T, Tmax = 2, 8, 2, 37, 50
+    q = torch.randn((B, Hq, 128), generator=gen).half()
+    kc = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    vc = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    want = F.scaled_dot_product_attention(q.float()[:, :, None, :],
+                                          kc[:, :T].float().transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1),
+                                          vc[:, :T].float().transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1))[:, :, 0].numpy()
+    got = decoder_oracle.attention_reference(q.numpy(), kc.numpy(), vc.numpy(), T)
+    assert np.abs(got - want).max() <= 1e-5
+
+
 def test_input_id_and_cache_bookkeeping():
     from autoawq_amd.modules.fused.cache import WindowedCache
     from autoawq_amd.modules.fused.model import prepare_input_ids
