@@ -91,3 +91,43 @@ class RowParallelWQLinear(nn.Module):
             if dist.is_available() and dist.is_initialized():  # one process per GPU: RCCL over xGMI
                 dist.all_reduce(y, group=self.group)
         return y
+
+
+# ---- a whole decoder layer: which columns / rows each rank owns
+def llama_layer_bounds(n_heads, n_kv_heads, head_dim, intermediate, group_size, rank, world):
+    """Megatron-style split of one Llama-style decoder layer.  Attention is split by HEADS (a rank keeps
+    whole query heads and the whole KV heads they attend to, so GQA groups stay together: n_kv_heads must be
+    divisible by world or world by n_kv_heads is not supported here); the MLP by whole quantisation GROUPS
+    of the down projection's input rows, gate / up columns following the same bounds (uneven splits allowed:
+    86 groups over 8 ranks = 6 x 11 + 2 x 10).  Returns a dict of [start, stop) bounds."""
+    if n_kv_heads % world:
+        raise ValueError(f"n_kv_heads {n_kv_heads} must be divisible by the tensor-parallel degree {world}")
+    gq = n_heads // n_kv_heads
+    kv0, kvc = split_even_units(n_kv_heads, world)[rank]
+    q0, q1 = kv0 * gq * head_dim, (kv0 + kvc) * gq * head_dim
+    k0, k1 = kv0 * head_dim, (kv0 + kvc) * head_dim
+    if intermediate % group_size:
+        raise ValueError("intermediate size must be a multiple of the group size")
+    g0, gc = split_even_units(intermediate // group_size, world)[rank]
+    i0, i1 = g0 * group_size, (g0 + gc) * group_size
+    return {"q": (q0, q1), "kv": (k0, k1), "heads": (kv0 * gq, (kv0 + kvc) * gq), "kv_heads": (kv0, kv0 + kvc),
+            "mlp": (i0, i1)}
+
+
+def shard_llama_layer(q_proj, k_proj, v_proj, o_proj, gate_proj, up_proj, down_proj, n_heads, n_kv_heads, head_dim,
+                      rank, world, group=None):
+    """This rank's slices of the seven GEMM-layout Linears of a decoder layer: q / k / v / gate / up
+    column-parallel (plain WQLinear_GEMM modules, no communication), o / down row-parallel
+    (RowParallelWQLinear: one all-reduce each, bias on rank 0)."""
+    b = llama_layer_bounds(n_heads, n_kv_heads, head_dim, gate_proj.out_features, down_proj.group_size, rank, world)
+
+    def col(m, lo, hi):
+        return _module_from(*column_shard(m.qweight, m.qzeros, m.scales, m.bias, lo, hi), m.group_size)
+
+    return {
+        "q_proj": col(q_proj, *b["q"]), "k_proj": col(k_proj, *b["kv"]), "v_proj": col(v_proj, *b["kv"]),
+        "o_proj": RowParallelWQLinear(o_proj, rank, world, bounds=b["q"], group=group),
+        "gate_proj": col(gate_proj, *b["mlp"]), "up_proj": col(up_proj, *b["mlp"]),
+        "down_proj": RowParallelWQLinear(down_proj, rank, world, bounds=b["mlp"], group=group),
+        "bounds": b,
+    }

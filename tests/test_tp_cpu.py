@@ -80,3 +80,52 @@ def test_uneven_group_split_llama7b_down():
     assert [c for _, c in parts] == [11] * 6 + [10] * 2
     assert parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(7))
     assert parts[-1][0] + parts[-1][1] == 86
+
+
+def test_llama_layer_sharding_reproduces_the_unsharded_layer(oracle):
+    """Every rank's slices of a (GQA) decoder layer, with the arithmetic done by the CPU oracle: q / k / v
+    slices concatenate to the full projections, and the sums over ranks of the o_proj and down partial
+    products equal the unsharded ones -- including an uneven split of the MLP's quantisation groups
+    (7 groups over 4 ranks) and KV heads shared by query-head groups."""
+    from autoawq_amd import tp
+    from autoawq_amd.modules.linear import WQLinear_GEMM
+
+    H, heads, kv_heads, D, I, g, world = 512, 8, 4, 64, 896, 128, 4   # I / g = 7 groups: 2 + 2 + 2 + 1
+    gen = torch.Generator().manual_seed(21)
+    lim = 0x7FFFFFFF
+
+    def lin(K, N):
+        m = WQLinear_GEMM(4, g, K, N, False, "cpu")
+        m.qweight = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, generator=gen)
+        m.qzeros = torch.randint(-lim - 1, lim, (K // g, N // 8), dtype=torch.int32, generator=gen)
+        m.scales = (torch.rand((K // g, N), generator=gen) * 0.02 + 0.005).half()
+        return m
+
+    def mm(x, m):  # fp32 product of the oracle
+        y32, _ = oracle.linear_gemm(x.numpy(), m.qweight.numpy(), m.qzeros.numpy(), m.scales.numpy(), g, None)
+        return torch.from_numpy(y32.astype(np.float64))
+
+    q, k, v, o = lin(H, heads * D), lin(H, kv_heads * D), lin(H, kv_heads * D), lin(heads * D, H)
+    gate, up, down = lin(H, I), lin(H, I), lin(I, H)
+    x = torch.randn((3, H), generator=gen).half()
+    attn = torch.randn((3, heads * D), generator=gen).half()      # stands for the attention heads' output
+    act = torch.randn((3, I), generator=gen).half()               # stands for silu(gate) * up
+    full = {"q": mm(x, q), "k": mm(x, k), "v": mm(x, v), "o": mm(attn, o), "gate": mm(x, gate), "up": mm(x, up), "down": mm(act, down)}
+    parts = {n: [] for n in ("q", "k", "v", "gate", "up")}
+    o_sum, down_sum, seen_groups = 0, 0, []
+    for rank in range(world):
+        sh = tp.shard_llama_layer(q, k, v, o, gate, up, down, heads, kv_heads, D, rank, world)
+        b = sh["bounds"]
+        for n in ("q", "k", "v", "gate", "up"):
+            parts[n].append(mm(x, sh[n + "_proj"]))
+        assert (b["heads"][1] - b["heads"][0]) == (heads // kv_heads) * (b["kv_heads"][1] - b["kv_heads"][0])
+        o_sum = o_sum + mm(attn[:, b["q"][0]:b["q"][1]], sh["o_proj"].shard)
+        down_sum = down_sum + mm(act[:, b["mlp"][0]:b["mlp"][1]], sh["down_proj"].shard)
+        seen_groups.append((b["mlp"][1] - b["mlp"][0]) // g)
+    assert seen_groups == [2, 2, 2, 1]
+    for n in parts:
+        assert torch.equal(torch.cat(parts[n], dim=1), full[n]), n          # column slices: exact
+    for got, want in ((o_sum, full["o"]), (down_sum, full["down"])):
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())   # fp32 partial sums reordered
+    with pytest.raises(ValueError):
+        tp.llama_layer_bounds(heads, 3, D, I, g, 0, 2)
