@@ -177,3 +177,18 @@ def test_gemvfast_module_surface_and_packer_match_reference(name):
     assert np.array_equal(p.qzeros.numpy().view(np.uint16), g["fast_qzeros"].view(np.uint16))
     with pytest.raises(ValueError):
         p(torch.randn(4, K))  # 3-D input required (gemv_fast.py:190)
+
+
+def test_no_wide_buffer_store_with_sgpr_soffset():
+    """Regression guard for profiles/r01_store_hazard.txt: in the ISA hipcc generates for the two kernels
+    that use buffer stores, every 12/16-byte store keeps soffset = 0 (with an SGPR soffset the compiler
+    inserts no wait states before the data registers are rewritten and gfx950 reads them late)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    csrc = os.path.join(ROOT, "autoawq_amd", "csrc")
+    rc, res = mod.main([os.path.join(csrc, "gemm_tiled.hip"), os.path.join(csrc, "gemv_mfma.hip")])
+    assert rc == 0, res
+    assert sum(stores for _, stores, _ in res) > 100  # the audit really saw the exchange stores

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Static audit of the compiled kernels for the store-data hazard of profiles/r01_store_hazard.txt:
+a >8-byte MUBUF store whose soffset is an SGPR gets no wait states from the compiler before its data
+VGPRs are rewritten, and gfx950 reads them late.  The rule in the sources is "16-byte buffer stores keep
+soffset = 0"; this script checks the generated ISA.  Usage: tools/isa_audit.py [file.hip ...]
+Exit status 1 if any 12/16-byte buffer store uses an SGPR soffset."""
+import concurrent.futures as cf
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "autoawq_amd", "csrc")
+STORE = re.compile(r"\s*buffer_store_dwordx([34])\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\[\d+:\d+\],\s*(\S+)")
+
+
+def audit(src):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                               "-fno-slp-vectorize", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"), "-S",
+                               "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+        lines = open(out).read().splitlines()
+    stores, bad = 0, []
+    for i, l in enumerate(lines):
+        m = STORE.match(l)
+        if not m:
+            continue
+        stores += 1
+        if m.group(5).startswith("s"):
+            bad.append((i + 1, l.strip()))
+    return os.path.basename(src), stores, bad
+
+
+def main(files):
+    files = files or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(files))) as ex:
+        res = list(ex.map(audit, files))
+    rc = 0
+    for name, stores, bad in res:
+        print(f"{name:20s} 12/16-byte buffer stores: {stores:4d}   with an SGPR soffset: {len(bad)}")
+        for ln, text in bad[:10]:
+            print(f"    line {ln}: {text}")
+            rc = 1
+    return rc, res
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:])[0])
