@@ -217,3 +217,29 @@ def test_repack_on_load_runs_the_gemm_kernels():
     with torch.no_grad():
         logits = model(torch.from_numpy(g["input_ids"]).cuda()).logits.float().cpu().numpy()
     assert np.abs(logits - g["logits"]).max() <= 2e-2 * np.abs(g["logits"]).max()
+
+
+@pytest.mark.parametrize("K,N,g", [(256, 64, 128), (1408, 96, 128), (512, 40, 64), (384, 72, 32), (11008, 32, 128), (256, 256, 256)])
+def test_layout_conversion_cycle_on_random_tensors(K, N, g):
+    """gemm -> gemv -> gemv_fast -> gemm on random integers, zero points and scales (padded group counts:
+    86 groups -> 88 columns, g = 64 / 32 round the zeros width up to 2 / 4 words): every hop preserves the
+    logical (w, z, s) and the cycle returns the original buffers bit for bit."""
+    from autoawq_amd.utils.convert import convert_linear, pack_linear, unpack_linear
+
+    if N % 4 or K % 64:
+        pytest.skip("GEMVFast needs N % 4 == 0 and K % 64 == 0")
+    gen = torch.Generator().manual_seed(K + N + g)
+    G = K // g
+    w = torch.randint(0, 16, (N, K), dtype=torch.int32, generator=gen)
+    z = torch.randint(0, 16, (N, G), dtype=torch.int32, generator=gen)
+    s = (torch.rand((N, G), generator=gen) * 0.02 + 0.004).half()
+    bias = torch.randn(N, generator=gen).half()
+    a = pack_linear("gemm", w, z, s, bias, K, N, g)
+    b = convert_linear(a, "gemv")
+    c = convert_linear(b, "gemv_fast")
+    d = convert_linear(c, "gemm")
+    for m in (a, b, c, d):
+        w2, z2, s2, b2 = unpack_linear(m)
+        assert torch.equal(w2, w) and torch.equal(z2, z) and torch.equal(s2, s) and torch.equal(b2, bias)
+    assert torch.equal(d.qweight, a.qweight) and torch.equal(d.qzeros, a.qzeros) and torch.equal(d.scales, a.scales)
+    assert convert_linear(a, "gemm") is a
