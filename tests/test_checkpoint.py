@@ -226,8 +226,7 @@ def test_layout_conversion_cycle_on_random_tensors(K, N, g):
     logical (w, z, s) and the cycle returns the original buffers bit for bit."""
     from autoawq_amd.utils.convert import convert_linear, pack_linear, unpack_linear
 
-    if N % 4 or K % 64:
-        pytest.skip("GEMVFast needs N % 4 == 0 and K % 64 == 0")
+    assert N % 4 == 0 and K % 64 == 0, "GEMVFast needs N % 4 == 0 and K % 64 == 0"
     gen = torch.Generator().manual_seed(K + N + g)
     G = K // g
     w = torch.randint(0, 16, (N, K), dtype=torch.int32, generator=gen)

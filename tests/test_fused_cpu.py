@@ -34,3 +34,36 @@ def test_fused_topk_matches_reference_rocm_branch():
     tw, ti = torch.topk(p, 2, -1)
     assert torch.equal(ids.long(), ti) and torch.allclose(w, tw / tw.sum(-1, keepdim=True))
     assert torch.allclose(w.sum(-1), torch.ones(6))
+
+
+def test_fuse_linears_builds_the_mixtral_expert_stacks():
+    """awq/models/mixtral.py:131-151: per expert cat(w1, w3) on N, then torch.stack over the experts
+    (awq/utils/fused_utils.py:145-162).  Pure buffer plumbing, so it runs on CPU tensors."""
+    from autoawq_amd import WQLinear_GEMM
+    from autoawq_amd.utils.fused_utils import fuse_linears
+
+    E, K, I, g = 4, 256, 384, 128
+    gen = torch.Generator().manual_seed(3)
+
+    def rand(Kd, Nd):
+        m = WQLinear_GEMM(4, g, Kd, Nd, False, "cpu")
+        m.qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (Kd, Nd // 8), dtype=torch.int32, generator=gen)
+        m.qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (Kd // g, Nd // 8), dtype=torch.int32, generator=gen)
+        m.scales = torch.rand((Kd // g, Nd), generator=gen).half()
+        return m
+
+    experts = [(rand(K, I), rand(K, I), rand(I, K)) for _ in range(E)]
+    keep = [[(m.qweight.clone(), m.qzeros.clone(), m.scales.clone()) for m in e] for e in experts]
+    fused = [fuse_linears([w1, w3], "cpu") for w1, w3, _ in experts]
+    for f, (k1, k3, _) in zip(fused, keep):
+        assert f.out_features == 2 * I and f.in_features == K and f.bias is None
+        assert torch.equal(f.qweight, torch.cat([k1[0], k3[0]], 1))   # gate columns first, then up (moe.py:73-76)
+        assert torch.equal(f.qzeros, torch.cat([k1[1], k3[1]], 1)) and torch.equal(f.scales, torch.cat([k1[2], k3[2]], 1))
+    assert all(not hasattr(m, "qweight") for e in experts for m in e[:2])
+    ws = fuse_linears(fused, "cpu", dim=0, operation=torch.stack)
+    w2s = fuse_linears([e[2] for e in experts], "cpu", dim=0, operation=torch.stack)
+    assert ws.qweight.shape == (E, K, 2 * I // 8) and ws.qzeros.shape == (E, K // g, 2 * I // 8) and ws.scales.shape == (E, K // g, 2 * I)
+    assert w2s.qweight.shape == (E, I, K // 8) and w2s.qzeros.shape == (E, I // g, K // 8) and w2s.scales.shape == (E, I // g, K)
+    for e in range(E):
+        assert torch.equal(ws.qweight[e, :, I // 8:], keep[e][1][0]) and torch.equal(w2s.scales[e], keep[e][2][2])
+    assert set(ws.state_dict()) == {"qweight", "qzeros", "scales"}

@@ -106,6 +106,8 @@ def gemm_variants(ops):
         v[f"mfma_w{wpl}_s3_two_pass"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, splitk=3, two_pass=True)
         v[f"mfma_w{wpl}_v2_u4"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=wpl, waves=2, unit=4)
     v["mfma_w2_v8_u8"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, waves=8, unit=8)
+    v["mfma_w2_s8_u2"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, splitk=8, unit=2)  # the wide (gate|up) tuning branch, forced
+    v["mfma_w2_s16_v8"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, splitk=16, waves=8)  # the narrow-matrix default, forced
     v["mfma_w2_v4_u8_s64"] = ops.gemm_flags(ops.KERNEL_MFMA_GEMV, nlog=2, waves=4, unit=8, splitk=64)
     return v
 
@@ -134,12 +136,11 @@ def test_gemm_golden(ops, oracle, name):
 
 
 @pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (4096, 11008, 128), (11008, 4096, 128),
-                                   (4096, 12288, 128), (1024, 8192, 128), (512, 96, 64), (512, 1056, 32),
+                                   (4096, 12288, 128), (4096, 22016, 128),  # every Linear bench.py times, at every M
+                                   (1024, 8192, 128), (512, 96, 64), (512, 1056, 32),
                                    (256, 40, 128), (2048, 2048, 2048)])
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 13, 16])
 def test_gemm_vs_oracle_all_variants(ops, oracle, K, N, g, M):
-    if M > 1 and K * N > 4096 * 4096:
-        pytest.skip("large shapes are covered at M=1; keeps the oracle time bounded")
     qw, qz, s, x, bias = fullrange_case(K, N, g, M, seed=K * 3 + N + M, realistic=(N % 64 == 0))
     y32, _ = oracle.linear_gemm(x.numpy(), qw.numpy(), qz.numpy(), s.numpy(), g, bias.numpy())
     W = oracle.dequant_gemm(qw.numpy(), qz.numpy(), s.numpy(), g)
@@ -414,8 +415,6 @@ def test_gemv_layout_golden(ops, oracle, name):
                                    (512, 40, 32), (2048, 200, 2048), (256, 16, 128)])
 @pytest.mark.parametrize("M", [1, 2, 5, 8, 16, 33])
 def test_gemv_layout_vs_oracle(ops, oracle, K, N, g, M):
-    if M > 2 and K * N > 4096 * 4096:
-        pytest.skip("large shapes are covered at small M; keeps the oracle time bounded")
     qw, qz, sc, x = gemv_case(K, N, g, M, seed=K + 3 * N + M)
     W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)      # [K, N] fp16, reference rounding
     Wt = ops.dequantize_weights_gemv(qw.cuda(), sc.cuda(), qz.cuda(), g)
@@ -640,8 +639,6 @@ def test_gemvfast_layout_golden(ops, oracle, name):
 @pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (11008, 4096, 128), (1024, 80, 64), (512, 48, 32), (2048, 208, 2048)])
 @pytest.mark.parametrize("M", [1, 3, 8, 16, 20])
 def test_gemvfast_layout_vs_oracle(ops, oracle, K, N, g, M):
-    if M > 3 and K * N > 4096 * 4096:
-        pytest.skip("large shapes are covered at small M")
     qw, sc, qz, x = gemvfast_case(K, N, g, M, seed=K + N + M)
     W = oracle.dequant_gemvfast(qw.numpy(), sc.numpy(), qz.numpy(), g)
     Wt = ops.dequantize_weights_gemv_fast(qw.cuda(), sc.cuda(), qz.cuda(), g)
