@@ -25,6 +25,14 @@ class AwqGemmEx(ctypes.Structure):
                 ("ssq_in", c_void_p), ("ssq_in_tiles", c_int64), ("add_residual", c_void_p), ("ssq_out", c_void_p)]
 
 
+class AwqChainLink(ctypes.Structure):
+    """struct AwqChainLink of include/awq_hip.h (same field order)."""
+    _fields_ = [("qweight", c_void_p), ("scales", c_void_p), ("qzeros", c_void_p), ("bias", c_void_p),
+                ("K", c_int64), ("N", c_int64), ("group_size", c_int64), ("x", c_void_p), ("x_stride", c_int64),
+                ("x_from", c_int64), ("x_col0", c_int64), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("y", c_void_p), ("add_residual", c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/awq_hip.h declares
 # (tests/test_boundary.py cross-checks this table against the header and the .so).
 SIGNATURES = {
@@ -60,6 +68,13 @@ SIGNATURES = {
     "awq_gemv_fast_lds_bytes_c": (c_size_t, [c_int64, c_int64, c_int64]),
     "awq_dequantize_weights_gemv_fast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                                  c_void_p]),
+    "awq_chain_plan_bytes": (c_size_t, [c_int64]),
+    "awq_chain_grid_blocks": (c_int, []),
+    "awq_chain_build": (c_int, [ctypes.POINTER(AwqChainLink), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
+                                ctypes.POINTER(c_size_t)]),
+    "awq_chain_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "awq_chain_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "awq_chain_status": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
 }
 
 

@@ -39,6 +39,7 @@
 //   trips, ~3 us, per call: profiles/ notes.)
 #include "awq_device.h"
 #include "awq_internal.h"
+#include "awq_mfma_decode.h"
 
 namespace {
 
@@ -76,13 +77,6 @@ struct GemvMfmaParams {
     int64_t expert_qw_words, expert_z_words, expert_s_halfs;  // per-expert strides
 };
 
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-
-AWQ_DEV rsrc_t mk_rsrc(const void* base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
-
 template <int WPL>
 struct Words;
 template <>
@@ -105,26 +99,6 @@ AWQ_DEV uint32_t pair16(uint32_t q) {
     const uint32_t t = SH >= 0 ? (q << (SH >= 0 ? SH : 0)) : (q >> (SH < 0 ? -SH : 0));
     return and_or(t, 0x03C003C0u, 0x4C004C00u);
 }
-
-// The same pair with the nibbles left where they are: bits 0-3 / 16-19 under exponent 2^10
-// (0x6400: 1024 + w), bits 4-7 / 20-23 under exponent 2^6 (0x5400: 64 + w); nibbles 2, 3, 6, 7 come
-// from ONE shared `q >> 8`.  5 VALU ops per packed word instead of 8; the bias (1024 or 64) goes
-// through the group factorisation like the 16 above: y += s * (acc - (bias_J + z) * sum_x), every
-// product still exact in fp32.
-template <int J>
-AWQ_DEV uint32_t pairb(uint32_t q, uint32_t q8) {
-    if constexpr (J == 0) return and_or(q, 0x000F000Fu, 0x64006400u);
-    else if constexpr (J == 1) return and_or(q, 0x00F000F0u, 0x54005400u);
-    else if constexpr (J == 2) return and_or(q8, 0x000F000Fu, 0x64006400u);
-    else return and_or(q8, 0x00F000F0u, 0x54005400u);
-}
-
-AWQ_DEV float4_t mfma16(u32x4v a, u32x4v b, float4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0,
-                                                  0, 0);
-}
-
-constexpr uint32_t OOB = 0x80000000u;  // lane offset beyond every descriptor: returns 0, no traffic
 
 // Phase timestamps for tools/trace_gemv.py (debug build only: -DAWQ_GEMV_TRACE)
 #ifdef AWQ_GEMV_TRACE
