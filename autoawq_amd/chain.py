@@ -75,7 +75,7 @@ class DecodeChain:
                 import struct
 
                 n_int, grid = struct.unpack_from("<II", self._plan_host, 4)
-                self.trace = torch.zeros((n_int, grid, 4, 4), dtype=torch.int64, device=dev)
+                self.trace = torch.zeros((n_int, grid, 10, 4), dtype=torch.int64, device=dev)
                 struct.pack_into("<Q", self._plan_host, 40, self.trace.data_ptr())
             self.plan_dev = torch.frombuffer(bytearray(self._plan_host), dtype=torch.uint8).to(dev)
             torch.cuda.current_stream().synchronize()

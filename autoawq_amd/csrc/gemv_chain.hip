@@ -9,24 +9,28 @@
 // streams), but gfx9 ignores hipExtAnyOrderLaunch (profiles/r02_anyorder_probe.txt) and overlapping
 // dependent launches on several queues has no dispatch-order guarantee.  So the chain is ONE kernel:
 //
-//   * grid = 3 blocks of 4 waves per CU, all resident, NO s_barrier after start-up: every wave is an
-//     independent worker.  11 of 12 blocks compute, 1 of 12 is a service block (below);
-//   * a compute wave owns (column tile, <= 128 rows = one quantisation group at most) of each link: it
-//     REQUESTS those packed weights (and the group's zeros / scales) into registers, then waits for its
-//     slice of the activations, feeds the MFMAs (the selector-row scheme of gemv_mfma.hip) and at once
-//     requests its unit of the NEXT link, before it folds -- the weight stream of link l+1 runs under the
-//     exchange latency of link l;
-//   * split-K partials are the ONLY thing that travels between links: the waves of a block fold through
-//     LDS (arrival counter, last arriver sums) and store one slab of 8-byte {fp32 value, tag} granules
-//     with write-through (sc1) 16-byte stores.  A granule validates itself (tag = epoch << 10 | Linear
-//     id), so nothing is ever reset, re-armed, fenced or drained (MI355X_MICROARCH.md price list
-//     "handoff-1to1", Guideline 16 form R2).  The CONSUMER reduces: while it stages its activations a
-//     wave of link l+1 sums the K slices of exactly the 128 columns of link l it needs (fixed order:
-//     bitwise reproducible, identical in every consumer), applies link l's bias / residual and rounds to
-//     fp16 -- one fabric hop per link instead of reduce -> publish -> poll (the first build of this file
-//     did that: 6 us from the last slab to the published vector, profiles/r02_chain_trace_service_hop.txt);
-//   * service waves do the same reduction for the links whose fp16 result the caller wants in memory
-//     (the end of the chain; any link in tests) -- off the critical path;
+//   * grid = ONE block of 8 waves per CU (its register footprint admits no second one), all resident, NO
+//     s_barrier after start-up: six COMPUTE waves and two POLL waves, every wave an independent worker;
+//   * unit = (256-column tile, 128 rows = one quantisation group at most) = 16 KB of packed weights.  The
+//     units of a link are dealt to the compute waves of the whole grid in order (wave g takes unit g: K
+//     groups of one tile are neighbours, so the waves of a block fold together).  A compute wave REQUESTS
+//     a unit (and the group's zeros / scales) into registers and holds TWO: while link l waits for its
+//     activations the units of links l+1 and l+2 are in flight or landed -- the weight stream runs two
+//     links ahead of the dependency chain, HBM never waits for the exchange;
+//   * vector-memory loads return in order per wave: a wave that polls behind its own prefetch sees
+//     nothing before 16 KB of weights have landed (profiles/r02_chain_v2_reduce_on_read_trace.txt: the
+//     stream serialised with the exchange, 10 us per link).  So compute waves never poll memory: the
+//     POLL waves, which have nothing else in flight, gather the activations and hand them over in LDS;
+//   * split-K partials are the ONLY thing that travels between links: the waves of a block that share a
+//     tile fold through LDS (arrival counter, last arriver sums) and store one slab of 8-byte
+//     {fp32 value, tag} granules with write-through (sc1) 16-byte stores.  A granule validates itself
+//     (tag = epoch << 10 | Linear id): nothing is ever reset, re-armed, fenced or drained
+//     (MI355X_MICROARCH.md price list "handoff-1to1", Guideline 16 form R2).  The CONSUMER reduces: a poll
+//     wave of link l+1 sums the slabs of exactly the 128 columns of link l each of its compute waves needs
+//     (canonical order: bitwise reproducible, identical in every consumer), applies link l's bias /
+//     residual and rounds to fp16 -- one fabric hop per link instead of reduce -> publish -> poll;
+//   * the same poll waves materialise y for the links whose fp16 result the caller wants in memory (the end
+//     of the chain; any link in tests), one link late, when its slabs are known to be complete;
 //   * the epoch comes from per-XCD arrival counters (a / (G/8) + 1): no host state, no reset kernel,
 //     identical under hipGraph replay; every spin is bounded and raises ctrl->err / ctrl->abort.
 //
@@ -44,11 +48,18 @@
 
 namespace {
 
-constexpr int NCW = 4;                  // waves per block: four compute waves, or four service waves
-constexpr int NTHR = NCW * 64;
-constexpr int SVC_EVERY = 12;           // block b is a SERVICE block when b % 12 == 11: 64 of 768 blocks = 256 service waves
+constexpr int NCWB = 6;                 // compute waves per block (waves 1 .. 6; wave 0 is the loader)
+constexpr int NPW = 3;                  // poll waves per block (waves 7 .. 9)
+constexpr int UPP = NCWB / NPW;         // compute waves served by one poll wave
+constexpr int NWAVES = 1 + NCWB + NPW;
+constexpr int NTHR = NWAVES * 64;
+constexpr int SLOT_BYTES = 17 * 1024;   // ring slot: 16 KiB of packed weights (128 rows x 128 bytes) + 128 B zeros + 512 B scales
+__host__ __device__ constexpr int ring_slots(int M) { return M <= 2 ? 8 : 4; }  // what the fold / staging areas leave of 160 KiB
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gl_ptr_t;
 constexpr int CW = 256;                 // columns per tile (2 packed words per lane)
-constexpr int MAXSETS = 8;              // 16-row sets a wave holds in registers (128 rows = one group at most)
+constexpr int SETS = 8;                 // 16-row sets per unit: 128 rows
+constexpr int MAX_SUB = 16;             // sub-links a Linear may be cut into
 constexpr unsigned SPIN_LIMIT = 1u << 17;
 constexpr uint32_t CHAIN_MAGIC = 0x41575143u;  // "AWQC"
 
@@ -61,20 +72,23 @@ struct ChainLinkDev {  // one (sub-)link; 128 bytes
     const half_t* bias;       // this Linear's epilogue: applied by whoever reduces its slabs
     const half_t* add_res;    // [M, N] or null
     const half_t* x;          // external fp16 rows (link 0), else null
-    half_t* y;                // plain fp16 [M, N] (written by service waves) or null
+    half_t* y;                // plain fp16 [M, N] (written by poll waves) or null
     int K, N;                 // the Linear's full shape
     int tile0, tiles;         // column tiles of this sub-link: [tile0, tile0 + tiles)
-    int tiles_full;           // column tiles of the whole Linear (slab layout)
-    int S, nsets;             // K slices (blocks per tile), 16-row sets per wave
+    int R;                    // units per tile = K / 128
+    int units;                // units of this sub-link = tiles * R (<= compute waves of the grid)
+    int per;                  // tiles per sub-link of this Linear (the last one may hold fewer)
+    int smax;                 // slab slots per tile: blocks that can share a tile
     int xflags;               // XF_*
     int x_stride;             // external x: halves per row
     int x_col0;               // in-chain x: first column taken of the producer's output
     int prod;                 // in-chain x: index (in this array) of the producer Linear's FIRST sub-link
     int out_id;               // id of this Linear (tag of its slabs)
     int g;                    // group size (multiple of 128)
-    uint32_t slab_off;        // byte offset of this LINEAR's slabs in the exchange area: [S][tiles_full][M][64 quads][32 B]
-    int first_sub;            // 1 on the first sub-link of a Linear (service jobs are issued there, for the whole Linear)
-    int pad_[3];
+    uint32_t slab_off;        // byte offset of this LINEAR's slabs: [tiles_full][smax][M][64 quads][32 B]
+    int last_sub;             // 1 on the last sub-link of a Linear
+    int tiles_full;           // column tiles of the whole Linear
+    int pad_;
 };
 static_assert(sizeof(ChainLinkDev) == 128, "ChainLinkDev layout");
 
@@ -83,7 +97,7 @@ struct ChainHeader {  // 128 bytes, followed by the links
     uint64_t slab_bytes, unused_;
     uint32_t n_linears;
     uint32_t pad0_;
-    unsigned long long* trace;  // debug: [n_links][G][NCW][4] wall_clock64 stamps, or null
+    unsigned long long* trace;  // debug: [n_links][G][8 waves][4] wall_clock64 stamps, or null
     uint32_t pad_[20];
 };
 static_assert(sizeof(ChainHeader) == 128, "ChainHeader layout");
@@ -119,71 +133,143 @@ AWQ_DEV bool give_up(unsigned& spins, ChainCtrl* c, uint32_t code, int lane) {
     return false;
 }
 
-// The output of Linear P (first sub-link descriptor `P`), columns col .. col + 3 of batch row m, as the four
-// fp16 values every reader agrees on: sum of the S slabs in the canonical order (even slices ascending, odd
-// slices ascending, even + odd), + bias, rounded to fp16, + residual rounded again.  A wave calls this with
-// lanes (qd = lane & 31, sh = lane >> 5): `col` is the lane's quad, `sh` the slice parity it sums; lanes with
-// !active request nothing.  The result is valid on every active lane (both parities).
-// wave-uniform control flow; `spins` / give-up shared with the caller.
-AWQ_DEV half4_t reduce_quad(const ChainLinkDev& P, const unsigned char* slab_base, int M, int m, int col, int sh, bool active,
-                            uint32_t stag, unsigned& spins, ChainCtrl* ctrl, uint32_t code, int lane) {
-    const int S = P.S;
-    const rsrc_t slres = mk_rsrc(slab_base + P.slab_off, (uint32_t)S * (uint32_t)P.tiles_full * (uint32_t)M * 2048u);
-    const uint32_t qoff = active ? (uint32_t)(((col >> 8) * M + m) * 2048 + ((col & 255) >> 2) * 32) : OOB;
-    const uint32_t sstride = (uint32_t)P.tiles_full * (uint32_t)M * 2048u;
-    float4_t part = {0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < S; s0 += 8) {  // this lane: slices s0 + sh, +2, +4, +6
-        u32x4 v[4][2];
+// The same for a COMPUTE wave waiting on an LDS word: it must not touch vector memory (a load would return
+// behind the wave's own weight prefetch), so it watches the block's LDS abort word, which the poll waves
+// set when they give up, and a wall-clock bound (s_memrealtime is a scalar access).
+AWQ_DEV bool give_up_lds(unsigned& spins, const uint32_t* lds_abort, unsigned long long& t0, ChainCtrl* c, uint32_t code, int lane) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 63u) != 0) return false;
+    if (__hip_atomic_load(lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return true;
+    const unsigned long long now = wall_clock64();
+    if (t0 == 0) t0 = now;
+    if (now - t0 > 20000000ull) {  // 0.2 s at 100 MHz
+        if (lane == 0) {
+            __hip_atomic_fetch_or(&c->err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return true;
+    }
+    return false;
+}
+
+AWQ_DEV uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AWQ_DEV void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Where the slabs of columns [col, col + 128) of Linear P live: which tile, how many blocks contributed
+// (slots 0 .. S-1) and the byte offset of slot 0, row 0, quad 0 of the range.
+struct SlabRange {
+    int S;
+    uint32_t base;
+};
+AWQ_DEV SlabRange slab_range(const ChainLinkDev& P, int M, int col) {
+    const int tp = col >> 8;                 // tile of the Linear
+    const int tl = tp % P.per;               // tile within its sub-link: unit numbering restarts there
+    const int b_lo = (tl * P.R) / NCWB, b_hi = ((tl + 1) * P.R - 1) / NCWB;
+    SlabRange r;
+    r.S = b_hi - b_lo + 1;
+    r.base = P.slab_off + (uint32_t)(tp * P.smax * M) * 2048u + (uint32_t)((col & 255) >> 2) * 32u;
+    return r;
+}
+
+// The output of Linear P, NR ranges of 128 columns (col[r] .. col[r] + 127, each inside one tile) of batch row
+// m, as the fp16 values every reader agrees on: sum of the slabs in the canonical order (even slots ascending,
+// odd slots ascending, even + odd), + bias, rounded to fp16, + residual rounded again.  Lane (qd = lane & 31,
+// sh = lane >> 5) owns quad qd of every range and sums the slots of parity sh; the result is valid on both
+// lanes of a quad.  Ranges with !on[r] request nothing.  All ranges are read in the SAME round trips.
+template <int NR>
+AWQ_DEV void gather_ranges(const ChainLinkDev& P, rsrc_t slres, int M, int m, const int (&col)[NR], const bool (&on)[NR],
+                           uint32_t stag, half4_t (&out)[NR], unsigned& spins, ChainCtrl* ctrl, uint32_t code, int lane) {
+    const int qd = lane & 31, sh = lane >> 5;
+    const uint32_t sstride = (uint32_t)M * 2048u;
+    int S[NR];
+    uint32_t base[NR];
+    int smost = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const SlabRange sr = slab_range(P, M, col[r]);
+        S[r] = on[r] ? sr.S : 0;
+        base[r] = sr.base + (uint32_t)m * 2048u + (uint32_t)qd * 32u;
+        smost = max(smost, S[r]);
+    }
+    float4_t part[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) part[r] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < smost; s0 += 8) {  // this lane: slots s0 + sh, +2, +4, +6 of every range
+        u32x4 v[NR][4][2];
         for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = s0 + sh + 2 * u;
-                const uint32_t off = s < S ? qoff : OOB;
-                v[u][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, off, (uint32_t)s * sstride, 16 /* sc1 */));
-                v[u][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, off == OOB ? OOB : off + 16u, (uint32_t)s * sstride, 16));
-            }
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (active && s0 + sh + 2 * u < S)
-                    ok &= v[u][0][1] == stag && v[u][0][3] == stag && v[u][1][1] == stag && v[u][1][3] == stag;
+                for (int u = 0; u < 4; ++u) {
+                    const int s = s0 + sh + 2 * u;
+                    const uint32_t off = s < S[r] ? base[r] + (uint32_t)s * sstride : OOB;
+                    v[r][u][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, off, 0, 16 /* sc1 */));
+                    v[r][u][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, off == OOB ? OOB : off + 16u, 0, 16));
+                }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (s0 + sh + 2 * u < S[r])
+                        ok &= v[r][u][0][1] == stag && v[r][u][0][3] == stag && v[r][u][1][1] == stag && v[r][u][1][3] == stag;
             if (__all(ok)) break;
             if (give_up(spins, ctrl, code, lane)) break;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)  // slices past S were requested out of range: zeros
-            part += float4_t{u2f(v[u][0][0]), u2f(v[u][0][2]), u2f(v[u][1][0]), u2f(v[u][1][2])};
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)  // slots past S were requested out of range: zeros
+                part[r] += float4_t{u2f(v[r][u][0][0]), u2f(v[r][u][0][2]), u2f(v[r][u][1][0]), u2f(v[r][u][1][2])};
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) part[e] = part[e] + __shfl_xor(part[e], 32, 64);  // even + odd slices: the same on both lanes
-    if (P.bias && active) {
-        const half4_t b4 = *reinterpret_cast<const half4_t*>(P.bias + col);
-        part += float4_t{(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
-    }
-    half4_t o = {(half_t)part[0], (half_t)part[1], (half_t)part[2], (half_t)part[3]};
-    if (P.add_res && active) {  // fp16(fp16(projection) + residual): the two roundings torch makes
-        const half4_t r4 = *reinterpret_cast<const half4_t*>(P.add_res + (size_t)m * P.N + col);
+    for (int r = 0; r < NR; ++r) {
+        float4_t p = part[r];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)o[e] + (float)r4[e]);
+        for (int e = 0; e < 4; ++e) p[e] = p[e] + __shfl_xor(p[e], 32, 64);  // even + odd slots: the same on both lanes
+        const int c = col[r] + 4 * qd;
+        const bool live = on[r] && c < P.N;  // N % 8 == 0: a quad is all in or all out
+        if (P.bias && live) {
+            const half4_t b4 = *reinterpret_cast<const half4_t*>(P.bias + c);
+            p += float4_t{(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+        }
+        half4_t o = {(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3]};
+        if (P.add_res && live) {  // fp16(fp16(projection) + residual): the two roundings torch makes
+            const half4_t r4 = *reinterpret_cast<const half4_t*>(P.add_res + (size_t)m * P.N + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)o[e] + (float)r4[e]);
+        }
+        out[r] = o;
     }
-    return o;
 }
 
-// Light wait: until one granule of each of the S slabs holding columns [col, col + ncols) of batch rows < M has
-// landed.  Lane i < S probes slice i (its first granule of the range), so a waiting wave costs S x 8 bytes per
-// turn instead of re-reading its whole slice of every slab.
-AWQ_DEV void probe_slabs(const ChainLinkDev& P, const unsigned char* slab_base, int M, int col, uint32_t stag, unsigned& spins,
-                         ChainCtrl* ctrl, uint32_t code, int lane) {
-    const int S = P.S;
-    const rsrc_t slres = mk_rsrc(slab_base + P.slab_off, (uint32_t)S * (uint32_t)P.tiles_full * (uint32_t)M * 2048u);
-    const uint32_t sstride = (uint32_t)P.tiles_full * (uint32_t)M * 2048u;
-    const bool probing = lane < S;
-    const uint32_t off = probing ? (uint32_t)lane * sstride + (uint32_t)(((col >> 8) * M + (M - 1)) * 2048 + ((col & 255) >> 2) * 32) : OOB;
-    for (;;) {
-        const u32x2 pv = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(slres, off, 0, 16 /* sc1 */));
-        if (__all(!probing || pv[1] == stag)) break;
-        __builtin_amdgcn_s_sleep(4);
-        if (give_up(spins, ctrl, code, lane)) break;
+// Light wait: until one granule (first quad, last batch row) of every slab of every range has landed.  Lane
+// (r = lane >> 4, i = lane & 15) probes slots i, i + 16, ... of range r: a waiting wave costs a few 8-byte
+// loads per turn instead of re-reading every slab.
+template <int NR>
+AWQ_DEV void probe_ranges(const ChainLinkDev& P, rsrc_t slres, int M, const int (&col)[NR], const bool (&on)[NR], uint32_t stag,
+                          unsigned& spins, ChainCtrl* ctrl, uint32_t code, int lane) {
+    static_assert(NR <= 4, "16 lanes per range");
+    const int pr = lane >> 4, pi = lane & 15;
+    int S = 0;
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+        if (r == pr && on[r]) {
+            const SlabRange sr = slab_range(P, M, col[r]);
+            S = sr.S;
+            base = sr.base + (uint32_t)(M - 1) * 2048u;
+        }
+    const uint32_t sstride = (uint32_t)M * 2048u;
+    for (int s0 = 0; __any(s0 < S); s0 += 16) {
+        const bool probing = s0 + pi < S;
+        const uint32_t off = probing ? base + (uint32_t)(s0 + pi) * sstride : OOB;
+        for (;;) {
+            const u32x2 pv = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(slres, off, 0, 16 /* sc1 */));
+            if (__all(!probing || pv[1] == stag)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (give_up(spins, ctrl, code, lane)) break;
+        }
     }
 }
 
@@ -192,208 +278,312 @@ template <int NREG>
 __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* __restrict__ plan, unsigned char* __restrict__ ws) {
     constexpr int CWP = CW + 8;  // LDS row pitch of the fold area (floats)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS: red[NCW][M][CWP] fp32 | xs[NCW][M + 1][128] fp16 | control words
+    // dynamic LDS: ring[NS][SLOT_BYTES] | red[NCWB][M][CWP] fp32 | xs[NCWB][M + 1][128] fp16 | control words
     const int M = (int)plan->M;
     const int G = (int)plan->G;
     const int n_links = (int)plan->n_links;
+    const int NS = ring_slots(M);
     const ChainLinkDev* __restrict__ links = reinterpret_cast<const ChainLinkDev*>(plan + 1);
     ChainCtrl* ctrl = reinterpret_cast<ChainCtrl*>(ws);
-    const unsigned char* slab_base = ws + CTRL_BYTES;
+    const rsrc_t slres = mk_rsrc(ws + CTRL_BYTES, (uint32_t)plan->slab_bytes);
 
-    float* red = reinterpret_cast<float*>(smem);
-    half_t* xs_all = reinterpret_cast<half_t*>(smem + (size_t)NCW * M * CWP * 4);
-    uint32_t* lds_ctl = reinterpret_cast<uint32_t*>(smem + (size_t)NCW * M * CWP * 4 + (size_t)NCW * (M + 1) * 128 * 2);
+    unsigned char* const ring = smem;
+    float* red = reinterpret_cast<float*>(smem + (size_t)NS * SLOT_BYTES);
+    half_t* xs_all = reinterpret_cast<half_t*>(reinterpret_cast<unsigned char*>(red) + (size_t)NCWB * M * CWP * 4);
+    uint32_t* lds_ctl = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(xs_all) + (size_t)NCWB * (M + 1) * 128 * 2);
+    uint32_t* const fold_cnt = lds_ctl + 1;   // [2] arrivals per fold group (monotonic)
+    uint32_t* const fold_done = lds_ctl + 3;  // [2] folds completed per group (monotonic)
+    uint32_t* const lds_abort = lds_ctl + 5;  // set by a wave that gave up: everybody in the block stops waiting
+    uint32_t* const xflag = lds_ctl + 8;      // [NCWB] link index + 1 whose activations are staged for the wave
+    uint32_t* const xdone = lds_ctl + 16;     // [NCWB] link index + 1 the wave has finished reading
+    uint32_t* const ready = lds_ctl + 24;     // [NS] fill index + 1 that has landed in the slot
+    uint32_t* const freed = lds_ctl + 32;     // [NS] fill index + 1 whose reader is done with the slot
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
+    if (tid < 64) lds_ctl[tid] = 0u;
+    __syncthreads();
     if (tid == 0) {
         const u64 a = __hip_atomic_fetch_add(&ctrl->arrive[b & 7], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lds_ctl[0] = (uint32_t)(a / (u64)(G >> 3)) + 1u;  // epoch of this launch
-        lds_ctl[1] = 0u;                                  // fold arrivals (monotonic)
-        lds_ctl[2] = 0u;                                  // folds completed
     }
-    for (int i = tid; i < NCW * 128; i += NTHR) xs_all[((i >> 7) * (M + 1) + M) * 128 + (i & 127)] = (half_t)0.f;  // the all-zero row M
+    for (int i = tid; i < NCWB * 128; i += NTHR) xs_all[((i >> 7) * (M + 1) + M) * 128 + (i & 127)] = (half_t)0.f;  // the all-zero row M
     __syncthreads();
     const uint32_t epoch = lds_ctl[0];
     const uint32_t tag_hi = epoch << 10;
     unsigned long long* const trace = plan->trace;
     auto stamp = [&](int l, int slot) {  // phase timeline for tools/chain_probe.py --trace (off unless the plan carries a buffer)
-        if (trace && lane == 0) trace[(((size_t)l * G + b) * NCW + wave) * 4 + slot] = wall_clock64();
+        if (trace && lane == 0) trace[(((size_t)l * G + b) * NWAVES + wave) * 4 + slot] = wall_clock64();
     };
+    auto units_here = [&](const ChainLinkDev& L) { return max(0, min(NCWB, L.units - b * NCWB)); };  // units of a link held by this block
 
-    // Roles by block: 256-thread blocks spread evenly over the four SIMDs whatever the dispatcher's starting
-    // SIMD is (a 5-wave block does not: two such blocks may need 4 waves on one SIMD and then only one fits)
-    const bool service = b % SVC_EVERY == SVC_EVERY - 1;
-    const int NSW = (G / SVC_EVERY) * NCW;  // service waves
-    if (service) {
-        // ================================================================ service waves: materialise y where asked
-        const int sw = (b / SVC_EVERY) * NCW + wave;  // this wave's index among the service waves
-        const int qd = lane & 31, sh = lane >> 5;
-        for (int l = 0; l < n_links; ++l) {
+    if (wave == 0) {
+        // ================================================================ loader wave: HBM -> LDS ring, paced
+        // The ONLY bulk reader of the CU.  It runs ahead of the dependency chain as far as the ring has room
+        // (the weights depend on nothing) but keeps at most three fills (51 KB) in flight, so that the CU's
+        // memory pipe never holds more than that in front of a poll wave's request.  All of its LDS accesses
+        // are inline asm: hipcc would drain the DMA queue (vmcnt(0)) in front of any LDS access it can see.
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic segment
+        const uint32_t ready_a = lds0 + (uint32_t)(reinterpret_cast<unsigned char*>(ready) - smem);
+        const uint32_t freed_a = lds0 + (uint32_t)(reinterpret_cast<unsigned char*>(freed) - smem);
+        const uint32_t abort_a = lds0 + (uint32_t)(reinterpret_cast<unsigned char*>(lds_abort) - smem);
+        auto lds_read = [](uint32_t addr) -> uint32_t {
+            uint32_t v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+            return v;
+        };
+        auto lds_write = [](uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); };
+        const int rr = lane >> 3, cc = lane & 7;
+        uint32_t f = 0;  // fill sequence number of this block
+        bool dead = false;
+        for (int l = 0; l < n_links && !dead; ++l) {
             const ChainLinkDev& L = links[l];
-            if (!L.y || !L.first_sub) continue;
-            const int njobs = L.tiles_full * M * 2;  // (tile, row, half tile): 32 quads x 2 slice parities per wave
-            const uint32_t stag = tag_hi | (uint32_t)(L.out_id + 1);
-            if (sw < njobs) stamp(l, 0);
-            for (int jb = sw; jb < njobs; jb += NSW) {
-                const int tl = jb / (2 * M), m = (jb >> 1) % M, hf = jb & 1;
-                const int col = tl * CW + hf * 128 + qd * 4;
-                const bool active = col < L.N;  // N % 8 == 0: a quad is all in or all out
-                unsigned spins = 0;
-                probe_slabs(L, slab_base, M, tl * CW + hf * 128, stag, spins, ctrl, 2u, lane);
-                stamp(l, 1);
-                const half4_t o = reduce_quad(L, slab_base, M, m, col, sh, active, stag, spins, ctrl, 2u, lane);
-                if (sh == 0 && active) *reinterpret_cast<u32x2*>(L.y + (size_t)m * L.N + col) = __builtin_bit_cast(u32x2, o);
-                stamp(l, 2);
+            const int nblk = units_here(L);
+            const uint32_t row_bytes = (uint32_t)(L.N >> 3) * 4u;
+            for (int i = 0; i < nblk; ++i, ++f) {
+                const int slot = (int)(f & (uint32_t)(NS - 1));
+                if (f >= (uint32_t)NS) {  // the slot's previous tenant has been read
+                    unsigned spins = 0;
+                    unsigned long long t0 = 0;
+                    while (lds_read(freed_a + 4u * slot) != f - (uint32_t)NS + 1u) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((++spins & 63u) == 0) {
+                            const unsigned long long now = wall_clock64();
+                            if (t0 == 0) t0 = now;
+                            if (lds_read(abort_a) || now - t0 > 20000000ull) { dead = true; break; }
+                        }
+                    }
+                    if (dead) break;
+                }
+                if (i == 0) stamp(l, 0);
+                const int u = b * NCWB + i;
+                const int tile = L.tile0 + u / L.R, row0 = (u % L.R) * 128;
+                unsigned char* const dst = ring + (size_t)slot * SLOT_BYTES;
+                // 16 x 1 KiB: instruction k moves rows row0 + 8k .. + 7, 128 bytes each (lane = row rr, 16-byte chunk cc)
+                const uint32_t coff = min((uint32_t)tile * 128u + (uint32_t)cc * 16u, row_bytes - 16u);  // ragged last tile: stay inside the row
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(L.qweight) + (size_t)(row0 + rr) * row_bytes + coff;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    __builtin_amdgcn_global_load_lds((gl_ptr_t)(src + (size_t)k * 8u * row_bytes), (lds_ptr_t)(dst + k * 1024), 16, 0, 2 /* nt */);
+                {   // the group's zeros (lanes 0-7: 128 bytes) and scales (lanes 8-39: 512 bytes) behind the weights
+                    const int grp = row0 / L.g;
+                    const unsigned char* zs;
+                    if (lane < 8) zs = reinterpret_cast<const unsigned char*>(L.qzeros) + (size_t)grp * row_bytes +
+                                       min((uint32_t)tile * 128u + (uint32_t)lane * 16u, row_bytes - 16u);
+                    else zs = reinterpret_cast<const unsigned char*>(L.scales) + ((size_t)grp * L.N) * 2u +
+                              min((uint32_t)tile * 512u + (uint32_t)(lane - 8) * 16u, (uint32_t)L.N * 2u - 16u);
+                    if (lane < 40) __builtin_amdgcn_global_load_lds((gl_ptr_t)zs, (lds_ptr_t)(dst + 16384), 16, 0, 0);
+                }
+                // fills land in order: everything but the two newest (2 x 17 instructions) is in LDS
+                asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+                if (f >= 2u) lds_write(ready_a + 4u * ((f - 2u) & (uint32_t)(NS - 1)), f - 1u);
             }
         }
+        asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+        if (f >= 2u) lds_write(ready_a + 4u * ((f - 2u) & (uint32_t)(NS - 1)), f - 1u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (f >= 1u) lds_write(ready_a + 4u * ((f - 1u) & (uint32_t)(NS - 1)), f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+    }
+
+    if (wave > NCWB) {
+        // ================================================================ poll waves: activations in, results out
+        const int pw = wave - NCWB - 1;
+        const int qd = lane & 31, sh = lane >> 5;
+        const int npoll = G * NPW, pidx = b * NPW + pw;
+        auto materialise = [&](int l) {  // y of the Linear whose last sub-link is l (its slabs are complete or about to be)
+            const ChainLinkDev& L = links[l];
+            const int njobs = L.tiles_full * M * 2;  // (tile, batch row, half tile)
+            const uint32_t stag = tag_hi | (uint32_t)(L.out_id + 1);
+            for (int jb = pidx; jb < njobs; jb += npoll) {
+                const int tl = jb / (2 * M), m = (jb >> 1) % M, hf = jb & 1;
+                const int col[1] = {tl * CW + hf * 128};
+                const bool on[1] = {true};
+                half4_t o[1];
+                unsigned spins = 0;
+                probe_ranges<1>(L, slres, M, col, on, stag, spins, ctrl, 2u, lane);
+                gather_ranges<1>(L, slres, M, m, col, on, stag, o, spins, ctrl, 2u, lane);
+                const int c = col[0] + 4 * qd;
+                if (sh == 0 && c < L.N) *reinterpret_cast<u32x2*>(L.y + (size_t)m * L.N + c) = __builtin_bit_cast(u32x2, o[0]);
+            }
+        };
+        for (int l = 0; l < n_links; ++l) {
+            const ChainLinkDev& L = links[l];
+            if ((l & 3) == 0 && ld_abort(ctrl)) lds_st(lds_abort, 1u);  // somebody gave up: release this block's other waves
+            const int nblk = units_here(L);
+            int kg[UPP];
+            bool has[UPP];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < UPP; ++i) {
+                has[i] = pw * UPP + i < nblk;
+                kg[i] = (b * NCWB + pw * UPP + i) % L.R;
+                any |= has[i];
+            }
+            if (any) {
+                stamp(l, 0);
+                unsigned spins = 0;
+#pragma unroll
+                for (int i = 0; i < UPP; ++i)  // the wave has finished reading what was staged for its previous link
+                    while (has[i] && lds_ld(&xdone[pw * UPP + i]) != (uint32_t)l)
+                        if (give_up(spins, ctrl, 8u, lane)) break;
+                if (L.xflags & XF_SLABS) {
+                    const ChainLinkDev& P = links[L.prod];
+                    const uint32_t stag = tag_hi | (uint32_t)(P.out_id + 1);
+                    const bool gated = (L.xflags & XF_GATED) != 0;
+                    int col[UPP], colu[UPP];
+#pragma unroll
+                    for (int i = 0; i < UPP; ++i) {
+                        col[i] = L.x_col0 + kg[i] * 128;
+                        colu[i] = col[i] + L.K;
+                    }
+                    probe_ranges<UPP>(P, slres, M, col, has, stag, spins, ctrl, 1u, lane);
+                    if (gated) probe_ranges<UPP>(P, slres, M, colu, has, stag, spins, ctrl, 1u, lane);
+                    stamp(l, 1);
+                    for (int m = 0; m < M; ++m) {
+                        half4_t xv[UPP];
+                        gather_ranges<UPP>(P, slres, M, m, col, has, stag, xv, spins, ctrl, 1u, lane);
+                        if (gated) {  // silu(gate) * up in fp32, one rounding: == awq_silu_and_mul_kernel
+                            half4_t up[UPP];
+                            gather_ranges<UPP>(P, slres, M, m, colu, has, stag, up, spins, ctrl, 1u, lane);
+#pragma unroll
+                            for (int i = 0; i < UPP; ++i)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float gx = (float)xv[i][e];
+                                    xv[i][e] = (half_t)((gx / (1.0f + expf(-gx))) * (float)up[i][e]);
+                                }
+                        }
+#pragma unroll
+                        for (int i = 0; i < UPP; ++i)
+                            if (has[i] && sh == 0)
+                                *reinterpret_cast<u32x2*>(xs_all + ((size_t)(pw * UPP + i) * (M + 1) + m) * 128 + 4 * qd) =
+                                    __builtin_bit_cast(u32x2, xv[i]);
+                    }
+                } else {
+                    stamp(l, 1);
+#pragma unroll
+                    for (int i = 0; i < UPP; ++i)
+                        for (int m = 0; m < M; ++m)
+                            if (has[i])
+                                *reinterpret_cast<uint32_t*>(xs_all + ((size_t)(pw * UPP + i) * (M + 1) + m) * 128 + 2 * lane) =
+                                    *reinterpret_cast<const uint32_t*>(L.x + (size_t)m * L.x_stride + kg[i] * 128 + 2 * lane);
+                }
+                if (spins >= 64u && ld_abort(ctrl)) lds_st(lds_abort, 1u);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+                for (int i = 0; i < UPP; ++i)
+                    if (has[i] && lane == 0) lds_st(&xflag[pw * UPP + i], (uint32_t)(l + 1));
+                stamp(l, 2);
+            }
+            // the Linear that ended one link ago: every one of its slabs has been consumed by now or is on its way
+            if (l > 0 && links[l - 1].last_sub && links[l - 1].y) materialise(l - 1);
+        }
+        if (links[n_links - 1].y) materialise(n_links - 1);
         return;
     }
 
     // ==================================================================== compute waves
-    const int cw = wave;
-    const int cb = b - b / SVC_EVERY;  // this block's index among the compute blocks
+    const int cw = wave - 1;
     const int j = lane & 15, kb = lane >> 4;
     half_t* xs = xs_all + (size_t)cw * (M + 1) * 128;  // this wave's activation rows [M + 1][128]
     float* myred = red + (size_t)cw * M * CWP;
-
-    struct Unit {  // what a wave holds in registers for one link
-        u32x2 q[MAXSETS][4];
-        u32x2 z;
-        u32x4 s[2];
-    };
-    auto request = [&](int l, Unit& U) {  // P0: issue every load of link l's unit (nothing is waited for)
-        const ChainLinkDev& L = links[l];
-        const int tiles = L.tiles, nsets = L.nsets;
-        const bool has = cb < tiles * L.S;
-        const int tile = L.tile0 + cb % tiles, slice = cb / tiles;
-        const int row0 = (slice * NCW + cw) * 16 * nsets;
-        const int NW = L.N >> 3;
-        const uint32_t row_bytes = (uint32_t)NW * 4u;
-        const int colw = (tile * 16 + j) * 2;
-        const bool act = has && row0 < L.K && colw < NW;
-        const rsrc_t wres = mk_rsrc(L.qweight, (uint32_t)L.K * row_bytes);
-        const uint32_t voff = act ? (uint32_t)colw * 4u + (uint32_t)(4 * kb) * row_bytes : OOB;
-        uint32_t soff = (uint32_t)row0 * row_bytes;
-#pragma unroll
-        for (int t = 0; t < MAXSETS; ++t) {
-            const uint32_t vo = t < nsets ? voff : OOB;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                U.q[t][r] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wres, vo, soff, 2 /* nt */));
-                soff += row_bytes;
-            }
-            soff += 12u * row_bytes;
-        }
-        const int grp = row0 / L.g;
-        const rsrc_t zres = mk_rsrc(L.qzeros, (uint32_t)(L.K / L.g) * row_bytes);
-        const rsrc_t sres = mk_rsrc(L.scales, (uint32_t)(L.K / L.g) * (uint32_t)L.N * 2u);
-        const uint32_t zo = act ? (uint32_t)grp * row_bytes + (uint32_t)colw * 4u : OOB;
-        const uint32_t so = act ? ((uint32_t)grp * (uint32_t)L.N + (uint32_t)colw * 8u) * 2u : OOB;
-        U.z = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(zres, zo, 0, 0));
-        U.s[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sres, so, 0, 0));
-        U.s[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sres, so == OOB ? OOB : so + 16u, 0, 0));
-    };
 
     const uint32_t sel_lo = (j & 1) ? 0x01000C0Cu : 0x0C0C0100u;  // low half of a dword -> slot (j & 1)
     const uint32_t sel_hi = (j & 1) ? 0x03020C0Cu : 0x0C0C0302u;  // high half
     const u32x4v ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
     const int arow = min(j >> 1, M);  // A row of this lane = batch row j >> 1 (parity j & 1); rows >= M read zeros
 
-    uint32_t nfold = 0;  // folds this block has taken part in
-    Unit U;
-    request(0, U);
+    // bookkeeping, identical in every wave of the block (pure arithmetic on the link table)
+    uint32_t fbase = 0u;            // fills of earlier links
+    uint32_t arr0 = 0u, arr1 = 0u;  // arrivals of earlier folds, per group
+    uint32_t fin0 = 0u, fin1 = 0u;  // completed folds of earlier links, per group
+    int my_pg = -1;                 // group and completion count of the last fold this wave wrote rows for
+    uint32_t my_pf = 0u;
+
     for (int l = 0; l < n_links; ++l) {
         const ChainLinkDev& L = links[l];
-        const int tiles = L.tiles, nsets = L.nsets, S = L.S;
-        const bool has = cb < tiles * S;
-        const int tl = L.tile0 + cb % tiles, slice = cb / tiles;  // tile of the whole Linear
-        const int row0 = (slice * NCW + cw) * 16 * nsets;
-        const int nrows = 16 * nsets;
+        const int R = L.R;
+        const int nblk = units_here(L);
+        const bool has = cw < nblk;
+        const int u0 = b * NCWB;
+        const int tloc = (u0 + cw) / R;  // tile within the sub-link
+        // the block's units u0 .. u0 + nblk - 1 touch at most two tiles (R >= NCWB): group 0 = the first unit's tile
+        const int t_first = u0 / R;
+        const int n0 = min(nblk, (t_first + 1) * R - u0);
+        const int n1 = nblk - n0;
+        const int grp = (has && tloc != t_first) ? 1 : 0;
         float yv[8][NREG];
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
             for (int r = 0; r < NREG; ++r) yv[c][r] = 0.f;
 
-        if (has) stamp(l, 0);
-        if (has && row0 < L.K) {
-            // ---- P1: this wave's slice of the activations -> LDS rows xs[m][0 .. nrows)
-            if (L.xflags & XF_SLABS) {
-                // reduce the producer's K slices for exactly the columns this wave needs: quad qd = lane & 31 of the
-                // slice, slice parity sh = lane >> 5
-                const ChainLinkDev& P = links[L.prod];
-                const uint32_t stag = tag_hi | (uint32_t)(P.out_id + 1);
-                const bool gated = (L.xflags & XF_GATED) != 0;
-                const int qd = lane & 31, sh = lane >> 5;
-                const bool active = 4 * qd < nrows;
-                const int col = L.x_col0 + row0 + 4 * qd;
+        if (has) {
+            stamp(l, 0);
+            const uint32_t f = fbase + (uint32_t)cw;
+            const int slot = (int)(f & (uint32_t)(NS - 1));
+            const unsigned char* const wb = ring + (size_t)slot * SLOT_BYTES;
+            {   // the unit's weights have landed in the ring, the poll wave has staged its 128 activations per batch row
                 unsigned spins = 0;
-                probe_slabs(P, slab_base, M, L.x_col0 + row0, stag, spins, ctrl, 1u, lane);
-                if (gated) probe_slabs(P, slab_base, M, L.x_col0 + L.K + row0, stag, spins, ctrl, 1u, lane);
-                for (int m = 0; m < M; ++m) {
-                    half4_t xv = reduce_quad(P, slab_base, M, m, col, sh, active, stag, spins, ctrl, 1u, lane);
-                    if (gated) {  // silu(gate) * up in fp32, one rounding: == awq_silu_and_mul_kernel
-                        const half4_t up = reduce_quad(P, slab_base, M, m, col + L.K, sh, active, stag, spins, ctrl, 1u, lane);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float gx = (float)xv[e];
-                            xv[e] = (half_t)((gx / (1.0f + expf(-gx))) * (float)up[e]);
-                        }
-                    }
-                    if (sh == 0 && active) *reinterpret_cast<u32x2*>(xs + m * 128 + 4 * qd) = __builtin_bit_cast(u32x2, xv);
-                }
-            } else {
-                const bool mine = 2 * lane < nrows;  // lane owns elements (2 lane, 2 lane + 1) of every row
-                for (int m = 0; m < M; ++m)
-                    if (mine) *reinterpret_cast<uint32_t*>(xs + m * 128 + 2 * lane) =
-                                  *reinterpret_cast<const uint32_t*>(L.x + (size_t)m * L.x_stride + row0 + 2 * lane);
+                unsigned long long t0 = 0;
+                while (lds_ld(&ready[slot]) != f + 1u)
+                    if (give_up_lds(spins, lds_abort, t0, ctrl, 32u, lane)) break;
+                while (lds_ld(&xflag[cw]) != (uint32_t)(l + 1))
+                    if (give_up_lds(spins, lds_abort, t0, ctrl, 16u, lane)) break;
             }
             stamp(l, 1);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // LDS writes of this wave before its own reads
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 
-            // ---- P2: MFMAs over the sets of the unit (all inside one group)
+            // ---- MFMAs over the 8 sets of the unit (all inside one group)
             float4_t acc[8];
             float4_t accsx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
             const half_t* xlane = xs + arow * 128 + 4 * kb;
+            const unsigned char* wl = wb + (4 * kb) * 128 + j * 8;  // this lane's 8 bytes of row 4 kb of a set
 #pragma unroll
-            for (int t = 0; t < MAXSETS; ++t) {
-                if (t < nsets) {
-                    const u32x2 xq = *reinterpret_cast<const u32x2*>(xlane + 16 * t);
-                    const uint32_t x01 = xq[0], x23 = xq[1];
-                    const u32x4v a0 = {__builtin_amdgcn_perm(0u, x01, sel_lo), __builtin_amdgcn_perm(0u, x01, sel_hi),
-                                       __builtin_amdgcn_perm(0u, x23, sel_lo), __builtin_amdgcn_perm(0u, x23, sel_hi)};
-                    accsx = mfma16(a0, ones, accsx);
+            for (int t = 0; t < SETS; ++t) {
+                const u32x2 xq = *reinterpret_cast<const u32x2*>(xlane + 16 * t);
+                const uint32_t x01 = xq[0], x23 = xq[1];
+                const u32x4v a0 = {__builtin_amdgcn_perm(0u, x01, sel_lo), __builtin_amdgcn_perm(0u, x01, sel_hi),
+                                   __builtin_amdgcn_perm(0u, x23, sel_lo), __builtin_amdgcn_perm(0u, x23, sel_hi)};
+                accsx = mfma16(a0, ones, accsx);
+                const u32x2 w0 = *reinterpret_cast<const u32x2*>(wl + (16 * t + 0) * 128);
+                const u32x2 w1 = *reinterpret_cast<const u32x2*>(wl + (16 * t + 1) * 128);
+                const u32x2 w2 = *reinterpret_cast<const u32x2*>(wl + (16 * t + 2) * 128);
+                const u32x2 w3 = *reinterpret_cast<const u32x2*>(wl + (16 * t + 3) * 128);
 #pragma unroll
-                    for (int wd = 0; wd < 2; ++wd) {
-                        const uint32_t q0 = U.q[t][0][wd], q1 = U.q[t][1][wd], q2 = U.q[t][2][wd], q3 = U.q[t][3][wd];
-                        const uint32_t h0 = q0 >> 8, h1 = q1 >> 8, h2 = q2 >> 8, h3 = q3 >> 8;
+                for (int wd = 0; wd < 2; ++wd) {
+                    const uint32_t q0 = w0[wd], q1 = w1[wd], q2 = w2[wd], q3 = w3[wd];
+                    const uint32_t h0 = q0 >> 8, h1 = q1 >> 8, h2 = q2 >> 8, h3 = q3 >> 8;
 #define AWQ_MMA_J(J)                                                                                     \
     {                                                                                                    \
         const u32x4v bf = {pairb<J>(q0, h0), pairb<J>(q1, h1), pairb<J>(q2, h2), pairb<J>(q3, h3)};      \
         acc[wd * 4 + J] = mfma16(a0, bf, acc[wd * 4 + J]);                                               \
     }
-                        AWQ_MMA_J(0)
-                        AWQ_MMA_J(1)
-                        AWQ_MMA_J(2)
-                        AWQ_MMA_J(3)
+                    AWQ_MMA_J(0)
+                    AWQ_MMA_J(1)
+                    AWQ_MMA_J(2)
+                    AWQ_MMA_J(3)
 #undef AWQ_MMA_J
-                    }
                 }
             }
-            // ---- P3: y = s * (acc - (bias_J + z) * sum_x), the unit lies inside one group
+            // ---- y = s * (acc - (bias_J + z) * sum_x), the unit lies inside one group
+            const u32x2 zq = *reinterpret_cast<const u32x2*>(wb + 16384 + j * 8);
+            const u32x4 sq0 = *reinterpret_cast<const u32x4*>(wb + 16384 + 128 + j * 32);
+            const u32x4 sq1 = *reinterpret_cast<const u32x4*>(wb + 16384 + 128 + j * 32 + 16);
 #pragma unroll
             for (int wd = 0; wd < 2; ++wd) {
-                const uint32_t zw = U.z[wd], zw8 = zw >> 8;
+                const uint32_t zw = zq[wd], zw8 = zw >> 8;
                 const uint32_t zp[4] = {pairb<0>(zw, zw8), pairb<1>(zw, zw8), pairb<2>(zw, zw8), pairb<3>(zw, zw8)};
+                const u32x4 sv = wd ? sq1 : sq0;
 #pragma unroll
                 for (int J = 0; J < 4; ++J) {
-                    const half2_t z2 = u2h2(zp[J]), s2 = u2h2(U.s[wd][J]);
+                    const half2_t z2 = u2h2(zp[J]), s2 = u2h2(sv[J]);
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) {
                         const int e = r & 1;
@@ -402,22 +592,22 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            if (lane == 0) lds_st(&freed[slot], f + 1u);  // the ring slot may be refilled
+            stamp(l, 2);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (has) stamp(l, 2);
-        // ---- request the NEXT link's unit now: its latency runs under this link's fold and exchange
-        if (l + 1 < n_links) request(l + 1, U);
-        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0) lds_st(&xdone[cw], (uint32_t)(l + 1));  // xs may be re-staged (also when this link had nothing for us)
 
         if (has) {
-            // ---- fold the block's waves through LDS; the last wave to arrive sums and stores the slab.
-            // Arrivals and completed folds are counted monotonically.  A wave may be one link ahead of the
-            // others (sub-links of one Linear share their input, so nothing else holds it back): it must not
-            // overwrite its fold rows before the previous fold has been read.
-            {
+            // ---- fold the waves of the block that share the tile through LDS; the last one to arrive sums and
+            // stores the slab.  Arrivals and completed folds are counted monotonically per group; a wave must not
+            // overwrite its rows before the fold it last took part in has been read.
+            if (my_pg >= 0) {
                 unsigned spins = 0;
-                while (__hip_atomic_load(&lds_ctl[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != nfold)
-                    if (give_up(spins, ctrl, 4u, lane)) break;
+                unsigned long long t0 = 0;
+                while (lds_ld(&fold_done[my_pg]) < my_pf)
+                    if (give_up_lds(spins, lds_abort, t0, ctrl, 4u, lane)) break;
             }
             // D row 4 kb + r = (batch row 2 kb + (r >> 1), column parity r & 1); column j*16 + 2c + e
 #pragma unroll
@@ -430,20 +620,23 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
                             float4_t{yv[c][2 * rp], yv[c][2 * rp + 1], yv[c + 1][2 * rp], yv[c + 1][2 * rp + 1]};
                 }
             }
+            const uint32_t fing = grp ? fin1 : fin0, arrg = grp ? arr1 : arr0;
+            my_pg = grp;
+            my_pf = fing + 1u;
             uint32_t arrived = 0;
-            if (lane == 0)
-                arrived = __hip_atomic_fetch_add(&lds_ctl[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) arrived = __hip_atomic_fetch_add(&fold_cnt[grp], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             arrived = __builtin_amdgcn_readfirstlane(arrived);
-            if (arrived == nfold * NCW + NCW - 1) {
+            const int ng = grp ? n1 : n0, w0 = grp ? n0 : 0;
+            if (arrived == arrg + (uint32_t)ng - 1u) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const uint32_t stag = tag_hi | (uint32_t)(L.out_id + 1);
-                const rsrc_t slres = mk_rsrc(ws + CTRL_BYTES + L.slab_off, (uint32_t)S * (uint32_t)L.tiles_full * (uint32_t)M * 2048u);
-                const uint32_t so = (uint32_t)((slice * L.tiles_full + tl) * M) * 2048u;
+                const int tile = L.tile0 + tloc;
+                const int slot = b - (tloc * R) / NCWB;
+                const uint32_t so = L.slab_off + (uint32_t)((tile * L.smax + slot) * M) * 2048u;
                 for (int qd = lane; qd < M * 64; qd += 64) {
                     const int m = qd >> 6, c4 = (qd & 63) * 4;
                     float4_t s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int w = 0; w < NCW; ++w) {
+                    for (int w = w0; w < w0 + ng; ++w) {
                         const float* src = red + (size_t)(w * M + m) * CWP + c4;
                         s += float4_t{src[0], src[1], src[2], src[3]};
                     }
@@ -453,11 +646,15 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
                     __builtin_amdgcn_raw_buffer_store_b128(g1, slres, (uint32_t)qd * 32u + 16u + so, 0, 16);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the fold rows have been read
-                if (lane == 0) __hip_atomic_store(&lds_ctl[2], nfold + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) lds_st(&fold_done[grp], fing + 1u);
             }
-            ++nfold;
             stamp(l, 3);
         }
+        fbase += (uint32_t)nblk;
+        arr0 += (uint32_t)n0;
+        arr1 += (uint32_t)n1;
+        fin0 += n0 > 0 ? 1u : 0u;
+        fin1 += n1 > 0 ? 1u : 0u;
     }
 }
 
@@ -476,7 +673,9 @@ DevInfo dev_info() {
     return d;
 }
 
-size_t chain_lds_bytes(int M) { return (size_t)NCW * M * (CW + 8) * 4 + (size_t)NCW * (M + 1) * 128 * 2 + 16; }
+size_t chain_lds_bytes(int M) {
+    return (size_t)ring_slots(M) * SLOT_BYTES + (size_t)NCWB * M * (CW + 8) * 4 + (size_t)NCWB * (M + 1) * 128 * 2 + 256;
+}
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -486,16 +685,16 @@ extern "C" {
 
 size_t awq_chain_plan_bytes(int64_t n_links) {
     if (n_links <= 0) return 0;
-    return sizeof(ChainHeader) + (size_t)n_links * 8 * sizeof(ChainLinkDev);  // a Linear splits into <= 8 sub-links
+    return sizeof(ChainHeader) + (size_t)n_links * MAX_SUB * sizeof(ChainLinkDev);
 }
 
 int awq_chain_grid_blocks(void) {
     static const int cached = [] {
         const char* e = getenv("AWQ_CHAIN_GRID");
-        if (e && atoi(e) >= 24) return atoi(e) / 24 * 24;
+        if (e && atoi(e) >= 8) return atoi(e) / 8 * 8;
         const DevInfo d = dev_info();
         const int cus = d.cus > 0 ? d.cus : 256;  // no device visible (build box): plan for an MI355X
-        return cus * 3 / 24 * 24;                 // 3 blocks per CU; a multiple of 8 (epoch counters) and of 12 (roles)
+        return cus / 8 * 8;                       // one block per CU; a multiple of 8 (epoch counters)
     }();
     return cached;
 }
@@ -505,18 +704,18 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
     if (!links || !plan_host) return AWQ_ERR_NULL;
     if (n < 1 || n > 1000 || M < 1 || M > 8) return AWQ_ERR_UNSUPPORTED;
     if (plan_bytes < awq_chain_plan_bytes(n)) return AWQ_ERR_WORKSPACE;
-    const int Gall = awq_chain_grid_blocks();
-    const int G = Gall - Gall / SVC_EVERY;  // compute blocks: what a (sub-)link's tiles x slices must fit
+    const int G = awq_chain_grid_blocks();
+    const int TCW = G * NCWB;  // compute waves of the grid = units a (sub-)link may hold
     ChainHeader* H = static_cast<ChainHeader*>(plan_host);
     ChainLinkDev* out = reinterpret_cast<ChainLinkDev*>(H + 1);
     memset(H, 0, sizeof(*H));
-    struct Lin { int nsets, S, tiles, nsub, first; size_t slab, off; };
+    struct Lin { int R, tiles, per, nsub, smax, first; size_t slab, off; };
     std::vector<Lin> lin((size_t)n);
-    // Slab regions.  A Linear's slabs are read by the next Linear's waves while they stage their input, so
+    // Slab regions.  A Linear's slabs are read by the next Linear's poll waves while they stage its input, so
     // Linear i and i + 2 never overlap in time (i + 2 stores only after every slab of i + 1 is complete, i.e.
-    // after every wave of i + 1 has finished reading i): two alternating regions serve the whole chain.  A
-    // Linear whose result is also materialised (y != NULL) is read by service waves at their own pace: it
-    // gets a private region.
+    // after every unit of i + 1 has been given its input, which was read from i): two alternating regions
+    // serve the whole chain.  A Linear whose result is also materialised (y != NULL) is read once more, one
+    // link later: it gets a private region.
     size_t half[2] = {0, 0}, priv = 0;
     int total = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -530,7 +729,6 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
             if (a.x_from != i - 1) return AWQ_ERR_UNSUPPORTED;  // a pure chain bounds how far blocks run ahead
             const AwqChainLink& p = links[a.x_from];
             if (a.x_col0 < 0 || a.x_col0 % 128 || a.x_col0 + (gated ? 2 : 1) * a.K > p.N) return AWQ_ERR_BAD_SHAPE;
-            if (gated && a.K % 128) return AWQ_ERR_BAD_SHAPE;
         } else {
             if (i != 0) return AWQ_ERR_UNSUPPORTED;
             if (!a.x || gated) return a.x ? AWQ_ERR_UNSUPPORTED : AWQ_ERR_NULL;
@@ -538,16 +736,16 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
         }
         if (i == n - 1 && !a.y) return AWQ_ERR_NULL;  // somebody has to want the result
         Lin& L = lin[(size_t)i];
+        L.R = (int)(a.K / 128);
         L.tiles = (int)((a.N + CW - 1) / CW);
-        // fat units: a wave holds up to 128 rows, a block 512 -- few K slices, so that a consumer sums few slabs
-        L.nsets = a.K >= NCW * 128 ? 8 : (a.K >= NCW * 64 ? 4 : 2);
-        const int rpb = NCW * 16 * L.nsets;
-        L.S = (int)((a.K + rpb - 1) / rpb);
-        if (L.S > 64 || L.S > G) return AWQ_ERR_UNSUPPORTED;
-        const int per = G / L.S;  // column ranges of <= G / S tiles, one sub-link after the other
-        L.nsub = (L.tiles + per - 1) / per;
-        if (L.nsub > 8) return AWQ_ERR_UNSUPPORTED;
-        L.slab = align_up((size_t)L.tiles * L.S * (size_t)M * 2048, 4096);
+        if (L.R > TCW || L.R < NCWB) return AWQ_ERR_UNSUPPORTED;  // a block's units touch at most two tiles
+        L.per = TCW / L.R;  // whole tiles per sub-link
+        if (L.per > L.tiles) L.per = L.tiles;
+        L.nsub = (L.tiles + L.per - 1) / L.per;
+        if (L.nsub > MAX_SUB) return AWQ_ERR_UNSUPPORTED;
+        L.per = (L.tiles + L.nsub - 1) / L.nsub;  // even sub-links
+        L.smax = (L.R + NCWB - 1) / NCWB + 1;
+        L.slab = align_up((size_t)L.tiles * L.smax * (size_t)M * 2048, 4096);
         if (a.y) { L.off = priv; priv += L.slab; }
         else if (L.slab > half[i & 1]) half[i & 1] = L.slab;
         L.first = total;
@@ -556,7 +754,7 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
     if (total > 1023 || n > 1023) return AWQ_ERR_UNSUPPORTED;  // 10 bits of tag
     const size_t slab_bytes = half[0] + half[1] + priv;
     const size_t need = CTRL_BYTES + slab_bytes;
-    if (slab_bytes >= ((size_t)1 << 32)) return AWQ_ERR_UNSUPPORTED;
+    if (slab_bytes >= ((size_t)1 << 31)) return AWQ_ERR_UNSUPPORTED;
     if (workspace_needed) *workspace_needed = need;
     if (!workspace) return AWQ_OK;  // size query
     if (workspace_bytes < need) return AWQ_ERR_WORKSPACE;
@@ -565,7 +763,6 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
     for (int64_t i = 0; i < n; ++i) {
         const AwqChainLink& a = links[i];
         const Lin& L = lin[(size_t)i];
-        const int per = (L.tiles + L.nsub - 1) / L.nsub;
         const size_t off = a.y ? half[0] + half[1] + L.off : ((i & 1) ? half[0] : 0);
         for (int sidx = 0; sidx < L.nsub; ++sidx) {
             ChainLinkDev& d = out[k++];
@@ -577,13 +774,16 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
             d.add_res = reinterpret_cast<const half_t*>(a.add_residual);
             d.y = reinterpret_cast<half_t*>(a.y);
             d.K = (int)a.K; d.N = (int)a.N; d.g = (int)a.group_size;
-            d.tile0 = sidx * per;
-            d.tiles = (sidx + 1) * per <= L.tiles ? per : L.tiles - sidx * per;
+            d.tile0 = sidx * L.per;
+            d.tiles = (sidx + 1) * L.per <= L.tiles ? L.per : L.tiles - sidx * L.per;
             d.tiles_full = L.tiles;
-            d.S = L.S; d.nsets = L.nsets;
+            d.R = L.R;
+            d.units = d.tiles * L.R;
+            d.per = L.per;
+            d.smax = L.smax;
             d.out_id = (int)i;
             d.slab_off = (uint32_t)off;
-            d.first_sub = sidx == 0;
+            d.last_sub = sidx == L.nsub - 1;
             if (a.x_from >= 0) {
                 d.xflags = XF_SLABS | ((a.flags & AWQ_CHAIN_X_GATED_SILU) ? XF_GATED : 0);
                 d.x = nullptr;
@@ -597,7 +797,7 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
             }
         }
     }
-    H->magic = CHAIN_MAGIC; H->n_links = (uint32_t)k; H->G = (uint32_t)Gall; H->M = (uint32_t)M;
+    H->magic = CHAIN_MAGIC; H->n_links = (uint32_t)k; H->G = (uint32_t)G; H->M = (uint32_t)M;
     H->slab_bytes = slab_bytes; H->n_linears = (uint32_t)n;
     return AWQ_OK;
 }

@@ -110,8 +110,6 @@ def main():
         tr = chain.trace.cpu().numpy().astype("float64")  # [links, G, 4 waves, 4 slots], 100 MHz ticks
         import numpy as np
 
-        G = tr.shape[1]
-        svc = (np.arange(G) % 6) == 5
         t0 = tr[tr > 0].min()
         us = lambda v: (v - t0) / 100.0
 
@@ -119,11 +117,12 @@ def main():
             v = v[v > 0]
             return "      -            " if v.size == 0 else f"{us(v.min()):7.2f} {us(np.median(v)):7.2f} {us(v.max()):7.2f}"
 
-        print("us since first stamp: min / median / max over waves")
-        print("link |        start         |       x ready        |      mfma done       |    slab stored       ||  svc start           | slabs complete       | published")
+        print("us since first stamp: min / median / max over waves (wave 0 loader, 1-6 compute, 7-9 poll)")
+        print("link | loader starts link   || compute: start       | weights + x ready    | mfma done            | folded / slab stored || poll: start          | slabs probed         | x staged")
         for l in range(min(tr.shape[0], a.trace_links)):
-            c, sv = tr[l][~svc], tr[l][svc]
-            print(f"{l:4d} | " + " | ".join(stat(c[..., k]) for k in range(4)) + " || " + " | ".join(stat(sv[..., k]) for k in range(3)))
+            ld, c, pl = tr[l][:, 0], tr[l][:, 1:7], tr[l][:, 7:]
+            print(f"{l:4d} | " + stat(ld[..., 0]) + " || " + " | ".join(stat(c[..., k]) for k in range(4)) + " || " +
+                  " | ".join(stat(pl[..., k]) for k in range(3)))
         return
     if a.no_time or st:
         return
