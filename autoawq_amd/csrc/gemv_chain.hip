@@ -48,16 +48,21 @@
 
 namespace {
 
-constexpr int NCWB = 6;                 // compute waves per block (waves 1 .. 6; wave 0 is the loader)
-constexpr int NPW = 3;                  // poll waves per block (waves 7 .. 9)
-constexpr int UPP = NCWB / NPW;         // compute waves served by one poll wave
+constexpr int CW = 256;                 // columns per tile (2 packed words per lane)
+constexpr int UPB = 6;                  // units a block holds of one (sub-)link
+constexpr int WPU = 1;                  // compute waves per unit (2: 64 rows each -- measured slower: 16 waves, 128 registers, 12-way fold)
+constexpr int NCWB = WPU * UPB;         // compute waves per block (waves 1 .. NCWB; wave 0 is the loader)
+constexpr int NPW = 3;                  // poll waves per block (waves 13 .. 15)
+constexpr int UPP = UPB / NPW;          // units served by one poll wave
 constexpr int NWAVES = 1 + NCWB + NPW;
 constexpr int NTHR = NWAVES * 64;
 constexpr int SLOT_BYTES = 17 * 1024;   // ring slot: 16 KiB of packed weights (128 rows x 128 bytes) + 128 B zeros + 512 B scales
-__host__ __device__ constexpr int ring_slots(int M) { return M <= 2 ? 8 : 4; }  // what the fold / staging areas leave of 160 KiB
+__host__ __device__ constexpr int ring_slots(int M) {  // what the fold / staging areas leave of 160 KiB, at most 8
+    const int n = (160 * 1024 - 256 - NCWB * M * (CW + 8) * 4 - UPB * (M + 1) * 256) / SLOT_BYTES;
+    return n > 8 ? 8 : n;
+}
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gl_ptr_t;
-constexpr int CW = 256;                 // columns per tile (2 packed words per lane)
 constexpr int SETS = 8;                 // 16-row sets per unit: 128 rows
 constexpr int MAX_SUB = 16;             // sub-links a Linear may be cut into
 constexpr unsigned SPIN_LIMIT = 1u << 17;
@@ -97,8 +102,10 @@ struct ChainHeader {  // 128 bytes, followed by the links
     uint64_t slab_bytes, unused_;
     uint32_t n_linears;
     uint32_t pad0_;
-    unsigned long long* trace;  // debug: [n_links][G][8 waves][4] wall_clock64 stamps, or null
-    uint32_t pad_[20];
+    unsigned long long* trace;  // debug: [n_links][G][NWAVES][4] wall_clock64 stamps, or null
+    uint32_t inflight;          // fills the loader keeps in flight (1 .. 3)
+    uint32_t slack;             // slabs a gather may still miss when it starts (0 | 1)
+    uint32_t pad_[18];
 };
 static_assert(sizeof(ChainHeader) == 128, "ChainHeader layout");
 
@@ -164,7 +171,7 @@ struct SlabRange {
 AWQ_DEV SlabRange slab_range(const ChainLinkDev& P, int M, int col) {
     const int tp = col >> 8;                 // tile of the Linear
     const int tl = tp % P.per;               // tile within its sub-link: unit numbering restarts there
-    const int b_lo = (tl * P.R) / NCWB, b_hi = ((tl + 1) * P.R - 1) / NCWB;
+    const int b_lo = (tl * P.R) / UPB, b_hi = ((tl + 1) * P.R - 1) / UPB;
     SlabRange r;
     r.S = b_hi - b_lo + 1;
     r.base = P.slab_off + (uint32_t)(tp * P.smax * M) * 2048u + (uint32_t)((col & 255) >> 2) * 32u;
@@ -196,31 +203,44 @@ AWQ_DEV void gather_ranges(const ChainLinkDev& P, rsrc_t slres, int M, int m, co
     for (int r = 0; r < NR; ++r) part[r] = float4_t{0.f, 0.f, 0.f, 0.f};
     for (int s0 = 0; s0 < smost; s0 += 8) {  // this lane: slots s0 + sh, +2, +4, +6 of every range
         u32x4 v[NR][4][2];
+        bool valid[NR][4];  // wave-uniform: the slot (pair: one slot per parity) has been read with good tags on every lane
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) valid[r][u] = s0 + 2 * u >= S[r];  // neither parity's slot exists: nothing to read
         for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int s = s0 + sh + 2 * u;
-                    const uint32_t off = s < S[r] ? base[r] + (uint32_t)s * sstride : OOB;
-                    v[r][u][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, off, 0, 16 /* sc1 */));
-                    v[r][u][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, off == OOB ? OOB : off + 16u, 0, 16));
-                }
+            // only what is still missing is requested again: the caller starts us when all slabs but one have
+            // been seen, so the last slab's DATA arrives with the poll that detects it
 #pragma unroll
             for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (s0 + sh + 2 * u < S[r])
-                        ok &= v[r][u][0][1] == stag && v[r][u][0][3] == stag && v[r][u][1][1] == stag && v[r][u][1][3] == stag;
-            if (__all(ok)) break;
+                    if (!valid[r][u]) {
+                        const int s = s0 + sh + 2 * u;
+                        const uint32_t off = s < S[r] ? base[r] + (uint32_t)s * sstride : OOB;
+                        v[r][u][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, off, 0, 16 /* sc1 */));
+                        v[r][u][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, off == OOB ? OOB : off + 16u, 0, 16));
+                    }
+            bool all = true;
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (!valid[r][u]) {
+                        const bool mine = s0 + sh + 2 * u < S[r];
+                        const bool ok = !mine || (v[r][u][0][1] == stag && v[r][u][0][3] == stag && v[r][u][1][1] == stag && v[r][u][1][3] == stag);
+                        valid[r][u] = __all(ok);
+                        all &= valid[r][u];
+                    }
+            if (all) break;
             if (give_up(spins, ctrl, code, lane)) break;
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)  // slots past S were requested out of range: zeros
-                part[r] += float4_t{u2f(v[r][u][0][0]), u2f(v[r][u][0][2]), u2f(v[r][u][1][0]), u2f(v[r][u][1][2])};
+            for (int u = 0; u < 4; ++u)  // slots past S were requested out of range or never: contribute zero
+                if (s0 + sh + 2 * u < S[r])
+                    part[r] += float4_t{u2f(v[r][u][0][0]), u2f(v[r][u][0][2]), u2f(v[r][u][1][0]), u2f(v[r][u][1][2])};
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -243,31 +263,48 @@ AWQ_DEV void gather_ranges(const ChainLinkDev& P, rsrc_t slres, int M, int m, co
     }
 }
 
-// Light wait: until one granule (first quad, last batch row) of every slab of every range has landed.  Lane
-// (r = lane >> 4, i = lane & 15) probes slots i, i + 16, ... of range r: a waiting wave costs a few 8-byte
-// loads per turn instead of re-reading every slab.
+// Light wait: until one granule (first quad, last batch row) of all but `slack` slabs of every range has landed.
+// Lane (r = lane >> 4, i = lane & 15) probes slot i of range r (ranges of more than 16 slabs: chunk after chunk,
+// every slab): a waiting wave costs a few 8-byte loads per turn instead of re-reading every slab.
 template <int NR>
 AWQ_DEV void probe_ranges(const ChainLinkDev& P, rsrc_t slres, int M, const int (&col)[NR], const bool (&on)[NR], uint32_t stag,
-                          unsigned& spins, ChainCtrl* ctrl, uint32_t code, int lane) {
+                          int slack, unsigned& spins, ChainCtrl* ctrl, uint32_t code, int lane) {
     static_assert(NR <= 4, "16 lanes per range");
     const int pr = lane >> 4, pi = lane & 15;
-    int S = 0;
+    int S = 0, Sr[NR];
     uint32_t base = 0;
+    bool small = true;
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
+    for (int r = 0; r < NR; ++r) {
+        const SlabRange sr = slab_range(P, M, col[r]);
+        Sr[r] = on[r] ? sr.S : 0;
+        small &= Sr[r] <= 16;
         if (r == pr && on[r]) {
-            const SlabRange sr = slab_range(P, M, col[r]);
             S = sr.S;
             base = sr.base + (uint32_t)(M - 1) * 2048u;
         }
+    }
     const uint32_t sstride = (uint32_t)M * 2048u;
+    if (small) {
+        const bool probing = pi < S;
+        const uint32_t off = probing ? base + (uint32_t)pi * sstride : OOB;
+        for (;;) {
+            const u32x2 pv = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(slres, off, 0, 16 /* sc1 */));
+            const unsigned long long seen = __ballot(probing && pv[1] == stag);
+            bool enough = true;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) enough &= __builtin_popcountll((seen >> (16 * r)) & 0xFFFFull) >= Sr[r] - slack;
+            if (enough) break;
+            if (give_up(spins, ctrl, code, lane)) break;
+        }
+        return;
+    }
     for (int s0 = 0; __any(s0 < S); s0 += 16) {
         const bool probing = s0 + pi < S;
         const uint32_t off = probing ? base + (uint32_t)(s0 + pi) * sstride : OOB;
         for (;;) {
             const u32x2 pv = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(slres, off, 0, 16 /* sc1 */));
             if (__all(!probing || pv[1] == stag)) break;
-            __builtin_amdgcn_s_sleep(2);
             if (give_up(spins, ctrl, code, lane)) break;
         }
     }
@@ -275,10 +312,10 @@ AWQ_DEV void probe_ranges(const ChainLinkDev& P, rsrc_t slres, int M, const int 
 
 // NREG = live D registers per lane: 2 when M == 1 (rows 0, 1 of the selector MFMA), 4 for M <= 8
 template <int NREG>
-__global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* __restrict__ plan, unsigned char* __restrict__ ws) {
+__global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const ChainHeader* __restrict__ plan, unsigned char* __restrict__ ws) {
     constexpr int CWP = CW + 8;  // LDS row pitch of the fold area (floats)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS: ring[NS][SLOT_BYTES] | red[NCWB][M][CWP] fp32 | xs[NCWB][M + 1][128] fp16 | control words
+    // dynamic LDS: ring[NS][SLOT_BYTES] | red[NCWB][M][CWP] fp32 | xs[UPB][M + 1][128] fp16 | control words
     const int M = (int)plan->M;
     const int G = (int)plan->G;
     const int n_links = (int)plan->n_links;
@@ -290,14 +327,14 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
     unsigned char* const ring = smem;
     float* red = reinterpret_cast<float*>(smem + (size_t)NS * SLOT_BYTES);
     half_t* xs_all = reinterpret_cast<half_t*>(reinterpret_cast<unsigned char*>(red) + (size_t)NCWB * M * CWP * 4);
-    uint32_t* lds_ctl = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(xs_all) + (size_t)NCWB * (M + 1) * 128 * 2);
+    uint32_t* lds_ctl = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(xs_all) + (size_t)UPB * (M + 1) * 128 * 2);
     uint32_t* const fold_cnt = lds_ctl + 1;   // [2] arrivals per fold group (monotonic)
     uint32_t* const fold_done = lds_ctl + 3;  // [2] folds completed per group (monotonic)
     uint32_t* const lds_abort = lds_ctl + 5;  // set by a wave that gave up: everybody in the block stops waiting
-    uint32_t* const xflag = lds_ctl + 8;      // [NCWB] link index + 1 whose activations are staged for the wave
+    uint32_t* const xflag = lds_ctl + 8;      // [UPB] link index + 1 whose activations are staged for the unit
     uint32_t* const xdone = lds_ctl + 16;     // [NCWB] link index + 1 the wave has finished reading
-    uint32_t* const ready = lds_ctl + 24;     // [NS] fill index + 1 that has landed in the slot
-    uint32_t* const freed = lds_ctl + 32;     // [NS] fill index + 1 whose reader is done with the slot
+    uint32_t* const ready = lds_ctl + 32;     // [NS] fill index + 1 that has landed in the slot
+    uint32_t* const freed = lds_ctl + 40;     // [NS] releases of the slot (two per tenant: one per half unit)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -308,7 +345,7 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
         const u64 a = __hip_atomic_fetch_add(&ctrl->arrive[b & 7], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lds_ctl[0] = (uint32_t)(a / (u64)(G >> 3)) + 1u;  // epoch of this launch
     }
-    for (int i = tid; i < NCWB * 128; i += NTHR) xs_all[((i >> 7) * (M + 1) + M) * 128 + (i & 127)] = (half_t)0.f;  // the all-zero row M
+    for (int i = tid; i < UPB * 128; i += NTHR) xs_all[((i >> 7) * (M + 1) + M) * 128 + (i & 127)] = (half_t)0.f;  // the all-zero row M
     __syncthreads();
     const uint32_t epoch = lds_ctl[0];
     const uint32_t tag_hi = epoch << 10;
@@ -316,7 +353,7 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
     auto stamp = [&](int l, int slot) {  // phase timeline for tools/chain_probe.py --trace (off unless the plan carries a buffer)
         if (trace && lane == 0) trace[(((size_t)l * G + b) * NWAVES + wave) * 4 + slot] = wall_clock64();
     };
-    auto units_here = [&](const ChainLinkDev& L) { return max(0, min(NCWB, L.units - b * NCWB)); };  // units of a link held by this block
+    auto units_here = [&](const ChainLinkDev& L) { return max(0, min(UPB, L.units - b * UPB)); };  // units of a link held by this block
 
     if (wave == 0) {
         // ================================================================ loader wave: HBM -> LDS ring, paced
@@ -336,17 +373,18 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
         auto lds_write = [](uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); };
         const int rr = lane >> 3, cc = lane & 7;
         uint32_t f = 0;  // fill sequence number of this block
+        const uint32_t lag = plan->inflight - 1u;  // fills still in flight when the next one is issued
         bool dead = false;
         for (int l = 0; l < n_links && !dead; ++l) {
             const ChainLinkDev& L = links[l];
             const int nblk = units_here(L);
             const uint32_t row_bytes = (uint32_t)(L.N >> 3) * 4u;
             for (int i = 0; i < nblk; ++i, ++f) {
-                const int slot = (int)(f & (uint32_t)(NS - 1));
-                if (f >= (uint32_t)NS) {  // the slot's previous tenant has been read
+                const int slot = (int)(f % (uint32_t)NS);
+                if (f >= (uint32_t)NS) {  // the slot's previous tenant has been read by both of its waves
                     unsigned spins = 0;
                     unsigned long long t0 = 0;
-                    while (lds_read(freed_a + 4u * slot) != f - (uint32_t)NS + 1u) {
+                    while (lds_read(freed_a + 4u * slot) != (uint32_t)WPU * (f / (uint32_t)NS)) {
                         __builtin_amdgcn_s_sleep(2);
                         if ((++spins & 63u) == 0) {
                             const unsigned long long now = wall_clock64();
@@ -357,7 +395,7 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
                     if (dead) break;
                 }
                 if (i == 0) stamp(l, 0);
-                const int u = b * NCWB + i;
+                const int u = b * UPB + i;
                 const int tile = L.tile0 + u / L.R, row0 = (u % L.R) * 128;
                 unsigned char* const dst = ring + (size_t)slot * SLOT_BYTES;
                 // 16 x 1 KiB: instruction k moves rows row0 + 8k .. + 7, 128 bytes each (lane = row rr, 16-byte chunk cc)
@@ -375,15 +413,19 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
                               min((uint32_t)tile * 512u + (uint32_t)(lane - 8) * 16u, (uint32_t)L.N * 2u - 16u);
                     if (lane < 40) __builtin_amdgcn_global_load_lds((gl_ptr_t)zs, (lds_ptr_t)(dst + 16384), 16, 0, 0);
                 }
-                // fills land in order: everything but the two newest (2 x 17 instructions) is in LDS
-                asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
-                if (f >= 2u) lds_write(ready_a + 4u * ((f - 2u) & (uint32_t)(NS - 1)), f - 1u);
+                // fills land in order: everything but the `lag` newest (17 instructions each) is in LDS
+                if (lag == 2u) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+                else if (lag == 1u) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (f >= lag) lds_write(ready_a + 4u * ((f - lag) % (uint32_t)NS), f - lag + 1u);
             }
         }
-        asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-        if (f >= 2u) lds_write(ready_a + 4u * ((f - 2u) & (uint32_t)(NS - 1)), f - 1u);
+        if (lag == 2u) {
+            asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            if (f >= 2u) lds_write(ready_a + 4u * ((f - 2u) % (uint32_t)NS), f - 1u);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (f >= 1u) lds_write(ready_a + 4u * ((f - 1u) & (uint32_t)(NS - 1)), f);
+        if (lag >= 1u && f >= 1u) lds_write(ready_a + 4u * ((f - 1u) % (uint32_t)NS), f);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         return;
     }
@@ -403,7 +445,7 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
                 const bool on[1] = {true};
                 half4_t o[1];
                 unsigned spins = 0;
-                probe_ranges<1>(L, slres, M, col, on, stag, spins, ctrl, 2u, lane);
+                probe_ranges<1>(L, slres, M, col, on, stag, 0, spins, ctrl, 2u, lane);
                 gather_ranges<1>(L, slres, M, m, col, on, stag, o, spins, ctrl, 2u, lane);
                 const int c = col[0] + 4 * qd;
                 if (sh == 0 && c < L.N) *reinterpret_cast<u32x2*>(L.y + (size_t)m * L.N + c) = __builtin_bit_cast(u32x2, o[0]);
@@ -419,16 +461,18 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
 #pragma unroll
             for (int i = 0; i < UPP; ++i) {
                 has[i] = pw * UPP + i < nblk;
-                kg[i] = (b * NCWB + pw * UPP + i) % L.R;
+                kg[i] = (b * UPB + pw * UPP + i) % L.R;
                 any |= has[i];
             }
             if (any) {
                 stamp(l, 0);
                 unsigned spins = 0;
 #pragma unroll
-                for (int i = 0; i < UPP; ++i)  // the wave has finished reading what was staged for its previous link
-                    while (has[i] && lds_ld(&xdone[pw * UPP + i]) != (uint32_t)l)
-                        if (give_up(spins, ctrl, 8u, lane)) break;
+                for (int i = 0; i < UPP; ++i)  // the waves of the unit have finished reading what was staged for their previous link
+#pragma unroll
+                    for (int h = 0; h < WPU; ++h)
+                        while (has[i] && lds_ld(&xdone[WPU * (pw * UPP + i) + h]) != (uint32_t)l)
+                            if (give_up(spins, ctrl, 8u, lane)) break;
                 if (L.xflags & XF_SLABS) {
                     const ChainLinkDev& P = links[L.prod];
                     const uint32_t stag = tag_hi | (uint32_t)(P.out_id + 1);
@@ -439,8 +483,10 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
                         col[i] = L.x_col0 + kg[i] * 128;
                         colu[i] = col[i] + L.K;
                     }
-                    probe_ranges<UPP>(P, slres, M, col, has, stag, spins, ctrl, 1u, lane);
-                    if (gated) probe_ranges<UPP>(P, slres, M, colu, has, stag, spins, ctrl, 1u, lane);
+                    // sub-links of one Linear share their producer: its slabs have been seen complete one link ago
+                    const bool seen = l > 0 && links[l - 1].out_id == L.out_id && !gated;
+                    if (!seen) probe_ranges<UPP>(P, slres, M, col, has, stag, (int)plan->slack, spins, ctrl, 1u, lane);
+                    if (gated) probe_ranges<UPP>(P, slres, M, colu, has, stag, (int)plan->slack, spins, ctrl, 1u, lane);
                     stamp(l, 1);
                     for (int m = 0; m < M; ++m) {
                         half4_t xv[UPP];
@@ -487,8 +533,9 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
 
     // ==================================================================== compute waves
     const int cw = wave - 1;
+    const int ui = cw / WPU, hf = cw % WPU;  // unit of the block, part of the unit (sets hf * SETS / WPU ...)
     const int j = lane & 15, kb = lane >> 4;
-    half_t* xs = xs_all + (size_t)cw * (M + 1) * 128;  // this wave's activation rows [M + 1][128]
+    half_t* xs = xs_all + (size_t)ui * (M + 1) * 128;  // the unit's activation rows [M + 1][128]
     float* myred = red + (size_t)cw * M * CWP;
 
     const uint32_t sel_lo = (j & 1) ? 0x01000C0Cu : 0x0C0C0100u;  // low half of a dword -> slot (j & 1)
@@ -507,10 +554,10 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
         const ChainLinkDev& L = links[l];
         const int R = L.R;
         const int nblk = units_here(L);
-        const bool has = cw < nblk;
-        const int u0 = b * NCWB;
-        const int tloc = (u0 + cw) / R;  // tile within the sub-link
-        // the block's units u0 .. u0 + nblk - 1 touch at most two tiles (R >= NCWB): group 0 = the first unit's tile
+        const bool has = ui < nblk;
+        const int u0 = b * UPB;
+        const int tloc = (u0 + ui) / R;  // tile within the sub-link
+        // the block's units u0 .. u0 + nblk - 1 touch at most two tiles (R >= UPB): group 0 = the first unit's tile
         const int t_first = u0 / R;
         const int n0 = min(nblk, (t_first + 1) * R - u0);
         const int n1 = nblk - n0;
@@ -523,30 +570,30 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
 
         if (has) {
             stamp(l, 0);
-            const uint32_t f = fbase + (uint32_t)cw;
-            const int slot = (int)(f & (uint32_t)(NS - 1));
+            const uint32_t f = fbase + (uint32_t)ui;
+            const int slot = (int)(f % (uint32_t)NS);
             const unsigned char* const wb = ring + (size_t)slot * SLOT_BYTES;
             {   // the unit's weights have landed in the ring, the poll wave has staged its 128 activations per batch row
                 unsigned spins = 0;
                 unsigned long long t0 = 0;
                 while (lds_ld(&ready[slot]) != f + 1u)
                     if (give_up_lds(spins, lds_abort, t0, ctrl, 32u, lane)) break;
-                while (lds_ld(&xflag[cw]) != (uint32_t)(l + 1))
+                while (lds_ld(&xflag[ui]) != (uint32_t)(l + 1))
                     if (give_up_lds(spins, lds_abort, t0, ctrl, 16u, lane)) break;
             }
             stamp(l, 1);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 
-            // ---- MFMAs over the 8 sets of the unit (all inside one group)
+            // ---- MFMAs over this wave's sets of the unit (all inside one group)
             float4_t acc[8];
             float4_t accsx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
-            const half_t* xlane = xs + arow * 128 + 4 * kb;
-            const unsigned char* wl = wb + (4 * kb) * 128 + j * 8;  // this lane's 8 bytes of row 4 kb of a set
+            const half_t* xlane = xs + arow * 128 + 4 * kb + (128 / WPU) * hf;
+            const unsigned char* wl = wb + ((128 / WPU) * hf + 4 * kb) * 128 + j * 8;  // this lane's 8 bytes of row 4 kb of the wave's first set
 #pragma unroll
-            for (int t = 0; t < SETS; ++t) {
+            for (int t = 0; t < SETS / WPU; ++t) {
                 const u32x2 xq = *reinterpret_cast<const u32x2*>(xlane + 16 * t);
                 const uint32_t x01 = xq[0], x23 = xq[1];
                 const u32x4v a0 = {__builtin_amdgcn_perm(0u, x01, sel_lo), __builtin_amdgcn_perm(0u, x01, sel_hi),
@@ -594,7 +641,7 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
             }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::: "memory");
-            if (lane == 0) lds_st(&freed[slot], f + 1u);  // the ring slot may be refilled
+            if (lane == 0) __hip_atomic_fetch_add(&freed[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // this half is done with the slot
             stamp(l, 2);
         }
         if (lane == 0) lds_st(&xdone[cw], (uint32_t)(l + 1));  // xs may be re-staged (also when this link had nothing for us)
@@ -603,10 +650,14 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
             // ---- fold the waves of the block that share the tile through LDS; the last one to arrive sums and
             // stores the slab.  Arrivals and completed folds are counted monotonically per group; a wave must not
             // overwrite its rows before the fold it last took part in has been read.
-            if (my_pg >= 0) {
+            {
+                // (a) the fold this wave last wrote rows for has been read; (b) every earlier fold of the group it
+                // joins NOW is complete -- a unit changes tile, hence group, from link to link, and a wave that is
+                // a link ahead of its new group's stragglers must not be counted among their arrivals
+                const uint32_t fing_ = grp ? fin1 : fin0;
                 unsigned spins = 0;
                 unsigned long long t0 = 0;
-                while (lds_ld(&fold_done[my_pg]) < my_pf)
+                while ((my_pg >= 0 && lds_ld(&fold_done[my_pg]) < my_pf) || lds_ld(&fold_done[grp]) < fing_)
                     if (give_up_lds(spins, lds_abort, t0, ctrl, 4u, lane)) break;
             }
             // D row 4 kb + r = (batch row 2 kb + (r >> 1), column parity r & 1); column j*16 + 2c + e
@@ -626,12 +677,12 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
             uint32_t arrived = 0;
             if (lane == 0) arrived = __hip_atomic_fetch_add(&fold_cnt[grp], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             arrived = __builtin_amdgcn_readfirstlane(arrived);
-            const int ng = grp ? n1 : n0, w0 = grp ? n0 : 0;
+            const int ng = WPU * (grp ? n1 : n0), w0 = grp ? WPU * n0 : 0;  // waves of the group
             if (arrived == arrg + (uint32_t)ng - 1u) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const uint32_t stag = tag_hi | (uint32_t)(L.out_id + 1);
                 const int tile = L.tile0 + tloc;
-                const int slot = b - (tloc * R) / NCWB;
+                const int slot = b - (tloc * R) / UPB;
                 const uint32_t so = L.slab_off + (uint32_t)((tile * L.smax + slot) * M) * 2048u;
                 for (int qd = lane; qd < M * 64; qd += 64) {
                     const int m = qd >> 6, c4 = (qd & 63) * 4;
@@ -651,8 +702,8 @@ __global__ __launch_bounds__(NTHR, 3) void awq_chain_kernel(const ChainHeader* _
             stamp(l, 3);
         }
         fbase += (uint32_t)nblk;
-        arr0 += (uint32_t)n0;
-        arr1 += (uint32_t)n1;
+        arr0 += (uint32_t)(WPU * n0);
+        arr1 += (uint32_t)(WPU * n1);
         fin0 += n0 > 0 ? 1u : 0u;
         fin1 += n1 > 0 ? 1u : 0u;
     }
@@ -674,7 +725,7 @@ DevInfo dev_info() {
 }
 
 size_t chain_lds_bytes(int M) {
-    return (size_t)ring_slots(M) * SLOT_BYTES + (size_t)NCWB * M * (CW + 8) * 4 + (size_t)NCWB * (M + 1) * 128 * 2 + 256;
+    return (size_t)ring_slots(M) * SLOT_BYTES + (size_t)NCWB * M * (CW + 8) * 4 + (size_t)UPB * (M + 1) * 128 * 2 + 256;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -705,7 +756,7 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
     if (n < 1 || n > 1000 || M < 1 || M > 8) return AWQ_ERR_UNSUPPORTED;
     if (plan_bytes < awq_chain_plan_bytes(n)) return AWQ_ERR_WORKSPACE;
     const int G = awq_chain_grid_blocks();
-    const int TCW = G * NCWB;  // compute waves of the grid = units a (sub-)link may hold
+    const int TCW = G * UPB;  // units a (sub-)link may hold: six per block
     ChainHeader* H = static_cast<ChainHeader*>(plan_host);
     ChainLinkDev* out = reinterpret_cast<ChainLinkDev*>(H + 1);
     memset(H, 0, sizeof(*H));
@@ -738,13 +789,13 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
         Lin& L = lin[(size_t)i];
         L.R = (int)(a.K / 128);
         L.tiles = (int)((a.N + CW - 1) / CW);
-        if (L.R > TCW || L.R < NCWB) return AWQ_ERR_UNSUPPORTED;  // a block's units touch at most two tiles
+        if (L.R > TCW || L.R < UPB) return AWQ_ERR_UNSUPPORTED;  // a block's units touch at most two tiles
         L.per = TCW / L.R;  // whole tiles per sub-link
         if (L.per > L.tiles) L.per = L.tiles;
         L.nsub = (L.tiles + L.per - 1) / L.per;
         if (L.nsub > MAX_SUB) return AWQ_ERR_UNSUPPORTED;
         L.per = (L.tiles + L.nsub - 1) / L.nsub;  // even sub-links
-        L.smax = (L.R + NCWB - 1) / NCWB + 1;
+        L.smax = (L.R + UPB - 1) / UPB + 1;
         L.slab = align_up((size_t)L.tiles * L.smax * (size_t)M * 2048, 4096);
         if (a.y) { L.off = priv; priv += L.slab; }
         else if (L.slab > half[i & 1]) half[i & 1] = L.slab;
@@ -799,6 +850,13 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
     }
     H->magic = CHAIN_MAGIC; H->n_links = (uint32_t)k; H->G = (uint32_t)G; H->M = (uint32_t)M;
     H->slab_bytes = slab_bytes; H->n_linears = (uint32_t)n;
+    {
+        const char* e = getenv("AWQ_CHAIN_INFLIGHT");
+        const int v = e ? atoi(e) : 3;
+        H->inflight = (uint32_t)(v < 1 ? 1 : (v > 3 ? 3 : v));
+        const char* e2 = getenv("AWQ_CHAIN_SLACK");
+        H->slack = e2 ? (uint32_t)(atoi(e2) != 0) : 1u;
+    }
     return AWQ_OK;
 }
 
