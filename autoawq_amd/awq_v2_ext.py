@@ -7,6 +7,7 @@ before importing `awq` makes the unmodified reference WQLinear_GEMVFast run on t
 import torch
 
 from . import ops
+from .utils.packing import calculate_zeros_width
 
 
 def gemv_forward_cuda_decode(x, qweight, scales, qzeros, m, n, k, group_size):
@@ -15,12 +16,22 @@ def gemv_forward_cuda_decode(x, qweight, scales, qzeros, m, n, k, group_size):
     return out.reshape(x.shape[:-1] + (n,))
 
 
+def infer_group_size(K, group_rows):
+    """The prefill entry point is not told the group size (gemv_fast.py:203-206); the padded row count of
+    scales / qzeros determines it: rows == calculate_zeros_width(K, g) * 8 (gemv_fast.py:86-104).  The
+    largest candidate wins when the padding makes several fit (it is the layout's default)."""
+    for g in (128, 64, 32):
+        if K % g == 0 and calculate_zeros_width(K, g) * 8 == group_rows:
+            return g
+    raise ValueError(f"awq_v2_ext.gemm_forward_cuda_prefill: cannot infer the group size from K={K} and "
+                     f"{group_rows} scale rows")
+
+
 def gemm_forward_cuda_prefill(x, qweight, scales, qzeros):
-    """gemv_fast.py:203-206: group size is implied by the shapes (K / number of used group rows is
-    not recoverable from padded tensors, so the layout's default 128 is assumed like the kernel)."""
+    """gemv_fast.py:203-206."""
     K, N = x.shape[-1], qweight.shape[0] * 4
     x2 = x.reshape(-1, K)
-    g = 128
+    g = infer_group_size(K, scales.shape[0])
     if x2.shape[0] <= 64 and N % 16 == 0:
         out = ops.gemv_fast_forward(x2, qweight, scales, qzeros, g)
     else:

@@ -80,7 +80,10 @@ __global__ __launch_bounds__(128) void awq_rope_kv_append_kernel(const half_t* _
                                                                 int Hkv, int D, int rot, int Tmax) {
     const int slot = blockIdx.x % (Hq + 2 * Hkv), tok = blockIdx.x / (Hq + 2 * Hkv);
     const int b = tok / S, s = tok % S;
-    const int pos = (pos_dev ? *pos_dev : start_pos) + s;
+    // A device-side position (hipGraph replay) is not seen by the host checks: clamp it to the cache so that a
+    // replay past max_seq_len overwrites the last row instead of memory behind the cache / the cos-sin tables
+    // (the caller is expected to roll the window before that: modules/fused/model.py).
+    const int pos = min((pos_dev ? *pos_dev : start_pos) + s, Tmax - 1);
     const int i = threadIdx.x;  // 0 .. D/2-1
     const half_t* src = qkv + (int64_t)tok * (Hq + 2 * Hkv) * D + (int64_t)slot * D;
     half_t* dst;
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
     const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 4, c = lane & 15;
-    const int T = (len_dev ? *len_dev : seq_len) + (FUSED ? 1 : 0);
+    // device-side lengths are clamped to the cache (see awq_rope_kv_append_kernel): never a row >= Tmax
+    const int T = max(1, min((len_dev ? *len_dev : seq_len) + (FUSED ? 1 : 0), Tmax));
     const int pos = T - 1;  // FUSED: the new token's position
     const int t0 = split * chunk, t1 = min(T, t0 + chunk);
 

@@ -101,7 +101,10 @@ class QuantAttentionFused(nn.Module):
         bsz, seqlen, _ = xqkv.shape
         self._resize_cache(bsz)
         device_pos = self._pos_dev is not None and seqlen == 1
-        if seqlen == 1 and self.head_dim == 128 and self.rotary_dim == 128 and self.FUSE_ROPE_INTO_ATTENTION:
+        # the hand-written decode kernels take head_dim 128 and 1, 2, 4 or 8 query heads per KV head; other
+        # shapes (e.g. 24 / 8 heads, 28 / 4) take the vendor path below instead of failing at the first decode step
+        native = self.head_dim == 128 and self.n_kv_groups in (1, 2, 4, 8)
+        if seqlen == 1 and native and self.rotary_dim == 128 and self.FUSE_ROPE_INTO_ATTENTION:
             # decode: rotation, cache append and attention in ONE launch (awq_decode_attention_rope)
             out = ops.decode_attention_rope(xqkv, self.cache.k, self.cache.v, self.rope.cos, self.rope.sin, self.start_pos,
                                             self.n_heads, self.n_kv_heads, pos_dev=self._pos_dev if device_pos else None,
@@ -128,7 +131,7 @@ class QuantAttentionFused(nn.Module):
                 out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
             output = out.transpose(1, 2).reshape(bsz, seqlen, -1)
         else:
-            if self.head_dim != 128:  # the hand-written kernel is specialised for 128; other sizes take the vendor path
+            if not native:  # the hand-written kernel is specialised (head_dim, GQA ratio); other shapes take the vendor path
                 k = self.cache.k[:bsz, : self.start_pos + 1].transpose(1, 2)
                 v = self.cache.v[:bsz, : self.start_pos + 1].transpose(1, 2)
                 if self.n_kv_groups > 1:

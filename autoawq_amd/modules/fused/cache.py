@@ -1,41 +1,59 @@
-"""WindowedCache (reference: awq/modules/fused/cache.py:4-79): fp16 K / V stores of shape
-[batch, max_seq_len, n_kv_heads, head_dim] that roll once max_seq_len is exceeded.  Device memory
-plumbing only; the kernels write rows through `ops.rope_kv_append` and read them through
-`ops.decode_attention`."""
+"""KV store of the fused attention block for MI355X.
+
+Role of `WindowedCache` (reference: awq/modules/fused/cache.py:4-79) with the same method surface --
+`get_kv`, `update_kv`, `roll_kv_n_steps`, `to`, `increase_batch_size`, `decrease_batch_size`, attributes
+`k`, `v`, `max_seq_len` -- but its own design:
+
+  * ONE allocation `kv[2, batch, max_seq_len, kv_heads, head_dim]` fp16; `k` / `v` are views of it (the
+    decode kernels take two base pointers, the sequence axis is dim 1 of each view: a cache row of one
+    (token, head) is 256 contiguous bytes, what `awq_decode_attention` reads per lane group);
+  * dropping the n oldest positions moves only the LIVE rows (`start_pos - n` of them) forward with one
+    strided device copy through a scratch of exactly that size.  The reference rolls and zero-fills the
+    whole buffer (two full-size copies per layer); rows at or past the new length are never read
+    (`awq_decode_attention` stops at the length), so nothing is cleared;
+  * batch-size changes keep the prefix of sequences that survive instead of discarding everything.
+"""
 import torch
 
 
 class WindowedCache:
     def __init__(self, cache_batch_size, n_heads, n_kv_heads, head_dim, max_seq_len, device):
-        size = (cache_batch_size, max_seq_len, n_kv_heads if n_kv_heads != 0 else n_heads, head_dim)
-        self.v = torch.zeros(size, device=device, dtype=torch.float16)
-        self.k = torch.zeros(size, device=device, dtype=torch.float16)
-        self.max_seq_len = max_seq_len
+        heads = n_kv_heads if n_kv_heads != 0 else n_heads
+        self.max_seq_len = int(max_seq_len)
+        self._alloc(int(cache_batch_size), heads, int(head_dim), device)
 
+    def _alloc(self, batch, heads, head_dim, device, keep=None):
+        kv = torch.zeros((2, batch, self.max_seq_len, heads, head_dim), dtype=torch.float16, device=device)
+        if keep is not None:
+            n = min(batch, keep.shape[1])
+            kv[:, :n] = keep[:, :n].to(device)
+        self.kv = kv
+        self.k, self.v = kv[0], kv[1]
+
+    # ---- reference surface -------------------------------------------------------------------
     def get_kv(self, batch_size, start_pos, seqlen):
-        return self.v[:batch_size, : start_pos + seqlen], self.k[:batch_size, : start_pos + seqlen]
+        end = start_pos + seqlen
+        return self.v[:batch_size, :end], self.k[:batch_size, :end]
 
     def update_kv(self, values_store, keys_store, batch_size, start_pos, seqlen):
-        self.v[:batch_size, start_pos: start_pos + seqlen, :, :] = values_store
-        self.k[:batch_size, start_pos: start_pos + seqlen, :, :] = keys_store
+        rows = slice(start_pos, start_pos + seqlen)
+        self.k[:batch_size, rows].copy_(keys_store)
+        self.v[:batch_size, rows].copy_(values_store)
 
     def roll_kv_n_steps(self, start_pos, n=100):
-        """Drop the n oldest positions (sequence axis = dim 1 of this layout) and zero the freed tail."""
-        n = min(n, self.max_seq_len)
-        self.v = torch.roll(self.v, shifts=-n, dims=1)
-        self.k = torch.roll(self.k, shifts=-n, dims=1)
-        self.v[:, -n:, :, :] = 0
-        self.k[:, -n:, :, :] = 0
-        return start_pos - n
+        """Forget the n oldest positions; returns the new start position (reference: cache.py:47-62)."""
+        n = max(0, min(int(n), int(start_pos), self.max_seq_len))
+        live = int(start_pos) - n
+        if n and live > 0:
+            moved = self.kv[:, :, n:n + live].clone()  # source and destination overlap: go through a scratch
+            self.kv[:, :, :live].copy_(moved)
+        return live
 
     def to(self, device):
-        self.k = self.k.to(device)
-        self.v = self.v.to(device)
+        self._alloc(self.kv.shape[1], self.kv.shape[3], self.kv.shape[4], device, keep=self.kv)
 
     def increase_batch_size(self, to_bsz):
-        self.v = torch.zeros(to_bsz, *self.v.shape[1:], dtype=self.v.dtype, device=self.v.device)
-        self.k = torch.zeros(to_bsz, *self.k.shape[1:], dtype=self.k.dtype, device=self.k.device)
+        self._alloc(int(to_bsz), self.kv.shape[3], self.kv.shape[4], self.kv.device, keep=self.kv)
 
     def decrease_batch_size(self, to_bsz):
-        self.v = self.v[:to_bsz].contiguous()
-        self.k = self.k[:to_bsz].contiguous()
+        self._alloc(int(to_bsz), self.kv.shape[3], self.kv.shape[4], self.kv.device, keep=self.kv)

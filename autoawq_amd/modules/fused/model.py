@@ -8,24 +8,50 @@ import torch
 import torch.nn as nn
 
 
+class StepPlan:
+    """What one `forward` call means for the caches: which ids are new, and how many cached positions every
+    block has to forget first.  Same policy as the reference (awq/utils/fused_utils.py:14-42 -- a new multi-token
+    context forgets everything cached, a decode step that would run past the window forgets the 100 oldest
+    positions; transformers >= 4.35 re-sends the whole context while decoding, only its last id is new), stated
+    as data instead of as two loops over the blocks."""
+
+    ROLL = 100
+
+    def __init__(self, input_ids, tokens_seen):
+        n = input_ids.shape[-1]
+        fresh = n if n == 1 else n - tokens_seen
+        if n != 1 and fresh == 1:
+            input_ids = input_ids[:, -1:]
+        self.input_ids = input_ids
+        self.tokens_seen = tokens_seen + fresh
+        self.seqlen = input_ids.shape[-1]
+
+    def forget(self, start_pos, max_seq_len):
+        """positions block must drop before this step, given its cache fill"""
+        over = start_pos + self.seqlen > max_seq_len
+        if self.seqlen > 1:
+            return start_pos if (over or start_pos > 0) else 0
+        return self.ROLL if over else 0
+
+    def apply(self, blocks):
+        for block in blocks:
+            a = block.attn
+            n = self.forget(a.start_pos, a.max_seq_len)
+            if n:
+                a.start_pos = a.cache.roll_kv_n_steps(a.start_pos, n=n)
+
+
 def prepare_cache(blocks, seqlen):
-    for block in blocks:
-        start_pos = block.attn.start_pos
-        exceeded = start_pos + seqlen > block.attn.max_seq_len
-        if seqlen > 1 and (exceeded or start_pos > 0):  # new context: drop what is cached
-            block.attn.start_pos = block.attn.cache.roll_kv_n_steps(start_pos, n=start_pos)
-        elif seqlen == 1 and exceeded:  # decoding past the window: roll 100 positions out
-            block.attn.start_pos = block.attn.cache.roll_kv_n_steps(start_pos, n=100)
+    """reference name (fused_utils.py:14-25), for callers that roll the caches themselves"""
+    plan = StepPlan.__new__(StepPlan)
+    plan.seqlen = seqlen
+    plan.apply(blocks)
 
 
 def prepare_input_ids(input_ids, last_forward_num_tokens):
-    num_input_tokens = input_ids.shape[-1]
-    num_new_tokens = num_input_tokens
-    if num_input_tokens != 1:
-        num_new_tokens = num_input_tokens - last_forward_num_tokens
-        if num_new_tokens == 1:  # transformers >= 4.35 passes the whole context while decoding
-            input_ids = input_ids[:, -1:]
-    return input_ids, last_forward_num_tokens + num_new_tokens
+    """reference name (fused_utils.py:28-42)"""
+    plan = StepPlan(input_ids, last_forward_num_tokens)
+    return plan.input_ids, plan.tokens_seen
 
 
 class LlamaLikeModel(nn.Module):
@@ -55,9 +81,9 @@ class LlamaLikeModel(nn.Module):
 
     @torch.inference_mode()
     def forward(self, input_ids, *args, **kwargs):
-        input_ids, self.last_forward_num_tokens = prepare_input_ids(input_ids, self.last_forward_num_tokens)
-        _bsz, seqlen = input_ids.shape
-        prepare_cache(self.blocks, seqlen)
+        plan = StepPlan(input_ids, self.last_forward_num_tokens)
+        input_ids, self.last_forward_num_tokens = plan.input_ids, plan.tokens_seen
+        plan.apply(self.blocks)
         h = self.embedding(input_ids)
         if self._stream_mode(h):
             x, ssq = None, None

@@ -44,25 +44,104 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_workspaces = {}
+_workspaces = {}   # (device index, stream handle) -> _Workspace
+_retired = []      # outgrown workspaces: a hipGraph captured earlier may still hold their pointers
+_retired_raw = []  # the same for the MoE / attention scratch tensors
+_CHECK_EVERY = 64  # calls between two asynchronous read-backs of a workspace's error word
+
+
+class _Workspace:
+    """One split-K workspace (control words + exchange + scratch) of one stream, with an asynchronous
+    watch on its error word: the kernels never hang -- a reducer that gives up waiting raises word 0
+    and uses what is there (csrc/gemv_mfma.hip) -- so somebody has to look at that word.  Every
+    `_CHECK_EVERY` calls a 4-byte device->pinned-host copy is queued behind the work; the next call
+    that finds the copy complete inspects it, re-initialises the workspace and raises."""
+
+    def __init__(self, device, nbytes):
+        self.buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        self.calls = 0
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+        self.init()
+
+    def init(self):
+        _lib.check(_lib.lib().awq_gemm_workspace_init(_ptr(self.buf), self.buf.numel(), _stream()), "awq_gemm_workspace_init")
+
+    def numel(self):
+        return self.buf.numel()
+
+    def poll(self):
+        """non-blocking: look at a finished read-back, start a new one now and then (never while capturing)"""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self.event is not None and self.event.query():
+            self.event = None
+            if int(self.host[0]) != 0:
+                self.host.zero_()
+                self.init()
+                raise _lib.AwqHipError("a split-K reducer gave up waiting for its partial sums on this workspace "
+                                       "(control word != 0): results since the last check are unreliable; the "
+                                       "workspace has been re-initialised")
+        self.calls += 1
+        if self.event is None and self.calls % _CHECK_EVERY == 0:
+            self.host.copy_(self.buf[:4].view(torch.int32), non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
 
 
 def workspace(device, nbytes):
     """Split-K workspace, one per (device, stream), grown on demand and prepared once by
-    awq_gemm_workspace_init (control words zero, exchange region = all-ones sentinel); every
-    kernel that uses it restores that state."""
+    awq_gemm_workspace_init (control words zero, exchange region = all-ones sentinel); every kernel
+    that uses it restores that state.  A workspace that has to grow is RETIRED, not freed: a hipGraph
+    captured earlier on the stream keeps replaying into the old buffer (`release_workspaces()` drops
+    them all once no such graph is alive)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _lib.check(_lib.lib().awq_gemm_workspace_init(_ptr(ws), ws.numel(), _stream()), "awq_gemm_workspace_init")
+        if ws is not None:
+            _retired.append(ws)
+        ws = _Workspace(device, nbytes)
         _workspaces[key] = ws
-    return ws
+    ws.poll()
+    return ws.buf
 
 
 def _current_workspace(device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
-    return _workspaces.get(key)
+    ws = _workspaces.get(key)
+    return None if ws is None else ws.buf
+
+
+def check_workspaces():
+    """Blocking form of the error watch: synchronises and raises if any workspace's error word is set
+    (after re-initialising it)."""
+    torch.cuda.synchronize()
+    bad = []
+    for key, ws in list(_workspaces.items()) + [(None, w) for w in _retired]:
+        if int(ws.buf[:4].view(torch.int32).item()) != 0:
+            bad.append(key)
+            with torch.cuda.device(ws.buf.device):
+                ws.init()
+    for d in (_moe_workspaces,):
+        for key, buf in d.items():
+            if int(buf[:4].view(torch.int32).item()) != 0:
+                bad.append(key)
+                with torch.cuda.device(buf.device):
+                    _lib.check(_lib.lib().awq_gemm_workspace_init(_ptr(buf), buf.numel(), _stream()), "awq_gemm_workspace_init")
+    torch.cuda.synchronize()
+    if bad:
+        raise _lib.AwqHipError(f"split-K error word set on workspace(s) {bad}: a reducer gave up waiting; re-initialised")
+
+
+def release_workspaces():
+    """Free every workspace (current and retired).  Only when no captured hipGraph that used them is
+    going to be replayed again."""
+    torch.cuda.synchronize()
+    _workspaces.clear()
+    _moe_workspaces.clear()
+    _attn_workspaces.clear()
+    del _retired[:]
+    del _retired_raw[:]
 
 
 def workspace_is_clean(device):
@@ -213,6 +292,8 @@ def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_
         key = (x.device.index, _stream())
         ws = _moe_workspaces.get(key)
         if ws is None or ws.numel() < need:
+            if ws is not None:
+                _retired_raw.append(ws)  # a captured graph may still replay into it
             ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
             _lib.check(L.awq_gemm_workspace_init(_ptr(ws), ws.numel(), _stream()), "awq_gemm_workspace_init")
             _moe_workspaces[key] = ws
@@ -318,11 +399,6 @@ def dequantize_weights_gemv_fast(qweight, scales, qzeros, group_size):
     return out
 
 
-def has_tiled_gemm():
-    """True once the fused LDS-tiled MFMA GEMM (large M) is built into the library."""
-    return True
-
-
 def last_kernel():
     return _lib.lib().awq_hip_last_kernel().decode()
 
@@ -379,6 +455,8 @@ def decode_attention(q, k_cache, v_cache, seq_len, scale=None, len_dev=None, max
     need = L.awq_decode_attention_workspace_bytes(B, Hq)
     ws = _attn_workspaces.get(key)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            _retired_raw.append(ws)
         ws = torch.empty(need, dtype=torch.uint8, device=q.device)
         _attn_workspaces[key] = ws
     if scale is None:
@@ -405,6 +483,8 @@ def decode_attention_rope(qkv, k_cache, v_cache, cos, sin, start_pos, n_heads, n
     need = L.awq_decode_attention_workspace_bytes(B, n_heads)
     ws = _attn_workspaces.get(key)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            _retired_raw.append(ws)
         ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
         _attn_workspaces[key] = ws
     if scale is None:

@@ -80,8 +80,34 @@ def test_input_id_and_cache_bookkeeping():
     assert c.k.shape == (2, 16, 2, 8)
     c.k[:, :, :, :] = torch.arange(16, dtype=torch.float16).reshape(1, 16, 1, 1)
     c.v[:] = c.k
+    assert c.k.data_ptr() == c.kv[0].data_ptr() and c.v.data_ptr() == c.kv[1].data_ptr()  # views of one allocation
+    # forget the 5 oldest of 12 cached positions: the 7 live rows move to the front (rows past the new length are
+    # never read by the attention kernels and are left as they are)
     assert c.roll_kv_n_steps(12, n=5) == 7
-    assert float(c.k[0, 0, 0, 0]) == 5.0 and float(c.k[0, 10, 0, 0]) == 15.0 and float(c.k[0, 11, 0, 0]) == 0.0
+    assert [float(c.k[1, t, 1, 3]) for t in range(7)] == [5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 11.0]
+    assert torch.equal(c.v[:, :7], c.k[:, :7])
+    assert c.roll_kv_n_steps(7, n=100) == 0 and c.roll_kv_n_steps(0, n=3) == 0
+    vv, kk = c.get_kv(2, 3, 2)
+    assert kk.shape == (2, 5, 2, 8) and vv.shape == (2, 5, 2, 8)
+    c.update_kv(torch.full((2, 2, 2, 8), 3.0, dtype=torch.float16), torch.full((2, 2, 2, 8), 4.0, dtype=torch.float16), 2, 3, 2)
+    assert float(c.k[1, 4, 0, 0]) == 4.0 and float(c.v[0, 3, 1, 7]) == 3.0 and float(c.k[0, 2, 0, 0]) == 7.0
+    c.increase_batch_size(3)   # surviving sequences keep their rows
+    assert c.k.shape == (3, 16, 2, 8) and float(c.k[1, 4, 0, 0]) == 4.0 and float(c.k[2, 0, 0, 0]) == 0.0
+    c.decrease_batch_size(1)
+    assert c.k.shape == (1, 16, 2, 8) and float(c.v[0, 3, 1, 7]) == 3.0
+
+
+def test_step_plan_policy():
+    """which ids are new and how much every block forgets (awq/utils/fused_utils.py:14-42)"""
+    from autoawq_amd.modules.fused.model import StepPlan
+
+    p = StepPlan(torch.arange(6).reshape(1, 6), 0)           # first prompt
+    assert p.seqlen == 6 and p.tokens_seen == 6 and p.forget(0, 16) == 0
+    p = StepPlan(torch.arange(7).reshape(1, 7), 6)           # whole context re-sent while decoding
+    assert p.seqlen == 1 and p.tokens_seen == 7 and int(p.input_ids[0, 0]) == 6
+    assert p.forget(6, 16) == 0 and p.forget(16, 16) == 100  # decode past the window: the 100 oldest go
+    p = StepPlan(torch.arange(5).reshape(1, 5), 20)          # a new, shorter context: everything cached goes
+    assert p.seqlen == 5 and p.forget(9, 16) == 9 and p.forget(0, 16) == 0
 
 
 def test_fused_module_surfaces():

@@ -16,7 +16,7 @@ fl = ops.gemm_flags(ops.KERNEL_TILED, nlog=1)
 ref = ops.gemm_forward(x, qw, s, qz, flags=fl).clone()
 bad = 0
 for it in range(int(os.environ.get("ITERS", "300"))):
-    ops._workspaces.clear()
+    ops.release_workspaces()
     if FRESH:
         torch.cuda.synchronize()
         torch.cuda.empty_cache()

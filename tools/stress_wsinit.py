@@ -17,7 +17,7 @@ firsts = {}
 bad = 0
 for it in range(400):
     for i, c in enumerate(cases):
-        ops._workspaces.clear()
+        ops.release_workspaces()
         # dirty the allocator's free blocks with finite floats, from a different set of CUs each time
         junk = torch.full((48 << 20,), 1.25 + it, dtype=torch.float32, device="cuda")
         junk2 = junk * 2
