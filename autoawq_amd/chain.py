@@ -89,6 +89,10 @@ class DecodeChain:
 
     __call__ = forward
 
+    @staticmethod
+    def grid_blocks():
+        return int(_lib.lib().awq_chain_grid_blocks())
+
     def status(self):
         """Synchronises the current stream; 0 = healthy, else the OR of give-up codes (bit 31: aborted)."""
         err = ctypes.c_uint32(0)

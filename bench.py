@@ -4,12 +4,19 @@
 Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 launched by
 torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 
-A "step" = one decode token through every int4 Linear of the model (the hot path): per layer
-qkv (fused, 4096->12288), o (4096->4096), gate+up (fused, 4096->22016), down (11008->4096), 32
-layers, batch 1, distinct random packed weights per layer (3.37 GB working set >> the 256 MiB
-Infinity Cache), captured in ONE hipGraph and replayed.  Inputs are resident in HBM before the
-timed region.  N > 1: the same model tensor-parallel over N GPUs (column-split qkv / gate+up,
-row-split o / down with one RCCL all-reduce each) -- strong scaling.
+A "step" = one decode token through every int4 Linear of the model (the hot path, BASELINE configs[1]):
+per layer qkv (fused, 4096->12288), o (4096->4096), gate+up (fused, 4096->22016), down (11008->4096), 32
+layers, batch 1, distinct random packed weights per layer (3.37 GB working set >> the 256 MiB Infinity Cache),
+captured in ONE hipGraph and replayed.  Inputs are resident in HBM before the timed region.  `value` is that
+leg and nothing else.  N > 1: the same model tensor-parallel over N GPUs (column-split qkv / gate+up,
+row-split o / down with one RCCL all-reduce each) -- strong scaling; `--model 70b` = BASELINE configs[3].
+
+Secondary objects on the same JSON line (N = 1, never `value`; each guarded so that the headline cannot
+depend on them): `sustained` (the same graph for >= 1 s), `gemm_bs` (configs[2]'s "bs=8 GEMM for 4096x11008":
+M = 1 .. 64, cold weights), `gemm_prefill` (configs[2]: M = 8 x 2048 = 16384, fused MFMA kernel vs HIP dequant
++ vendor GEMM, which one the module picks), `moe_bs4` (configs[4]), `decode_chain` (the same Linears as ONE
+persistent launch with true data dependencies, csrc/gemv_chain.hip), `whole_model` (the fused decoder), and
+`cpu_baseline` (the reference's CPU path restated in torch, per shape, M = 1 and 8, on this host's cores).
 """
 import argparse
 import json
@@ -23,8 +30,14 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured-achievable copy is 6290
-HIDDEN, INTER, LAYERS, GROUP = 4096, 11008, 32, 128
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); measured-achievable copy is 6290
+MFMA_PEAK_TF = 2500.0    # dense fp16 / bf16 MFMA (same file); AMD's 5 PF headline includes 2:1 sparsity
+GROUP = 128
+MODELS = {  # hidden, intermediate, layers, heads, kv heads
+    "7b": dict(hidden=4096, inter=11008, layers=32, heads=32, kv_heads=32, name="Llama-2-7B"),
+    "70b": dict(hidden=8192, inter=28672, layers=80, heads=64, kv_heads=8, name="Llama-3-70B"),
+}
+HIDDEN, INTER, LAYERS = 4096, 11008, 32  # the headline model (kept as names for tools/ that import them)
 
 
 def algorithmic_bytes(K, N, M, g, bias=False):
@@ -57,18 +70,20 @@ def rand_packed(K, N, g, dev, gen):
     return qw, qz, sc
 
 
-def build_model(dev, rank, world, layers, seed=1234, layout="gemm"):
-    """Per-rank shard shapes: column split of qkv / gate+up, whole-group row split of o / down."""
-    from autoawq_amd.tp import split_even_units
+def build_model(dev, rank, world, layers, seed=1234, layout="gemm", model="7b"):
+    """Per-rank shard shapes (autoawq_amd.tp.llama_layer_bounds): attention split by whole KV heads with the
+    query heads that attend to them, the MLP by whole quantisation groups of down's rows (uneven splits allowed:
+    Llama-2-7B has 86 groups)."""
+    from autoawq_amd.tp import llama_layer_bounds
 
+    cfg = MODELS[model]
+    H, I = cfg["hidden"], cfg["inter"]
+    hd = H // cfg["heads"]
+    b = llama_layer_bounds(cfg["heads"], cfg["kv_heads"], hd, I, GROUP, rank, world)
+    nq, nkv, ni = b["q"][1] - b["q"][0], b["kv"][1] - b["kv"][0], b["mlp"][1] - b["mlp"][0]
     gen = torch.Generator(device=dev).manual_seed(seed + rank)
-    # o_proj rows / qkv columns: split the 32 heads (128 columns each)
-    hs, hc = split_even_units(HIDDEN // 128, world)[rank]
-    # down rows: split the 86 groups; gate/up columns follow the same bounds
-    gs, gc = split_even_units(INTER // GROUP, world)[rank]
-    shapes = [("qkv", HIDDEN, 3 * hc * 128, False), ("o", hc * 128, HIDDEN, True),
-              ("gate_up", HIDDEN, 2 * gc * GROUP, False), ("down", gc * GROUP, HIDDEN, True)]
-    model = []
+    shapes = [("qkv", H, nq + 2 * nkv, False), ("o", nq, H, True), ("gate_up", H, 2 * ni, False), ("down", ni, H, True)]
+    net = []
     for _ in range(layers):
         layer = []
         for name, K, N, reduce_after in shapes:
@@ -79,8 +94,8 @@ def build_model(dev, rank, world, layers, seed=1234, layout="gemm"):
             x = torch.randn((1, K), device=dev, generator=gen).half()
             layer.append(dict(name=name, K=K, N=N, qw=qw, qz=qz, sc=sc, x=x, reduce=reduce_after and world > 1,
                               layout=layout))
-        model.append(layer)
-    return model, shapes
+        net.append(layer)
+    return net, shapes
 
 
 def run_step(model, outs, ops, dist):
@@ -99,30 +114,222 @@ def run_step(model, outs, ops, dist):
             i += 1
 
 
+def graph_time(fn, stream, reps, warm=2, min_seconds=0.0):
+    """us per call of fn(): captured once, replayed `reps` times (at least `min_seconds`), HIP events on `stream`."""
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            fn()
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            fn()
+        for _ in range(warm):
+            g.replay()
+        stream.synchronize()
+        total, n = 0.0, 0
+        while True:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                g.replay()
+            e1.record(stream)
+            e1.synchronize()
+            total += e0.elapsed_time(e1)
+            n += reps
+            if total >= min_seconds * 1e3:
+                break
+    del g
+    return total * 1e3 / n
+
+
+# ------------------------------------------------------------------------------------------ secondary legs
+
+def leg_gemm_bs(dev, ops):
+    """BASELINE configs[2] / north_star: "bs=8 GEMM for 4096x11008" -- HBM-bound (AI 30 flop/B): us per call over
+    distinct matrices (> 256 MiB of them, so nothing is served by the Infinity Cache), GB/s, fraction of 8 TB/s."""
+    K, N = 4096, 11008
+    gen = torch.Generator(device=dev).manual_seed(5)
+    nsets = 28  # 28 x 22.5 MB = 631 MB
+    sets = [rand_packed(K, N, GROUP, dev, gen) for _ in range(nsets)]
+    st = torch.cuda.Stream(device=dev)
+    out = {"shape": f"{K}x{N} g{GROUP}", "weights": f"{nsets} distinct matrices ({nsets * K * N // 2 / 1e6:.0f} MB), one call each per replay",
+           "unit": "us per call", "by_batch": {}}
+    for M in (1, 8, 16, 32, 64):
+        x = torch.randn((M, K), device=dev, generator=gen).half()
+
+        def fn():
+            for qw, qz, sc in sets:
+                ops.gemm_forward(x, qw, sc, qz)
+
+        us = graph_time(fn, st, reps=5) / nsets
+        by = algorithmic_bytes(K, N, M, GROUP)
+        out["by_batch"][str(M)] = {"us": us, "kernel": ops.last_kernel(),
+                                   "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": by / us / 1e3 / HBM_PEAK_GBS, "bytes_per_launch": by}}
+    out["bs8"] = out["by_batch"]["8"]
+    del sets
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_gemm_prefill(dev, ops):
+    """BASELINE configs[2]: bs=8 x seq=2048 -> M = 16384 on 4096x11008 (MFMA-bound, AI 2850 flop/B): the fused
+    dequant + MFMA kernel, the reference's own two-pass route (HIP dequant + vendor fp16 GEMM, gemm.py:48-54), and
+    what WQLinear_GEMM.forward dispatches to."""
+    from autoawq_amd import WQLinear_GEMM
+    from autoawq_amd.modules.linear import gemm as gemm_mod
+
+    K, N, M = 4096, 11008, 16384
+    gen = torch.Generator(device=dev).manual_seed(6)
+    qw, qz, sc = rand_packed(K, N, GROUP, dev, gen)
+    x = torch.randn((M, K), device=dev, generator=gen).half()
+    fl = 2.0 * M * K * N
+
+    def timeit(fn, reps=6):
+        fn()
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    us_f = timeit(lambda: ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2)))
+    us_2 = timeit(lambda: torch.matmul(x, ops.dequantize_weights(qw, sc, qz)))
+    mod = WQLinear_GEMM(4, GROUP, K, N, False, dev)
+    mod.qweight, mod.qzeros, mod.scales = qw, qz, sc
+    us_m = timeit(lambda: mod(x))
+    a = ops.gemm_forward(x[:256], qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2)).float()
+    b = torch.matmul(x[:256], ops.dequantize_weights(qw, sc, qz)).float()
+    rel = float((a - b).abs().max() / b.abs().max())
+    assert rel < 5e-3, f"fused prefill kernel disagrees with the two-pass route: {rel}"
+
+    def roof(us):
+        return {"bound": "mfma", "achieved": fl / us / 1e6, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / us / 1e6 / MFMA_PEAK_TF}
+
+    return {"shape": f"{K}x{N} g{GROUP}, M={M} (bs 8 x seq 2048)", "flops": fl,
+            "fused_mfma": {"us": us_f, "roofline": roof(us_f)}, "two_pass": {"us": us_2, "roofline": roof(us_2)},
+            "module": {"us": us_m, "roofline": roof(us_m), "route": "two_pass (HIP dequant + vendor fp16 GEMM)" if M >= gemm_mod.TWO_PASS_MIN_TOKENS
+                       else "fused_mfma", "two_pass_min_tokens": gemm_mod.TWO_PASS_MIN_TOKENS},
+            "fused_vs_two_pass_max_rel": rel}
+
+
+def leg_moe(dev):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_moe
+
+    r = bench_moe.run(dev=dev, verbose=False)
+    by, us = r["bytes"], r["us_per_block"]
+    return {"what": "Mixtral-8x7B-shape fused MoE MLP, bs=4, top-2 (BASELINE configs[4]); router excluded", "us_per_block": us,
+            "experts_hit": r["experts_hit"], "checked_against": r["checked_against"],
+            "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS,
+                         "bytes_per_block": by}}
+
+
+def leg_decode_chain(dev, ops, model, bytes_step):
+    """The headline Linears as ONE dependent chain: qkv -> o (reads q) -> gate|up -> down (reads the first 11008 columns;
+    a 128-link chain of random matrices with the quadratic silu * up in it blows up numerically) -> next qkv.  Timed both
+    as one persistent launch (csrc/gemv_chain.hip) and as one launch per Linear with the SAME data dependencies."""
+    from autoawq_amd.chain import ChainLink, DecodeChain
+
+    lins = [lin for layer in model for lin in layer]
+    x0 = lins[0]["x"]
+    x = x0
+    for lin in lins:  # unit gain per link, or fp16 overflows after a few layers
+        y = ops.gemm_forward(x[:, : lin["K"]].contiguous(), lin["qw"], lin["sc"], lin["qz"])
+        rms = float(y.float().pow(2).mean().sqrt())
+        lin["sc"].mul_(1.0 / max(rms, 1e-6))
+        x = ops.gemm_forward(x[:, : lin["K"]].contiguous(), lin["qw"], lin["sc"], lin["qz"])
+    y_last = torch.zeros((1, lins[-1]["N"]), dtype=torch.float16, device=dev)
+    links = [ChainLink(l["qw"], l["sc"], l["qz"], x=x0 if i == 0 else None, y=y_last if i == len(lins) - 1 else None)
+             for i, l in enumerate(lins)]
+    chain = DecodeChain(links, M=1)
+
+    def sequential():
+        t = x0
+        for l in lins:
+            t = ops.gemm_forward(t[:, : l["K"]], l["qw"], l["sc"], l["qz"])
+        return t
+
+    ref = sequential()
+    chain()
+    torch.cuda.synchronize()
+    st_ = chain.status()
+    err = float((y_last.float() - ref.float()).abs().max() / ref.float().abs().max())
+    assert st_ == 0 and err < 2e-2, f"persistent chain: status {st_:#x}, final output off by {err}"
+    st = torch.cuda.Stream(device=dev)
+    us_seq = graph_time(sequential, st, reps=10, min_seconds=0.3)
+    us_chain = graph_time(chain.forward, st, reps=10, min_seconds=0.3)
+    assert chain.status() == 0
+
+    def obj(us):
+        return {"ms_per_token": us / 1e3, "tok_s": 1e6 / us,
+                "roofline": {"bound": "hbm", "achieved": bytes_step / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": bytes_step / us / 1e3 / HBM_PEAK_GBS}}
+
+    return {"what": "the same 128 Linears with TRUE data dependencies (each consumes the previous one's output)",
+            "one_launch_per_linear": obj(us_seq), "persistent_chain": obj(us_chain), "final_output_max_rel_diff": err,
+            "links": len(links), "grid_blocks": chain.grid_blocks()}
+
+
+def leg_whole_model(dev):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_decode_model
+
+    wm = bench_decode_model.run(contexts=(64, 2048), steps=48, dev=dev, verbose=False, check=True)
+    return {"unit": "tok/s", "context_64": 1000.0 / wm[64], "context_2048": 1000.0 / wm[2048],
+            "what": "synthetic 7B-shape fused decoder (32 blocks + lm_head), one hipGraph per token; logits checked against "
+                    "the unfused module path before timing",
+            "published_reference": {"value": 198.848, "context": 64, "hardware": "RTX 4090", "source": "README.md:207 (BASELINE.md)"},
+            "vs_published_ctx64": (1000.0 / wm[64]) / 198.848}
+
+
 def cpu_baseline(layers_total):
-    """AutoAWQ's own CPU path (dequantize_gemm + fp16 matmul, awq/modules/linear/gemm.py:71-79)
-    restated in torch (oracle/awq_oracle.py, kind="port"), timed on this host's cores on a bounded
-    sample: the 4 Linears of ONE layer, median of 3 after one warm-up."""
+    """AutoAWQ's own CPU path (dequantize_gemm + fp16 matmul, awq/modules/linear/gemm.py:71-79) restated in torch
+    (oracle/awq_oracle.py, kind="port": /root/reference does not exist on the GPU box), on this host's cores.
+    SURVEY.md 8(d): per shape, M = 1 and M = 8, dequant and matmul apart, plus the cached-dequant variant (matmul
+    only).  Bounded sample: the three distinct Linear shapes of one layer, median of 3 after a warm-up."""
     from oracle import awq_oracle
 
     torch.set_num_threads(os.cpu_count() or 1)
     gen = torch.Generator().manual_seed(7)
-    lins = []
-    for K, N in [(HIDDEN, 3 * HIDDEN), (HIDDEN, HIDDEN), (HIDDEN, 2 * INTER), (INTER, HIDDEN)]:
+
+    def med(fn, n=3):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    per_shape = {}
+    for K, N in [(HIDDEN, HIDDEN), (HIDDEN, INTER), (INTER, HIDDEN)]:
         qw, qz, sc = rand_packed(K, N, GROUP, "cpu", gen)
-        lins.append((torch.randn((1, K), generator=gen).half(), qw, qz, sc))
-    times = []
-    for it in range(4):
-        t0 = time.perf_counter()
-        for x, qw, qz, sc in lins:
-            awq_oracle.torch_linear_gemm(x, qw, qz, sc, GROUP)
-        dt = time.perf_counter() - t0
-        if it:
-            times.append(dt)
-    layer_s = statistics.median(times)
-    return {"value": 1.0 / (layer_s * layers_total), "unit": "tok/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"4 Linears of 1 of {layers_total} layers, median of 3 ({layer_s:.2f} s/layer); "
-                                       "torch-CPU restatement of dequantize_gemm + fp16 matmul"}
+        t_dq = med(lambda: awq_oracle.torch_dequantize_gemm(qw, qz, sc, GROUP))
+        W = awq_oracle.torch_dequantize_gemm(qw, qz, sc, GROUP)
+        e = {"dequant_s": t_dq}
+        for M in (1, 8):
+            x = torch.randn((M, K), generator=gen).half()
+            e[f"matmul_M{M}_s"] = med(lambda: torch.matmul(x, W), n=5)
+            e[f"linear_M{M}_s"] = t_dq + e[f"matmul_M{M}_s"]
+        per_shape[f"{K}x{N}"] = e
+    a, b, c = (per_shape[f"{HIDDEN}x{HIDDEN}"], per_shape[f"{HIDDEN}x{INTER}"], per_shape[f"{INTER}x{HIDDEN}"])
+
+    def layer_s(key):  # q, k, v, o + gate, up + down: the reference calls seven Linears per layer on CPU (no fused qkv there)
+        return 4 * a[key] + 2 * b[key] + c[key]
+
+    return {"value": 1.0 / (layer_s("linear_M1_s") * layers_total), "unit": "tok/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"the 3 distinct Linear shapes of 1 of {layers_total} layers, median of 3 (dequant) / 5 (matmul); a layer = 4 x "
+                      f"{HIDDEN}x{HIDDEN} + 2 x {HIDDEN}x{INTER} + 1 x {INTER}x{HIDDEN} = {layer_s('linear_M1_s'):.2f} s; "
+                      "torch-CPU restatement of dequantize_gemm + fp16 matmul",
+            "per_shape": per_shape,
+            "tok_s_M8_per_sequence": 1.0 / (layer_s("linear_M8_s") * layers_total),
+            "cached_dequant_tok_s_M1": 1.0 / (layer_s("matmul_M1_s") * layers_total),
+            "cached_dequant_tok_s_M8_per_sequence": 1.0 / (layer_s("matmul_M8_s") * layers_total)}
 
 
 def main():
@@ -130,12 +337,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--layers", type=int, default=LAYERS, help="debug only; the metric is quoted at 32")
+    ap.add_argument("--model", choices=sorted(MODELS), default="7b", help="7b = BASELINE configs[1] (the metric); 70b = configs[3] (TP=8)")
+    ap.add_argument("--layers", type=int, default=0, help="debug only; the metric is quoted at the model's full depth")
     ap.add_argument("--layout", choices=["gemm", "gemv", "gemvfast"], default="gemm",
                     help="checkpoint format of the Linears: WQLinear_GEMM (default) / _GEMV / _GEMVFast buffers")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-model", action="store_true", help="skip the secondary whole-decoder figure")
+    ap.add_argument("--no-secondary", action="store_true", help="headline leg (and cpu_baseline) only")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,9 +365,11 @@ def main():
     from autoawq_amd import _lib, ops
 
     _lib.lib()
-    if world > 1 and a.layout != "gemm":
-        raise SystemExit("tensor-parallel shards are implemented for the GEMM layout")
-    model, shapes = build_model(dev, rank, world, a.layers, layout=a.layout)
+    cfg = MODELS[a.model]
+    layers = a.layers or cfg["layers"]
+    if world > 1 and a.layout == "gemvfast":
+        raise SystemExit("tensor-parallel shards are implemented for the GEMM and GEMV layouts")
+    model, shapes = build_model(dev, rank, world, layers, layout=a.layout, model=a.model)
     nl = sum(len(l) for l in model)
     outs = [None] * nl
     bytes_step = sum(algorithmic_bytes(l["K"], l["N"], 1, GROUP) for layer in model for l in layer)
@@ -166,7 +377,7 @@ def main():
         bytes_step += sum((l["K"] // GROUP) * l["N"] * 3 // 2 for layer in model for l in layer)
 
     stream = torch.cuda.Stream(device=dev)
-    graph, used_graph = None, False
+    graph, used_graph, capture_note = None, False, None
     with torch.cuda.stream(stream):
         for _ in range(max(a.warmup, 3) if a.no_graph else 3):
             run_step(model, outs, ops, dist)
@@ -177,9 +388,10 @@ def main():
                 with torch.cuda.graph(graph, stream=stream):
                     run_step(model, outs, ops, dist)
                 used_graph = True
-            except Exception as e:  # e.g. collective not capturable: fall back to eager launches
+            except Exception as e:  # e.g. collective not capturable: fall back to eager launches, and SAY so
+                capture_note = f"hipGraph capture failed ({type(e).__name__}: {str(e)[:200]}): every launch and all-reduce is issued eagerly"
                 if rank == 0:
-                    print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+                    print(f"[bench] {capture_note}", file=sys.stderr)
                 graph = None
         step = graph.replay if graph is not None else (lambda: run_step(model, outs, ops, dist))
         for _ in range(a.warmup):
@@ -196,6 +408,19 @@ def main():
         e1.synchronize()
         torch.cuda.synchronize()
         ms_total = e0.elapsed_time(e1)
+        sustained = None
+        if world == 1 and not a.no_secondary:  # the same replay for >= 1 s: a leg the GPU-busy sampler of the driver can see
+            t_end, n_sus = time.perf_counter() + 1.2, 0
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record(stream)
+            while time.perf_counter() < t_end:
+                for _ in range(50):
+                    step()
+                n_sus += 50
+                stream.synchronize()
+            s1.record(stream)
+            s1.synchronize()
+            sustained = (s0.elapsed_time(s1), n_sus)
     if dist is not None:
         t = torch.tensor([ms_total], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -214,48 +439,51 @@ def main():
         # dominant kernel = the fused int4 GEMV; the timed region holds nothing but its launches
         # (N=1), so its average launch duration (incl. inter-kernel gap) = step time / launches.
         achieved = (bytes_step / launches) / (ms_step * 1e-3 / launches) / 1e9  # this rank's GB/s
+        shape_txt = ", ".join(f"{n} {K}->{N}" for n, K, N, _ in shapes)
         out = {
-            "metric": "decode tok/s @bs=1 (int4 linears), 7B AWQ-int4 g128", "value": tok_s, "unit": "tok/s",
+            "metric": f"decode tok/s @bs=1 (int4 linears), {a.model.upper()} AWQ-int4 g128", "value": tok_s, "unit": "tok/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f16 (int4 weights, f32 accumulate)", "data": "synthetic",
-            "config": {"workload": "Llama-2-7B-shape AWQ int4 g128, GEMV bs=1 decode: 32 layers x "
-                                   "{qkv 4096->12288, o 4096->4096, gate+up 4096->22016, down 11008->4096}",
-                       "layers": a.layers, "launches_per_step": launches, "hipgraph": used_graph, "layout": a.layout,
+            "config": {"workload": f"{cfg['name']}-shape AWQ int4 g128, GEMV bs=1 decode: {layers} layers x {{{shape_txt}}}"
+                                   + (" per rank" if world > 1 else ""),
+                       "layers": layers, "launches_per_step": launches, "hipgraph": used_graph, "layout": a.layout,
                        "parallelism": f"tp{world}" if world > 1 else "single",
+                       "collectives_per_step": sum(1 for layer in model for l in layer if l["reduce"]),
                        "algorithmic_bytes_per_step_all_ranks": bytes_all, "kernel": ops.last_kernel()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         # HBM bytes per launch from the TCC fabric counters (own --pmc FETCH_SIZE pass,
-                         # x2 x 1024 per MI355X_MICROARCH.md; profiles/r01_pmc_fetch_size.txt), N=1 shapes
-                         "traffic": 26.980e6 if world == 1 and a.layers == LAYERS and a.layout == "gemm" else None,
+                         # HBM bytes per launch need the TCC fabric counters of a separate rocprofv3 --pmc pass
+                         # (MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950): not measurable from inside this process
+                         "traffic": None, "traffic_measured_in": "profiles/r02_pmc_fetch_size.txt (own --pmc FETCH_SIZE pass of this command)",
                          "bytes_per_launch": bytes_step / launches, "avg_launch_us": ms_step * 1e3 / launches,
                          "kernel": "awq_gemv_mfma_kernel (4 shapes per layer: qkv, o, gate+up, down)",
                          "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "
                                  "HIP-event-timed replay of the captured stream / launches, i.e. it contains the "
                                  "dispatch gap exactly as rocprofv3's back-to-back kernel durations do "
-                                 "(profiles/r01_bench_kernel_trace_stats.txt)"},
+                                 "(profiles/r02_bench_kernel_trace_stats.txt)"},
         }
-        if world == 1 and not a.no_whole_model and a.layers == LAYERS and a.layout == "gemm":
-            # secondary figure (never `value`): the same shape as a WHOLE decoder -- fused blocks with
-            # norms, RoPE + KV cache, attention, lm_head -- which is what the reference's README
-            # tables measure (Vicuna-7B GEMV, bs=1, ctx/gen 64: 198.848 tok/s on an RTX 4090)
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import bench_decode_model
-
-                del model, outs, graph
+        if capture_note:
+            out["config"]["capture_note"] = capture_note
+        if sustained is not None:
+            ms_s, n_s = sustained
+            out["sustained"] = {"seconds": ms_s / 1e3, "steps": n_s, "ms_per_step": ms_s / n_s, "tok_s": 1000.0 * n_s / ms_s,
+                                "GBps": bytes_step * n_s / ms_s / 1e6, "frac": bytes_step * n_s / ms_s / 1e6 / HBM_PEAK_GBS}
+        full = world == 1 and layers == cfg["layers"] and a.layout == "gemm" and a.model == "7b" and not a.no_secondary
+        if full:
+            del graph, outs
+            legs = [("gemm_bs", lambda: leg_gemm_bs(dev, ops)), ("gemm_prefill", lambda: leg_gemm_prefill(dev, ops)),
+                    ("moe_bs4", lambda: leg_moe(dev)), ("decode_chain", lambda: leg_decode_chain(dev, ops, model, bytes_step))]
+            if not a.no_whole_model:
+                legs.append(("whole_model", lambda: (model.clear(), torch.cuda.empty_cache(), leg_whole_model(dev))[2]))
+            for name, fn in legs:
+                try:
+                    out[name] = fn()
+                except Exception as e:  # the headline line must not depend on a secondary leg
+                    out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                 torch.cuda.empty_cache()
-                wm = bench_decode_model.run(contexts=(64, 2048), steps=48, dev=dev, verbose=False)
-                out["whole_model"] = {"unit": "tok/s", "context_64": 1000.0 / wm[64], "context_2048": 1000.0 / wm[2048],
-                                      "what": "synthetic 7B-shape fused decoder (32 blocks + lm_head), one hipGraph per token",
-                                      "published_reference": {"value": 198.848, "context": 64, "hardware": "RTX 4090",
-                                                              "source": "README.md:207 (BASELINE.md)"},
-                                      "vs_published_ctx64": (1000.0 / wm[64]) / 198.848}
-            except Exception as e:  # the headline line must not depend on this leg
-                out["whole_model"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.layers)
+            out["cpu_baseline"] = cpu_baseline(cfg["layers"])
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -13,8 +13,10 @@ sys.path.insert(0, ROOT)
 H, I, V, HEADS, G = 4096, 11008, 32000, 32, 128
 
 
-def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbose=True):
-    """Returns {context: ms_per_token}."""
+def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbose=True, check=True):
+    """Returns {context: ms_per_token}.  check: before timing, the logits of the five-launch stream path (norms folded
+    into the projections, fused RoPE + append + attention) must agree with the plain module path (separate norm, RoPE /
+    append, attention, o_proj, MLP launches) on the same weights and cache."""
     from autoawq_amd.fuser import FusedCausalLM
     from autoawq_amd.modules.fused.block import LlamaLikeBlock
     from autoawq_amd.modules.fused.mlp import QuantFusedMLP
@@ -58,6 +60,28 @@ def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbos
             blk.attn.cache.v.normal_(generator=gen)
         lm(tok)
         s.synchronize()
+        if check:
+            pos.fill_(40)
+            ln.fill_(41)
+            for blk in blocks:
+                blk.attn.start_pos = 40
+            fused = lm(tok).float().clone()
+            pos.fill_(40)
+            ln.fill_(41)
+            for blk in blocks:
+                blk.attn.start_pos = 40
+                blk.attn.use_device_positions(None, None)
+            saved = (LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS, type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION)
+            LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS = False
+            type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION = False
+            try:
+                plain = lm(tok).float()
+            finally:
+                LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS, type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION = saved
+            for blk in blocks:
+                blk.attn.use_device_positions(pos, ln)
+            rel = float((fused - plain).abs().max() / plain.abs().max())
+            assert rel < 3e-2, f"fused decode path differs from the plain module path by {rel}"
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=s):
             lm(tok)

@@ -1,60 +1,89 @@
 #!/usr/bin/env python3
 """BASELINE configs[4]: Mixtral-8x7B-shape AWQ int4 g128 fused MoE MLP, bs=4 decode on 1 MI355X.
 E=8, top-2, hidden 4096, inter 14336: w1|w3 stacked [8, 4096, 3584] i32, w2 [8, 14336, 512] i32.
-Reports us per MoE block (router excluded), bytes of the experts actually hit, GB/s."""
-import os, sys
+Reports us per MoE block (router excluded), bytes of the experts actually hit, GB/s -- after checking the block's
+output against the same experts run one (token, expert) pair at a time through the plain decode kernel."""
+import os
+import sys
+
 import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from autoawq_amd.modules.fused.moe import apply_moe_weights
-from bench import algorithmic_bytes
 
-dev = torch.device("cuda")
-gen = torch.Generator(device=dev).manual_seed(0)
 E, H, I, g, T, topk = 8, 4096, 14336, 128, 4, 2
-lim = 0x7FFFFFFF
 
 
 class Stack:
     pass
 
 
-def experts(K, N):
-    s = Stack()
-    s.qweight = torch.randint(-lim - 1, lim, (E, K, N // 8), dtype=torch.int32, device=dev, generator=gen)
-    s.qzeros = torch.randint(-lim - 1, lim, (E, K // g, N // 8), dtype=torch.int32, device=dev, generator=gen)
-    s.scales = (torch.rand((E, K // g, N), device=dev, generator=gen) * 0.02 + 0.005).half()
-    return s
+def run(dev=None, verbose=True, layers=2, reps=20):
+    from autoawq_amd import ops
+    from autoawq_amd.modules.fused.moe import apply_moe_weights
+    from bench import algorithmic_bytes
 
+    dev = dev or torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(0)
+    lim = 0x7FFFFFFF
 
-layers = [(experts(H, 2 * I), experts(I, H)) for _ in range(2)]  # 2 layers x 733 MB: defeats the 256 MiB L3
-x = torch.randn((T, H), device=dev, generator=gen).half()
-logits = torch.randn((T, E), device=dev, generator=gen)
-hit = len(set(torch.topk(torch.softmax(logits.float(), -1), topk, -1)[1].reshape(-1).tolist()))
-by = hit * (algorithmic_bytes(H, 2 * I, 1, g) + algorithmic_bytes(I, H, 1, g))
+    def experts(K, N):
+        s = Stack()
+        s.qweight = torch.randint(-lim - 1, lim, (E, K, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        s.qzeros = torch.randint(-lim - 1, lim, (E, K // g, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        s.scales = (torch.rand((E, K // g, N), device=dev, generator=gen) * 0.02 + 0.005).half()
+        return s
 
+    stacks = [(experts(H, 2 * I), experts(I, H)) for _ in range(layers)]  # 2 layers x 733 MB: defeats the 256 MiB L3
+    x = torch.randn((T, H), device=dev, generator=gen).half()
+    logits = torch.randn((T, E), device=dev, generator=gen)
+    w, ids = ops.fused_topk(logits, topk, True)
+    hit = len(set(ids.reshape(-1).tolist()))
+    by = hit * (algorithmic_bytes(H, 2 * I, 1, g) + algorithmic_bytes(I, H, 1, g))
 
-def step():
-    for w1, w2 in layers:
-        apply_moe_weights(w1, w2, x, logits, topk, True)
+    # correctness before timing: the block vs one (token, expert) pair at a time through awq_gemm_forward
+    w1, w2 = stacks[0]
+    got = apply_moe_weights(w1, w2, x, logits, topk, True).float()
+    want = torch.zeros((T, H), dtype=torch.float32, device=dev)
+    for t in range(T):
+        for j in range(topk):
+            e = int(ids[t, j])
+            gu = ops.gemm_forward(x[t:t + 1], w1.qweight[e], w1.scales[e], w1.qzeros[e])
+            d = ops.gemm_forward(ops.silu_and_mul(gu), w2.qweight[e], w2.scales[e], w2.qzeros[e])
+            want[t] += (float(w[t, j]) * d[0].float()).half().float()
+    rel = float((got - want).abs().max() / want.abs().max())
+    assert rel < 5e-3, f"MoE block differs from the per-pair computation by {rel}"
 
+    def step():
+        for a, b in stacks:
+            apply_moe_weights(a, b, x, logits, topk, True)
 
-s = torch.cuda.Stream()
-with torch.cuda.stream(s):
-    step(); step()
-    s.synchronize()
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr, stream=s):
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
         step()
-    gr.replay()
-    s.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s)
-    reps = 20
-    for _ in range(reps):
+        step()
+        s.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            step()
         gr.replay()
-    e1.record(s)
-    e1.synchronize()
-us = e0.elapsed_time(e1) * 1e3 / (reps * len(layers))
-print(f"Mixtral-8x7B-shape MoE MLP, bs={T}, top-{topk}, {hit} experts hit: {us:.1f} us per block "
-      f"({by / 1e6:.0f} MB of expert weights streamed -> {by / us / 1e3:.0f} GB/s, {by / us / 80e3:.1f}% of 8 TB/s); hipGraph-captured, no host reads")
+        s.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(reps):
+            gr.replay()
+        e1.record(s)
+        e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * len(stacks))
+    del gr, stacks
+    torch.cuda.empty_cache()
+    if verbose:
+        print(f"Mixtral-8x7B-shape MoE MLP, bs={T}, top-{topk}, {hit} experts hit: {us:.1f} us per block "
+              f"({by / 1e6:.0f} MB of expert weights streamed -> {by / us / 1e3:.0f} GB/s, {by / us / 80e3:.1f}% of 8 TB/s); "
+              f"hipGraph-captured, no host reads; output within {rel:.1e} of the per-pair computation")
+    return {"us_per_block": us, "bytes": by, "experts_hit": hit,
+            "checked_against": f"per-(token, expert) awq_gemm_forward calls, max rel diff {rel:.1e}"}
+
+
+if __name__ == "__main__":
+    run()
