@@ -16,6 +16,8 @@ import torch
 import torch.nn as nn
 
 from .modules.linear.gemm import WQLinear_GEMM
+from .modules.linear.gemv import WQLinear_GEMV
+from .utils.packing import GEMV_ORDER, calculate_zeros_width, pack_rows_int4
 
 
 def split_even_units(total_units, world):
@@ -42,6 +44,39 @@ def row_shard(qweight, qzeros, scales, k0, k1, group_size):
     return qweight[k0:k1].contiguous(), qzeros[g0:g1].contiguous(), scales[g0:g1].contiguous()
 
 
+# ---- the GEMV layout (qweight [N, K/8], qzeros [N, ZW], scales [N, 8 ZW]: awq/modules/linear/gemv.py:45-69)
+def column_shard_gemv(qweight, qzeros, scales, bias, n0, n1):
+    """Output columns are ROWS of every GEMV-layout buffer: a plain row slice, any n0 / n1."""
+    return (qweight[n0:n1].contiguous(), qzeros[n0:n1].contiguous(), scales[n0:n1].contiguous(),
+            None if bias is None else bias[n0:n1].contiguous())
+
+
+def row_shard_gemv(qweight, qzeros, scales, k0, k1, group_size):
+    """Input rows [k0, k1) (whole groups): the packed K words k0/8 .. k1/8 of every row, and the groups'
+    zero points / scales re-packed to the zeros width of the SHARD's in_features (the padding rule of
+    calculate_zeros_width depends on K, gemv.py:12-24)."""
+    assert k0 % group_size == 0 and k1 % group_size == 0, "row shards must be whole groups"
+    g0, g1 = k0 // group_size, k1 // group_size
+    N = qweight.shape[0]
+    zw = calculate_zeros_width(k1 - k0, group_size)
+    shifts = torch.arange(0, 32, 4, device=qzeros.device, dtype=torch.int32)
+    znib = ((qzeros.unsqueeze(-1) >> shifts) & 0xF).reshape(N, -1)[:, g0:g1]
+    zpad = torch.zeros((N, zw * 8), dtype=torch.int32, device=qzeros.device)
+    zpad[:, : g1 - g0] = znib
+    spad = torch.zeros((N, zw * 8), dtype=scales.dtype, device=scales.device)
+    spad[:, : g1 - g0] = scales[:, g0:g1]
+    return qweight[:, k0 // 8:k1 // 8].contiguous(), pack_rows_int4(zpad, GEMV_ORDER), spad
+
+
+def _module_from_gemv(qweight, qzeros, scales, bias, group_size):
+    N, K = qweight.shape[0], qweight.shape[1] * 8
+    m = WQLinear_GEMV(4, group_size, K, N, bias is not None, qweight.device)
+    m.qweight, m.qzeros, m.scales = qweight, qzeros, scales
+    if bias is not None:
+        m.bias = bias
+    return m
+
+
 def _module_from(qweight, qzeros, scales, bias, group_size):
     K, N = qweight.shape[0], qweight.shape[1] * 8
     m = WQLinear_GEMM(4, group_size, K, N, bias is not None, qweight.device)
@@ -52,9 +87,9 @@ def _module_from(qweight, qzeros, scales, bias, group_size):
 
 
 class ColumnParallelWQLinear(nn.Module):
-    """Holds this rank's output-column slice; forward returns the local slice (no collective)."""
+    """Holds this rank's output-column slice (GEMM or GEMV layout); forward returns the local slice (no collective)."""
 
-    def __init__(self, full: WQLinear_GEMM, rank, world, unit=8, bounds=None):
+    def __init__(self, full, rank, world, unit=8, bounds=None):
         super().__init__()
         N = full.out_features
         if bounds is None:
@@ -62,17 +97,21 @@ class ColumnParallelWQLinear(nn.Module):
             s, c = split_even_units(N // unit, world)[rank]
             bounds = (s * unit, (s + c) * unit)
         self.bounds = bounds
-        self.shard = _module_from(*column_shard(full.qweight, full.qzeros, full.scales, full.bias, *bounds),
-                                  full.group_size)
+        if isinstance(full, WQLinear_GEMV):
+            self.shard = _module_from_gemv(*column_shard_gemv(full.qweight, full.qzeros, full.scales, full.bias, *bounds),
+                                           full.group_size)
+        else:
+            self.shard = _module_from(*column_shard(full.qweight, full.qzeros, full.scales, full.bias, *bounds),
+                                      full.group_size)
 
     def forward(self, x):
         return self.shard(x)
 
 
 class RowParallelWQLinear(nn.Module):
-    """Holds this rank's input-row slice (whole groups); forward all-reduces the partial sums."""
+    """Holds this rank's input-row slice (whole groups; GEMM or GEMV layout); forward all-reduces the partial sums."""
 
-    def __init__(self, full: WQLinear_GEMM, rank, world, bounds=None, group=None):
+    def __init__(self, full, rank, world, bounds=None, group=None):
         super().__init__()
         g = full.group_size
         if bounds is None:
@@ -80,8 +119,12 @@ class RowParallelWQLinear(nn.Module):
             bounds = (s * g, (s + c) * g)
         self.bounds = bounds
         self.rank, self.world, self.group = rank, world, group
-        qw, qz, sc = row_shard(full.qweight, full.qzeros, full.scales, bounds[0], bounds[1], g)
-        self.shard = _module_from(qw, qz, sc, full.bias if rank == 0 else None, g)
+        if isinstance(full, WQLinear_GEMV):
+            qw, qz, sc = row_shard_gemv(full.qweight, full.qzeros, full.scales, bounds[0], bounds[1], g)
+            self.shard = _module_from_gemv(qw, qz, sc, full.bias if rank == 0 else None, g)
+        else:
+            qw, qz, sc = row_shard(full.qweight, full.qzeros, full.scales, bounds[0], bounds[1], g)
+            self.shard = _module_from(qw, qz, sc, full.bias if rank == 0 else None, g)
 
     def forward(self, x_local):
         y = self.shard(x_local)
@@ -122,6 +165,8 @@ def shard_llama_layer(q_proj, k_proj, v_proj, o_proj, gate_proj, up_proj, down_p
     b = llama_layer_bounds(n_heads, n_kv_heads, head_dim, gate_proj.out_features, down_proj.group_size, rank, world)
 
     def col(m, lo, hi):
+        if isinstance(m, WQLinear_GEMV):
+            return _module_from_gemv(*column_shard_gemv(m.qweight, m.qzeros, m.scales, m.bias, lo, hi), m.group_size)
         return _module_from(*column_shard(m.qweight, m.qzeros, m.scales, m.bias, lo, hi), m.group_size)
 
     return {

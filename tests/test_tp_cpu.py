@@ -129,3 +129,132 @@ def test_llama_layer_sharding_reproduces_the_unsharded_layer(oracle):
         assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())   # fp32 partial sums reordered
     with pytest.raises(ValueError):
         tp.llama_layer_bounds(heads, 3, D, I, g, 0, 2)
+
+
+# ------------------------------------------------------------------ the modules' own collective path
+
+def _oracle_forward_gemm(self, x):
+    """stand-in for the HIP kernels on a CPU-only box: WQLinear_GEMM.forward computed by the oracle (fp16 out)"""
+    from oracle import awq_oracle
+
+    x2 = x.reshape(-1, x.shape[-1]).half()
+    _, y16 = awq_oracle.linear_gemm(x2.numpy(), self.qweight.numpy(), self.qzeros.numpy(), self.scales.numpy(), self.group_size,
+                                    None if self.bias is None else self.bias.numpy())
+    return torch.from_numpy(y16).reshape(x.shape[:-1] + (self.out_features,))
+
+
+def _oracle_forward_gemv(self, x):
+    from oracle import awq_oracle
+
+    x2 = x.reshape(-1, x.shape[-1]).half()
+    W = awq_oracle.dequant_gemv(self.qweight.numpy(), self.qzeros.numpy(), self.scales.numpy(), self.group_size)
+    _, y16 = awq_oracle.matmul(x2.numpy(), W, None if self.bias is None else self.bias.numpy())
+    return torch.from_numpy(y16).reshape(x.shape[:-1] + (self.out_features,))
+
+
+def _module_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autoawq_amd import WQLinear_GEMM, WQLinear_GEMV, tp
+        from autoawq_amd.utils.convert import convert_linear
+        from oracle import awq_oracle
+
+        WQLinear_GEMM.forward = _oracle_forward_gemm   # the arithmetic of a shard: oracle; the collective: the module's own
+        WQLinear_GEMV.forward = _oracle_forward_gemv
+        gen = torch.Generator().manual_seed(9)          # same data on every rank
+        H, heads, kv_heads, D, I, g, M = 512, 8, 4, 64, 896, 128, 2   # 7 MLP groups over 2 ranks: 4 + 3
+        lim = 0x7FFFFFFF
+
+        def lin(K, N, bias=False):
+            m = WQLinear_GEMM(4, g, K, N, bias, "cpu")
+            m.qweight = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, generator=gen)
+            m.qzeros = torch.randint(-lim - 1, lim, (K // g, N // 8), dtype=torch.int32, generator=gen)
+            m.scales = (torch.rand((K // g, N), generator=gen) * 0.02 + 0.005).half()
+            if bias:
+                m.bias = torch.randn(N, generator=gen).half()
+            return m
+
+        qp, kp, vp, op = lin(H, heads * D), lin(H, kv_heads * D), lin(H, kv_heads * D), lin(heads * D, H, bias=True)
+        gate, up, down = lin(H, I), lin(H, I), lin(I, H, bias=True)
+        attn = torch.randn((M, heads * D), generator=gen).half()
+        act = torch.randn((M, I), generator=gen).half()
+        full_o, full_d = _oracle_forward_gemm(op, attn).float(), _oracle_forward_gemm(down, act).float()
+        res = {}
+        for layout in ("gemm", "gemv"):
+            mods = (qp, kp, vp, op, gate, up, down) if layout == "gemm" else tuple(convert_linear(m, "gemv") for m in (qp, kp, vp, op, gate, up, down))
+            sh = tp.shard_llama_layer(*mods, heads, kv_heads, D, rank, world)
+            b = sh["bounds"]
+            # RowParallelWQLinear.forward: local partial product, then ITS OWN dist.all_reduce (bias on rank 0 only)
+            yo = sh["o_proj"](attn[:, b["q"][0]:b["q"][1]]).float()
+            yd = sh["down_proj"](act[:, b["mlp"][0]:b["mlp"][1]]).float()
+            eo = float((yo - full_o).abs().max() / full_o.abs().max())
+            ed = float((yd - full_d).abs().max() / full_d.abs().max())
+            # column-parallel: the local slices gathered over ranks are the full projection, exactly
+            x = torch.randn((M, H), generator=torch.Generator().manual_seed(11)).half()
+            mine = sh["gate_proj"](x).float()
+            sizes = [(tp.llama_layer_bounds(heads, kv_heads, D, I, g, r, world)["mlp"]) for r in range(world)]
+            parts = [torch.empty((M, hi - lo), dtype=torch.float32) for lo, hi in sizes]
+            if len({p.shape for p in parts}) == 1:
+                dist.all_gather(parts, mine)
+            else:  # uneven shards: gather through a padded buffer
+                w = max(p.shape[1] for p in parts)
+                pad = [torch.zeros((M, w), dtype=torch.float32) for _ in range(world)]
+                mp_ = torch.zeros((M, w), dtype=torch.float32)
+                mp_[:, : mine.shape[1]] = mine
+                dist.all_gather(pad, mp_)
+                parts = [pad[r][:, : sizes[r][1] - sizes[r][0]] for r in range(world)]
+            full_g = (_oracle_forward_gemm(gate, x) if layout == "gemm" else _oracle_forward_gemv(mods[4], x)).float()
+            res[layout] = (eo, ed, bool(torch.equal(torch.cat(parts, 1), full_g)),
+                           (sh["o_proj"].shard.bias is not None) == (rank == 0), b["mlp"])
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_parallel_forward_and_layer_sharding_world2_gloo():
+    """World-size-2 gloo run THROUGH `RowParallelWQLinear.forward` and `shard_llama_layer` (GEMM and GEMV layouts):
+    the modules issue their own all-reduce; only the per-shard arithmetic is the oracle's (no GPU here)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_module_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        for layout, (eo, ed, col_ok, bias_ok, mlp_bounds) in r.items():
+            # fp16 partial products summed by the collective: a few fp16 ulps of the full product
+            assert eo < 4e-3 and ed < 4e-3, (rank, layout, eo, ed)
+            assert col_ok and bias_ok, (rank, layout)
+        assert r["gemm"][4] == ((0, 512) if rank == 0 else (512, 896))   # 7 groups over 2 ranks: 4 + 3
+
+
+def test_gemv_layout_row_shard_repacks_zero_width(oracle):
+    """A GEMV-layout row shard re-pads its zero points / scales to the SHARD's zeros width (11008 rows -> 11 words;
+    a 1408-row shard -> 2): dequantising the shard gives exactly the rows of the full matrix."""
+    from autoawq_amd import tp
+    from autoawq_amd.utils.packing import calculate_zeros_width
+
+    gen = torch.Generator().manual_seed(2)
+    K, N, g = 11008, 16, 128
+    G, zw = K // g, calculate_zeros_width(K, g)
+    lim = 0x7FFFFFFF
+    qw = torch.randint(-lim - 1, lim, (N, K // 8), dtype=torch.int32, generator=gen)
+    zn = torch.randint(0, 16, (N, zw * 8), dtype=torch.int32, generator=gen)
+    zn[:, G:] = 0
+    qz = torch.zeros((N, zw), dtype=torch.int32)
+    for i in range(8):
+        qz |= zn[:, i::8] << (4 * i)
+    sc = torch.zeros((N, zw * 8), dtype=torch.float16)
+    sc[:, :G] = (torch.rand((N, G), generator=gen) * 0.02 + 0.005).half()
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)          # [K, N]
+    for k0, k1 in ((0, 1408), (1408, 2816), (9728, 11008)):
+        q2, z2, s2 = tp.row_shard_gemv(qw, qz, sc, k0, k1, g)
+        assert z2.shape == (N, calculate_zeros_width(k1 - k0, g)) and s2.shape == (N, 8 * z2.shape[1])
+        assert np.array_equal(oracle.dequant_gemv(q2.numpy(), z2.numpy(), s2.numpy(), g).view(np.uint16), W[k0:k1].view(np.uint16))
