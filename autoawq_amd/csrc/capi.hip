@@ -226,6 +226,16 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
 
 }  // namespace
 
+int awq_gemm_workspace_status(const void* workspace, void* stream, int32_t* err_out) {
+    if (!workspace || !err_out) return AWQ_ERR_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t word = 0;
+    if (hipMemcpyAsync(&word, workspace, sizeof(word), hipMemcpyDeviceToHost, st) != hipSuccess) return AWQ_ERR_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return AWQ_ERR_LAUNCH;
+    *err_out = word;
+    return AWQ_OK;
+}
+
 /* ---- fused MLP / MoE ------------------------------------------------------------------- */
 
 int awq_silu_and_mul(const uint16_t* gate_up, uint16_t* out, int64_t rows, int64_t d, void* stream) {

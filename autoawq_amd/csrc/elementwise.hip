@@ -128,3 +128,4 @@ int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int*
                        num_post_pad, T, E, k, renorm, block, P + E * (block - 1), P + E);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
+

@@ -58,7 +58,7 @@ constexpr int NWAVES = 1 + NCWB + NPW;
 constexpr int NTHR = NWAVES * 64;
 constexpr int SLOT_BYTES = 17 * 1024;   // ring slot: 16 KiB of packed weights (128 rows x 128 bytes) + 128 B zeros + 512 B scales
 __host__ __device__ constexpr int ring_slots(int M) {  // what the fold / staging areas leave of 160 KiB, at most 8
-    const int n = (160 * 1024 - 256 - NCWB * M * (CW + 8) * 4 - UPB * (M + 1) * 256) / SLOT_BYTES;
+    const int n = (160 * 1024 - 256 - NCWB * M * (CW + 8) * 4 - 2 * UPB * (M + 1) * 256) / SLOT_BYTES;
     return n > 8 ? 8 : n;
 }
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -185,7 +185,8 @@ AWQ_DEV SlabRange slab_range(const ChainLinkDev& P, int M, int col) {
 // lanes of a quad.  Ranges with !on[r] request nothing.  All ranges are read in the SAME round trips.
 template <int NR>
 AWQ_DEV void gather_ranges(const ChainLinkDev& P, rsrc_t slres, int M, int m, const int (&col)[NR], const bool (&on)[NR],
-                           uint32_t stag, half4_t (&out)[NR], unsigned& spins, ChainCtrl* ctrl, uint32_t code, int lane) {
+                           uint32_t stag, half4_t (&out)[NR], unsigned& spins, ChainCtrl* ctrl, uint32_t code, int lane,
+                           unsigned long long* t_loaded = nullptr) {
     const int qd = lane & 31, sh = lane >> 5;
     const uint32_t sstride = (uint32_t)M * 2048u;
     int S[NR];
@@ -235,6 +236,7 @@ AWQ_DEV void gather_ranges(const ChainLinkDev& P, rsrc_t slres, int M, int m, co
             if (all) break;
             if (give_up(spins, ctrl, code, lane)) break;
         }
+        if (t_loaded) *t_loaded = wall_clock64();
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -315,7 +317,7 @@ template <int NREG>
 __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const ChainHeader* __restrict__ plan, unsigned char* __restrict__ ws) {
     constexpr int CWP = CW + 8;  // LDS row pitch of the fold area (floats)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS: ring[NS][SLOT_BYTES] | red[NCWB][M][CWP] fp32 | xs[UPB][M + 1][128] fp16 | control words
+    // dynamic LDS: ring[NS][SLOT_BYTES] | red[NCWB][M][CWP] fp32 | xs[2][UPB][M + 1][128] fp16 (by link parity) | control words
     const int M = (int)plan->M;
     const int G = (int)plan->G;
     const int n_links = (int)plan->n_links;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
     unsigned char* const ring = smem;
     float* red = reinterpret_cast<float*>(smem + (size_t)NS * SLOT_BYTES);
     half_t* xs_all = reinterpret_cast<half_t*>(reinterpret_cast<unsigned char*>(red) + (size_t)NCWB * M * CWP * 4);
-    uint32_t* lds_ctl = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(xs_all) + (size_t)UPB * (M + 1) * 128 * 2);
+    uint32_t* lds_ctl = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(xs_all) + (size_t)2 * UPB * (M + 1) * 128 * 2);
     uint32_t* const fold_cnt = lds_ctl + 1;   // [2] arrivals per fold group (monotonic)
     uint32_t* const fold_done = lds_ctl + 3;  // [2] folds completed per group (monotonic)
     uint32_t* const lds_abort = lds_ctl + 5;  // set by a wave that gave up: everybody in the block stops waiting
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
         const u64 a = __hip_atomic_fetch_add(&ctrl->arrive[b & 7], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lds_ctl[0] = (uint32_t)(a / (u64)(G >> 3)) + 1u;  // epoch of this launch
     }
-    for (int i = tid; i < UPB * 128; i += NTHR) xs_all[((i >> 7) * (M + 1) + M) * 128 + (i & 127)] = (half_t)0.f;  // the all-zero row M
+    for (int i = tid; i < 2 * UPB * 128; i += NTHR) xs_all[((i >> 7) * (M + 1) + M) * 128 + (i & 127)] = (half_t)0.f;  // the all-zero rows M
     __syncthreads();
     const uint32_t epoch = lds_ctl[0];
     const uint32_t tag_hi = epoch << 10;
@@ -468,11 +470,12 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
                 stamp(l, 0);
                 unsigned spins = 0;
 #pragma unroll
-                for (int i = 0; i < UPP; ++i)  // the waves of the unit have finished reading what was staged for their previous link
+                for (int i = 0; i < UPP; ++i)  // the staging rows alternate by link parity: the waves of the unit are done with link l - 2
 #pragma unroll
                     for (int h = 0; h < WPU; ++h)
-                        while (has[i] && lds_ld(&xdone[WPU * (pw * UPP + i) + h]) != (uint32_t)l)
+                        while (has[i] && (int)lds_ld(&xdone[WPU * (pw * UPP + i) + h]) < l - 1)
                             if (give_up(spins, ctrl, 8u, lane)) break;
+                half_t* const xs_l = xs_all + (size_t)(l & 1) * UPB * (M + 1) * 128;
                 if (L.xflags & XF_SLABS) {
                     const ChainLinkDev& P = links[L.prod];
                     const uint32_t stag = tag_hi | (uint32_t)(P.out_id + 1);
@@ -490,7 +493,9 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
                     stamp(l, 1);
                     for (int m = 0; m < M; ++m) {
                         half4_t xv[UPP];
-                        gather_ranges<UPP>(P, slres, M, m, col, has, stag, xv, spins, ctrl, 1u, lane);
+                        unsigned long long t_ld = 0;
+                        gather_ranges<UPP>(P, slres, M, m, col, has, stag, xv, spins, ctrl, 1u, lane, trace ? &t_ld : nullptr);
+                        if (trace && lane == 0 && m == 0) trace[(((size_t)l * G + b) * NWAVES + wave) * 4 + 3] = t_ld;
                         if (gated) {  // silu(gate) * up in fp32, one rounding: == awq_silu_and_mul_kernel
                             half4_t up[UPP];
                             gather_ranges<UPP>(P, slres, M, m, colu, has, stag, up, spins, ctrl, 1u, lane);
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
 #pragma unroll
                         for (int i = 0; i < UPP; ++i)
                             if (has[i] && sh == 0)
-                                *reinterpret_cast<u32x2*>(xs_all + ((size_t)(pw * UPP + i) * (M + 1) + m) * 128 + 4 * qd) =
+                                *reinterpret_cast<u32x2*>(xs_l + ((size_t)(pw * UPP + i) * (M + 1) + m) * 128 + 4 * qd) =
                                     __builtin_bit_cast(u32x2, xv[i]);
                     }
                 } else {
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
                     for (int i = 0; i < UPP; ++i)
                         for (int m = 0; m < M; ++m)
                             if (has[i])
-                                *reinterpret_cast<uint32_t*>(xs_all + ((size_t)(pw * UPP + i) * (M + 1) + m) * 128 + 2 * lane) =
+                                *reinterpret_cast<uint32_t*>(xs_l + ((size_t)(pw * UPP + i) * (M + 1) + m) * 128 + 2 * lane) =
                                     *reinterpret_cast<const uint32_t*>(L.x + (size_t)m * L.x_stride + kg[i] * 128 + 2 * lane);
                 }
                 if (spins >= 64u && ld_abort(ctrl)) lds_st(lds_abort, 1u);
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
     const int cw = wave - 1;
     const int ui = cw / WPU, hf = cw % WPU;  // unit of the block, part of the unit (sets hf * SETS / WPU ...)
     const int j = lane & 15, kb = lane >> 4;
-    half_t* xs = xs_all + (size_t)ui * (M + 1) * 128;  // the unit's activation rows [M + 1][128]
+    half_t* const xs0 = xs_all + (size_t)ui * (M + 1) * 128;  // the unit's activation rows [M + 1][128], parity 0
     float* myred = red + (size_t)cw * M * CWP;
 
     const uint32_t sel_lo = (j & 1) ? 0x01000C0Cu : 0x0C0C0100u;  // low half of a dword -> slot (j & 1)
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
                 unsigned long long t0 = 0;
                 while (lds_ld(&ready[slot]) != f + 1u)
                     if (give_up_lds(spins, lds_abort, t0, ctrl, 32u, lane)) break;
-                while (lds_ld(&xflag[ui]) != (uint32_t)(l + 1))
+                while (lds_ld(&xflag[ui]) < (uint32_t)(l + 1))  // the poll wave may already be a link ahead
                     if (give_up_lds(spins, lds_abort, t0, ctrl, 16u, lane)) break;
             }
             stamp(l, 1);
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
             float4_t accsx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
-            const half_t* xlane = xs + arow * 128 + 4 * kb + (128 / WPU) * hf;
+            const half_t* xlane = xs0 + (size_t)(l & 1) * UPB * (M + 1) * 128 + arow * 128 + 4 * kb + (128 / WPU) * hf;
             const unsigned char* wl = wb + ((128 / WPU) * hf + 4 * kb) * 128 + j * 8;  // this lane's 8 bytes of row 4 kb of the wave's first set
 #pragma unroll
             for (int t = 0; t < SETS / WPU; ++t) {
@@ -725,7 +730,7 @@ DevInfo dev_info() {
 }
 
 size_t chain_lds_bytes(int M) {
-    return (size_t)ring_slots(M) * SLOT_BYTES + (size_t)NCWB * M * (CW + 8) * 4 + (size_t)UPB * (M + 1) * 128 * 2 + 256;
+    return (size_t)ring_slots(M) * SLOT_BYTES + (size_t)NCWB * M * (CW + 8) * 4 + (size_t)2 * UPB * (M + 1) * 128 * 2 + 256;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -79,6 +79,11 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
                      int64_t N, int64_t group_size, void* workspace, size_t workspace_bytes,
                      uint32_t flags, void* stream);
 
+/* The kernels never hang: a split-K reducer that gives up waiting for its partial sums raises control word 0 of the
+ * workspace and uses what is there.  awq_gemm_workspace_status copies that word to the host (synchronises `stream`);
+ * non-zero = results since the last check are unreliable: call awq_gemm_workspace_init again. */
+AWQ_EXPORT int awq_gemm_workspace_status(const void* workspace, void* stream, int32_t* err_out);
+
 /* flags for awq_gemm_forward: bits 0-3 kernel family, bits 4-7 lane geometry, bits 8-15 split-K */
 #define AWQ_GEMM_KERNEL_AUTO 0u
 #define AWQ_GEMM_KERNEL_NAIVE 1u     /* one thread per output, reference-order loop (checker / odd shapes) */

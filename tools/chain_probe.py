@@ -118,11 +118,11 @@ def main():
             return "      -            " if v.size == 0 else f"{us(v.min()):7.2f} {us(np.median(v)):7.2f} {us(v.max()):7.2f}"
 
         print("us since first stamp: min / median / max over waves (wave 0 loader, 1-6 compute, 7-9 poll)")
-        print("link | loader starts link   || compute: start       | weights + x ready    | mfma done            | folded / slab stored || poll: start          | slabs probed         | x staged")
+        print("link | loader starts link   || compute: start       | weights + x ready    | mfma done            | folded / slab stored || poll: start          | slabs probed         | gather loads back    | x staged")
         for l in range(min(tr.shape[0], a.trace_links)):
             ld, c, pl = tr[l][:, 0], tr[l][:, 1:7], tr[l][:, 7:]
             print(f"{l:4d} | " + stat(ld[..., 0]) + " || " + " | ".join(stat(c[..., k]) for k in range(4)) + " || " +
-                  " | ".join(stat(pl[..., k]) for k in range(3)))
+                  " | ".join(stat(pl[..., k]) for k in (0, 1, 3, 2)))
         return
     if a.no_time or st:
         return
