@@ -66,7 +66,8 @@ struct GemvMfmaParams {
     int tiles, S;
     int rows_per_block;  // K slice per block: a whole number of 16*UNIT-row units
     int ng_max;          // groups a slice can touch (sizes the LDS staging area)
-    int two_pass;
+    int combine;         // split-K combine: 0 one reducer block per tile, 1 two-pass (plain slabs, a second kernel reduces),
+                         // 2 / 3: two / four reducer blocks per tile
     // ---- grouped (MoE) mode: one 16-row token block per blockIdx / (tiles*S), each with its own
     // expert's weights (awq/modules/fused/moe.py:60-89).  All null / 0 in the plain mode.
     const int* sorted_ids;    // [nblk*16] (token, expert) pair index per row, >= num_pairs = padding
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         emit_ssq(ss);
         return;
     }
-    if (p.two_pass) {  // plain fp32 slabs [S][M][N]; a second kernel reduces
+    if (NREG == 4 ? p.combine == 1 : p.combine != 0) {  // plain fp32 slabs [S][M][N]; a second kernel reduces
         for (int qd = tid; qd < quads; qd += NWAVES * 64) {
             const int m = qd / (CW / 4), col = col0 + (qd % (CW / 4)) * 4;
             if (col < p.N)
@@ -508,64 +509,146 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     // The exchange region is kept filled with a sentinel (all bits set, a NaN no arithmetic here
     // produces).  A producer block stores its fp32 partial tile with 16-byte write-through stores
     // and exits: no drain, no flag, no ticket -- every aligned 4-byte word is its own "ready"
-    // signal, so torn 16-byte stores are harmless.  The block of the LAST K slice of a tile is its
-    // reducer: it polls the other slices' words with agent-scope (sc1) loads until none is the
-    // sentinel, adds them in slice order (bitwise reproducible), adds its own partial last,
-    // writes fp16 and re-arms the words it consumed.  Producers never wait; reducers are the last
-    // blocks in dispatch order, their spin is bounded and raises *err instead of hanging.
+    // signal, so torn 16-byte stores are harmless.  The blocks of the LAST R K slices of a tile are
+    // its reducers (R = 1 up to four batch rows, 2 or 4 above), each for 1/R of the tile's quads: a
+    // reducer stores its partial for the quads the others own, polls the other slices' words of ITS
+    // quads with agent-scope (sc1) loads until none is the sentinel, adds all S partials in slice
+    // order (bitwise reproducible, and independent of R), writes fp16 and re-arms the words it
+    // consumed.  One reducer per tile spent 2.8 us (M = 8) to 5 us (M = 16) of serial polling over
+    // 512 / 1024 quads (profiles/r01_gemv_phase_trace_by_m.txt); R of them take one round trip each.
+    // Producers never wait; the reducers are the last blocks in dispatch order and wait only for
+    // producers and for reducers dispatched BEFORE or right after them (R x tiles <= 256 blocks, so
+    // every one of them gets a slot while the others spin); every spin is bounded and raises *err
+    // instead of hanging.  The R = 1 path is kept as its own, older code: routed through the general
+    // loop below the M = 1 launches lose 5 % (producer phase 0.24 -> 0.40 us, r02 trace A/B).
     constexpr uint32_t SENT = 0xFFFFFFFFu, QNAN = 0x7FC00000u;
     const uint32_t slab_bytes = (uint32_t)quads * 16u;
-    const uint32_t tb0 = (uint32_t)tblk * (uint32_t)(S - 1) * (uint32_t)p.tiles;  // this token block's slabs
-    const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)((gridDim.x / (p.tiles * S)) * (S - 1)) * (uint32_t)p.tiles * slab_bytes);
-    if (slice != S - 1) {
-        for (int qd = tid; qd < quads; qd += NWAVES * 64) {
-            u32x4 b = __builtin_bit_cast(u32x4, block_sum4(qd));
+    // NOTE: the statements of the one-reducer path below are deliberately left exactly as they were tuned: this
+    // kernel's M = 1 time moves by 1-2 % with source-neutral rearrangements here (r02 A/B: an extra `if` around it,
+    // S instead of S - 1 in the two lines below: 866 -> 846 / 854 tok/s on the headline), code placement, not work.
+    if (NREG != 4 || p.combine == 0) {  // ---- one reducer: the block of the tile's LAST K slice (its own partial never leaves the block)
+        const uint32_t tb0 = (uint32_t)tblk * (uint32_t)(S - 1) * (uint32_t)p.tiles;  // this token block's slabs: [S-1][tiles]
+        const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)((gridDim.x / (p.tiles * S)) * (S - 1)) * (uint32_t)p.tiles * slab_bytes);
+        if (slice != S - 1) {
+            for (int qd = tid; qd < quads; qd += NWAVES * 64) {
+                u32x4 b = __builtin_bit_cast(u32x4, block_sum4(qd));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b[e] = (b[e] == SENT) ? QNAN : b[e];
-            // soffset must stay the constant 0 on 16-byte buffer stores (see gemm_tiled.hip: with
-            // an SGPR soffset no wait states are inserted before the data VGPRs are rewritten)
-            __builtin_amdgcn_raw_buffer_store_b128(b, slres, (uint32_t)qd * 16u + (tb0 + (uint32_t)(slice * p.tiles + tile)) * slab_bytes,
-                                                   0, 16 /* sc1 */);
+                for (int e = 0; e < 4; ++e) b[e] = (b[e] == SENT) ? QNAN : b[e];
+                // soffset must stay the constant 0 on 16-byte buffer stores (see gemm_tiled.hip: with
+                // an SGPR soffset no wait states are inserted before the data VGPRs are rewritten)
+                __builtin_amdgcn_raw_buffer_store_b128(b, slres, (uint32_t)qd * 16u + (tb0 + (uint32_t)(slice * p.tiles + tile)) * slab_bytes,
+                                                       0, 16 /* sc1 */);
+            }
+            AWQ_STAMP(4);
+            return;
         }
-        AWQ_STAMP(4);
+        const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+        float ssq_acc = 0.f;
+        for (int qd = tid; qd < quads; qd += NWAVES * 64) {
+            const float4_t own = block_sum4(qd);
+            float4_t s = {0.f, 0.f, 0.f, 0.f};
+            for (int sl0 = 0; sl0 < S - 1; sl0 += 8) {  // 8 independent 16-byte loads in flight per poll
+                u32x4 v[8];
+                for (unsigned spins = 0;; ++spins) {
+                    uint32_t pending = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)  // slices past S-1 are requested out of range: zeros, no traffic
+                        v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                             slres, (sl0 + u < S - 1) ? (uint32_t)qd * 16u : OOB,
+                                                             (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes, 16));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        pending |= (v[u][0] == SENT) | (v[u][1] == SENT) | (v[u][2] == SENT) | (v[u][3] == SENT);
+                    if (!pending) break;
+                    if (spins > (1u << 18)) {  // give up: flag the error, use what is there
+                        *p.err = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += __builtin_bit_cast(float4_t, v[u]);  // fixed order: bitwise reproducible
+#pragma unroll
+                for (int u = 0; u < 8; ++u)  // re-arm (write-through; also drops the line from this XCD's L2)
+                    if (sl0 + u < S - 1)
+                        __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, (uint32_t)qd * 16u + (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes,
+                                                               0, 16);
+            }
+            ssq_acc += emit4(qd, s + own);
+        }
+        emit_ssq(ssq_acc);
+        AWQ_STAMP(5);
         return;
     }
-    const u32x4 sent4 = {SENT, SENT, SENT, SENT};
-    float ssq_acc = 0.f;
-    for (int qd = tid; qd < quads; qd += NWAVES * 64) {
-        const float4_t own = block_sum4(qd);
-        float4_t s = {0.f, 0.f, 0.f, 0.f};
-        for (int sl0 = 0; sl0 < S - 1; sl0 += 8) {  // 8 independent 16-byte loads in flight per poll
-            u32x4 v[8];
-            for (unsigned spins = 0;; ++spins) {
-                uint32_t pending = 0;
+    if constexpr (NREG == 4) {  // batch rows > 1 only: the M = 1 instantiations do not carry this code
+        const uint32_t tb0 = (uint32_t)tblk * (uint32_t)S * (uint32_t)p.tiles;  // this token block's slabs: [S][tiles]
+        const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)((gridDim.x / (p.tiles * S)) * S) * (uint32_t)p.tiles * slab_bytes);
+        // Reducer ranges are whole 64-quad blocks (quads = 64 M with 256-column tiles), so a wave is either all
+        // "store" or all "reduce" in an iteration; a reducer walks the quads starting AFTER its own range, i.e.
+        // stores everything the other reducers wait for before it starts waiting itself.
+        const int rlog = p.combine - 1;           // 2 or 4 reducers (a shift: an integer division here costs every block ~0.3 us)
+        const int ridx = slice - (S - (1 << rlog));   // >= 0: this block reduces quads [q0, q1)
+        const int q64 = quads >> 6;
+        const int q0 = ridx >= 0 ? ((q64 * ridx) >> rlog) << 6 : quads;
+        const int q1 = ridx >= 0 ? (ridx + 1 == (1 << rlog) ? quads : ((q64 * (ridx + 1)) >> rlog) << 6) : quads;
+        const int start = q1 >= quads ? 0 : q1;
+        const uint32_t my_slab = (tb0 + (uint32_t)(slice * p.tiles + tile)) * slab_bytes;
+        const u32x4 sent4 = {SENT, SENT, SENT, SENT};
+        float ssq_acc = 0.f;
+        for (int i = tid; i < quads; i += NWAVES * 64) {
+            int qd = start + i;
+            if (qd >= quads) qd -= quads;
+            u32x4 own = __builtin_bit_cast(u32x4, block_sum4(qd));
+            if (qd < q0 || qd >= q1) {  // somebody else reduces this quad
 #pragma unroll
-                for (int u = 0; u < 8; ++u)  // slices past S-1 are requested out of range: zeros, no traffic
-                    v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                         slres, (sl0 + u < S - 1) ? (uint32_t)qd * 16u : OOB,
-                                                         (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes, 16));
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    pending |= (v[u][0] == SENT) | (v[u][1] == SENT) | (v[u][2] == SENT) | (v[u][3] == SENT);
-                if (!pending) break;
-                if (spins > (1u << 18)) {  // give up: flag the error, use what is there
-                    *p.err = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+                for (int e = 0; e < 4; ++e) own[e] = (own[e] == SENT) ? QNAN : own[e];
+                // soffset must stay the constant 0 on 16-byte buffer stores (see gemm_tiled.hip: with
+                // an SGPR soffset no wait states are inserted before the data VGPRs are rewritten)
+                __builtin_amdgcn_raw_buffer_store_b128(own, slres, (uint32_t)qd * 16u + my_slab, 0, 16 /* sc1 */);
+                continue;
             }
+            float4_t s = {0.f, 0.f, 0.f, 0.f};
+            // the S - 1 OTHER slices, k = 0 .. S-2 -> slice k + (k >= own): no poll round is spent on this block's own slot
+            for (int k0 = 0; k0 < S - 1; k0 += 8) {  // 8 independent 16-byte loads in flight per poll
+                u32x4 v[8];
+                uint32_t soff[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += __builtin_bit_cast(float4_t, v[u]);  // fixed order: bitwise reproducible
+                for (int u = 0; u < 8; ++u)  // wave-uniform by construction; say so, or the loads are wrapped in waterfall loops
+                    soff[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tb0 + (uint32_t)((k0 + u + (k0 + u >= slice ? 1 : 0)) * p.tiles + tile)) * slab_bytes));
+                for (unsigned spins = 0;; ++spins) {
+                    uint32_t pending = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)  // re-arm (write-through; also drops the line from this XCD's L2)
-                if (sl0 + u < S - 1)
-                    __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, (uint32_t)qd * 16u + (tb0 + (uint32_t)((sl0 + u) * p.tiles + tile)) * slab_bytes,
-                                                           0, 16);
+                    for (int u = 0; u < 8; ++u)  // past the last slice: requested out of range, zeros and no traffic
+                        v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(slres, (k0 + u < S - 1) ? (uint32_t)qd * 16u : OOB, soff[u], 16));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        pending |= (v[u][0] == SENT) | (v[u][1] == SENT) | (v[u][2] == SENT) | (v[u][3] == SENT);
+                    if (!pending) break;
+                    if (spins > (1u << 18)) {  // give up: flag the error, use what is there
+                        *p.err = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {  // slice order, this block's own partial at its place: bitwise reproducible for every R
+                    if (k0 + u == slice && k0 + u < S - 1) s += __builtin_bit_cast(float4_t, own);
+                    s += __builtin_bit_cast(float4_t, v[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)  // re-arm (write-through; also drops the line from this XCD's L2)
+                    if (k0 + u < S - 1) __builtin_amdgcn_raw_buffer_store_b128(sent4, slres, (uint32_t)qd * 16u + soff[u], 0, 16);
+            }
+            if (slice == S - 1) s += __builtin_bit_cast(float4_t, own);
+            ssq_acc += emit4(qd, s);
         }
-        ssq_acc += emit4(qd, s + own);
+        if (ridx < 0) {
+            AWQ_STAMP(4);
+            return;
+        }
+        emit_ssq(ssq_acc);
+        AWQ_STAMP(5);
     }
-    emit_ssq(ssq_acc);
-    AWQ_STAMP(5);
 }
 
 // y[m, n] = fp16( sum_s slabs[s, m, n] + bias[n] )   (two-pass mode)
@@ -671,6 +754,18 @@ struct GemvCfg {
     size_t lds;
 };
 
+// log2 of the reducer blocks per tile.  Reducers wait for each other, so all of them must be able to be resident at the same
+// time whatever else runs: at most one per CU of the smallest part this may run on.  The per-tile sum of squares
+// (ssq_out) wants the whole tile in one block.
+int reducers_per_tile(int S, int tile_blocks, int M, bool whole_tile) {
+    // up to 4 batch rows one block reduces a tile in a single round (256 quads) and extra reducers only add stores and
+    // waiting: 4096 x 11008, M = 1: 8.9 -> 10.1 us with four; M = 8: 13.2 -> 12.7, M = 16: 18.0 -> 15.5
+    if (whole_tile || M <= 4 || S < 2 || tile_blocks < 1) return 0;
+    int rlog = 0;
+    while (rlog < 2 && (2 << rlog) <= S && (2 << rlog) * tile_blocks <= 256) ++rlog;
+    return rlog;  // log2 of the count
+}
+
 size_t gemv_lds_bytes(int M, int CW, int nwaves, int rows_per_block, int ng_max) {
     const size_t staging = (size_t)(M + 1) * rows_per_block * 2 + (size_t)ng_max * (CW / 2 + 2 * CW);
     const size_t red = (size_t)nwaves * M * (CW + 16) * 4;
@@ -733,7 +828,7 @@ bool gemv_config(const AwqGemmArgs& a, bool two_pass, GemvCfg& c) {
     if (c.S > 1) {  // keep the slabs inside the workspace the caller gave us
         const size_t per_slice = (two_pass ? (size_t)M * N : (size_t)tiles * M * CW) * sizeof(float);
         const size_t have = two_pass ? a.partial_floats * sizeof(float) : a.exchange_bytes;
-        const size_t fit = have / per_slice + (two_pass ? 0 : 1);  // the reducer's own slice is not stored
+        const size_t fit = have / per_slice;  // every slice has a slab (the reducers store what the others reduce)
         if ((size_t)c.S > fit) return false;
     }
     return true;
@@ -760,7 +855,7 @@ void launch_moe(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) 
 size_t awq_grouped_workspace_bytes_impl(int max_blocks, int K, int N) {
     (void)K;
     const size_t tiles = (size_t)(N + 255) / 256;
-    return (size_t)AWQ_WS_COUNTER_BYTES + (size_t)max_blocks * 7 * tiles * 16 * 256 * 4;  // S <= 8
+    return (size_t)AWQ_WS_COUNTER_BYTES + (size_t)max_blocks * 8 * tiles * 16 * 256 * 4;  // S <= 8
 }
 
 int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const int* expert_ids, const int* num_post_pad,
@@ -796,7 +891,7 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
         if (S >= units || S >= 64) return AWQ_ERR_UNSUPPORTED;
     }
     if (c.S > 1) {
-        const size_t need = (size_t)max_blocks * (c.S - 1) * tiles * a.M * CW * sizeof(float);
+        const size_t need = (size_t)max_blocks * c.S * tiles * a.M * CW * sizeof(float);
         if (!a.exchange || !a.counters || a.exchange_bytes < need) return AWQ_ERR_WORKSPACE;
     }
     GemvMfmaParams p;
@@ -816,9 +911,10 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
     p.tiles = tiles; p.S = c.S;
+    const int rlog = reducers_per_tile(c.S, tiles * max_blocks, a.M, a.ssq_out != nullptr);
     p.rows_per_block = c.rows_per_block;
     p.ng_max = c.ng_max;
-    p.two_pass = 0;
+    p.combine = rlog ? 1 + rlog : 0;
     p.slabs = a.exchange;
     p.scratch = nullptr;
     p.err = a.counters;
@@ -865,9 +961,10 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
     p.tiles = tiles; p.S = c.S;
+    const int rlog = reducers_per_tile(c.S, tiles, a.M, a.ssq_out != nullptr);
     p.rows_per_block = c.rows_per_block;
     p.ng_max = c.ng_max;
-    p.two_pass = two_pass ? 1 : 0;
+    p.combine = two_pass ? 1 : (rlog ? 1 + rlog : 0);
     p.slabs = a.exchange;
     p.scratch = a.partial;
     p.err = a.counters;

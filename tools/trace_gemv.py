@@ -26,7 +26,10 @@ def build():
 
 
 if __name__ == "__main__":
-    build()
+    if os.environ.get("AWQ_TRACE_LIB"):  # a prebuilt trace library (A/B of two kernel versions)
+        OUT = os.environ["AWQ_TRACE_LIB"]
+    else:
+        build()
     if "--build-only" in sys.argv:
         sys.exit(0)
     import ctypes
