@@ -69,6 +69,7 @@ SIGNATURES = {
     "awq_dequantize_weights_gemv_fast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                                  c_void_p]),
     "awq_gemm_workspace_status": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "awq_gemm_auto_kernel": (c_int, [c_int64, c_int64, c_int64, c_int64]),
     "awq_chain_plan_bytes": (c_size_t, [c_int64]),
     "awq_chain_grid_blocks": (c_int, []),
     "awq_chain_build": (c_int, [ctypes.POINTER(AwqChainLink), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,

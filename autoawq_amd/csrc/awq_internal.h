@@ -48,6 +48,9 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
 // Fused dequant + LDS-tiled MFMA GEMM, any M (meant for M > 16).  bn: block tile width (128|256, 0 = auto).
 bool awq_gemm_tiled_supports(int M, int K, int N, int g);
 int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk);
+// Prefill GEMM with the weight operand decoded in registers (gemm_regb.hip).  bm: rows per block tile (128|256, 0 = auto).
+bool awq_gemm_regb_supports(int M, int K, int N, int g);
+int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm);
 // GEMV layout (qweight [N, K/8], qzeros [N, ZW], scales [N, 8*ZW]): MFMA GEMV, M <= 16, and the
 // bit-exact dequant to W^T [N, K].  nwaves (4|8|16) / unroll (4|8): 0 = auto.
 bool awq_gemv_nk_supports(int M, int K, int N, int g);

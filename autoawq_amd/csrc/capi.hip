@@ -138,6 +138,15 @@ int awq_gemm_forward_ex(const AwqGemmEx* e) {
 }
 
 namespace {
+// M > 16.  The register-decoded prefill kernel wins once its 128 x 256 tiles give every CU a block (r02 sweep,
+// profiles/r02_regb_by_m.txt: 4096 x 11008 from M = 768, 11008 x 4096 from M = 2048); below that the LDS-tiled kernel with
+// split-K (smaller tiles, in-launch combine) fills the chip better.
+unsigned auto_kernel_large(int M, int K, int N, int g) {
+    if (awq_gemm_regb_supports(M, K, N, g) && (int64_t)((M + 127) / 128) * ((N + 255) / 256) >= 256) return AWQ_GEMM_KERNEL_REGB;
+    if (awq_gemm_tiled_supports(M, K, N, g)) return AWQ_GEMM_KERNEL_TILED;
+    return AWQ_GEMM_KERNEL_NAIVE;  // odd shapes
+}
+
 int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                       const uint16_t* bias, uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size,
                       void* workspace, size_t workspace_bytes, uint32_t flags, void* stream, const NormArgs* nrm) {
@@ -196,8 +205,7 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
             }
         }
         if (a.x_gated || extras) return AWQ_ERR_UNSUPPORTED;
-        if (M > 16 && awq_gemm_tiled_supports(a.M, a.K, a.N, a.g)) kern = AWQ_GEMM_KERNEL_TILED;
-        else kern = AWQ_GEMM_KERNEL_NAIVE;  // odd shapes
+        kern = auto_kernel_large(a.M, a.K, a.N, a.g);
     }
     switch (kern) {
         case AWQ_GEMM_KERNEL_NAIVE:
@@ -219,12 +227,22 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
             g_last_kernel = "gemm_tiled";
             return awq_launch_gemm_tiled(a, nlog == 2 ? 256 : (nlog == 1 ? 128 : 0), splitk);
         }
+        case AWQ_GEMM_KERNEL_REGB: {
+            g_last_kernel = "gemm_regb";
+            return awq_launch_gemm_regb(a, nlog == 2 ? 256 : (nlog == 1 ? 128 : 0));
+        }
         default:
             return AWQ_ERR_UNSUPPORTED;
     }
 }
 
 }  // namespace
+
+int awq_gemm_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size) {
+    if (M <= 0 || K <= 0 || N <= 0 || M > INT32_MAX || check_gemm_layout(K, N, group_size)) return -1;
+    if (M <= 16 && awq_gemv_mfma_supports((int)M, (int)K, (int)N, (int)group_size, 2)) return AWQ_GEMM_KERNEL_MFMA_GEMV;
+    return (int)auto_kernel_large((int)M, (int)K, (int)N, (int)group_size);
+}
 
 int awq_gemm_workspace_status(const void* workspace, void* stream, int32_t* err_out) {
     if (!workspace || !err_out) return AWQ_ERR_NULL;

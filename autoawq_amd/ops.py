@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 # kernel-selection flags (mirror include/awq_hip.h)
-KERNEL_AUTO, KERNEL_NAIVE, KERNEL_VALU, KERNEL_MFMA_GEMV, KERNEL_TILED = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_NAIVE, KERNEL_VALU, KERNEL_MFMA_GEMV, KERNEL_TILED, KERNEL_REGB = 0, 1, 2, 3, 4, 5
 FLAG_TWO_PASS = 1 << 16
 FLAG_NO_NT = 1 << 17
 
@@ -397,6 +397,11 @@ def dequantize_weights_gemv_fast(qweight, scales, qzeros, group_size):
         _lib.check(_lib.lib().awq_dequantize_weights_gemv_fast(_ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(out), K, N,
                                                                group_size, _stream()), "awq_dequantize_weights_gemv_fast")
     return out
+
+
+def auto_kernel(M, K, N, group_size):
+    """KERNEL_* the AUTO dispatch of gemm_forward takes for this shape (host-only query, no launch)."""
+    return _lib.lib().awq_gemm_auto_kernel(M, K, N, group_size)
 
 
 def last_kernel():

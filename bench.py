@@ -173,11 +173,11 @@ def leg_gemm_bs(dev, ops):
 
 
 def leg_gemm_prefill(dev, ops):
-    """BASELINE configs[2]: bs=8 x seq=2048 -> M = 16384 on 4096x11008 (MFMA-bound, AI 2850 flop/B): the fused
-    dequant + MFMA kernel, the reference's own two-pass route (HIP dequant + vendor fp16 GEMM, gemm.py:48-54), and
-    what WQLinear_GEMM.forward dispatches to."""
+    """BASELINE configs[2]: bs=8 x seq=2048 -> M = 16384 on 4096x11008 (MFMA-bound, AI 2850 flop/B), and M = 4096 / 8192 next
+    to it: the fused register-decoded kernel (csrc/gemm_regb.hip, what awq_gemm_forward's AUTO dispatch runs at these
+    sizes), the LDS-tiled fused kernel of round 1, the reference's own two-pass route (HIP dequant + vendor fp16 GEMM,
+    gemm.py:48-54), and what WQLinear_GEMM.forward dispatches to."""
     from autoawq_amd import WQLinear_GEMM
-    from autoawq_amd.modules.linear import gemm as gemm_mod
 
     K, N, M = 4096, 11008, 16384
     gen = torch.Generator(device=dev).manual_seed(6)
@@ -197,23 +197,33 @@ def leg_gemm_prefill(dev, ops):
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
 
-    us_f = timeit(lambda: ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2)))
+    us_f = timeit(lambda: ops.gemm_forward(x, qw, sc, qz))
+    kernel = ops.last_kernel()
+    us_t = timeit(lambda: ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2)))
     us_2 = timeit(lambda: torch.matmul(x, ops.dequantize_weights(qw, sc, qz)))
     mod = WQLinear_GEMM(4, GROUP, K, N, False, dev)
     mod.qweight, mod.qzeros, mod.scales = qw, qz, sc
     us_m = timeit(lambda: mod(x))
-    a = ops.gemm_forward(x[:256], qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2)).float()
-    b = torch.matmul(x[:256], ops.dequantize_weights(qw, sc, qz)).float()
+    a = ops.gemm_forward(x[:2048], qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_REGB)).float()
+    b = torch.matmul(x[:2048], ops.dequantize_weights(qw, sc, qz)).float()
     rel = float((a - b).abs().max() / b.abs().max())
     assert rel < 5e-3, f"fused prefill kernel disagrees with the two-pass route: {rel}"
+    by_m = {}
+    for m in (4096, 8192):
+        xs = x[:m]
+        f = 2.0 * m * K * N
+        uf, u2 = timeit(lambda: ops.gemm_forward(xs, qw, sc, qz)), timeit(lambda: torch.matmul(xs, ops.dequantize_weights(qw, sc, qz)))
+        by_m[str(m)] = {"fused_us": uf, "fused_tflops": f / uf / 1e6, "two_pass_us": u2, "two_pass_tflops": f / u2 / 1e6}
 
     def roof(us):
         return {"bound": "mfma", "achieved": fl / us / 1e6, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / us / 1e6 / MFMA_PEAK_TF}
 
     return {"shape": f"{K}x{N} g{GROUP}, M={M} (bs 8 x seq 2048)", "flops": fl,
-            "fused_mfma": {"us": us_f, "roofline": roof(us_f)}, "two_pass": {"us": us_2, "roofline": roof(us_2)},
-            "module": {"us": us_m, "roofline": roof(us_m), "route": "two_pass (HIP dequant + vendor fp16 GEMM)" if M >= gemm_mod.TWO_PASS_MIN_TOKENS
-                       else "fused_mfma", "two_pass_min_tokens": gemm_mod.TWO_PASS_MIN_TOKENS},
+            "fused_mfma": {"us": us_f, "kernel": kernel, "roofline": roof(us_f)},
+            "fused_lds_tiled_r01": {"us": us_t, "roofline": roof(us_t)}, "two_pass": {"us": us_2, "roofline": roof(us_2)},
+            "module": {"us": us_m, "roofline": roof(us_m),
+                       "route": "fused (gemm_regb)" if ops.auto_kernel(M, K, N, GROUP) == ops.KERNEL_REGB else "two_pass (HIP dequant + vendor fp16 GEMM)"},
+            "other_token_counts": by_m,
             "fused_vs_two_pass_max_rel": rel}
 
 

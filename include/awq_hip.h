@@ -83,6 +83,10 @@ AWQ_EXPORT int awq_gemm_forward(const uint16_t* x, const int32_t* qweight, const
  * workspace and uses what is there.  awq_gemm_workspace_status copies that word to the host (synchronises `stream`);
  * non-zero = results since the last check are unreliable: call awq_gemm_workspace_init again. */
 AWQ_EXPORT int awq_gemm_workspace_status(const void* workspace, void* stream, int32_t* err_out);
+/* Which AWQ_GEMM_KERNEL_* the AUTO dispatch of awq_gemm_forward takes for this shape (-1: invalid shape).  Host code that
+ * keeps its own alternative for large M (dequantise + vendor GEMM, awq/modules/linear/gemm.py:48-54) asks this to know
+ * whether the fused prefill kernel (AWQ_GEMM_KERNEL_REGB) would run. */
+AWQ_EXPORT int awq_gemm_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size);
 
 /* flags for awq_gemm_forward: bits 0-3 kernel family, bits 4-7 lane geometry, bits 8-15 split-K */
 #define AWQ_GEMM_KERNEL_AUTO 0u
@@ -90,6 +94,7 @@ AWQ_EXPORT int awq_gemm_workspace_status(const void* workspace, void* stream, in
 #define AWQ_GEMM_KERNEL_VALU 2u      /* wave64 VALU GEMV, reference-order fp16 dequant + fp32 FMA, M <= 4 */
 #define AWQ_GEMM_KERNEL_MFMA_GEMV 3u /* MFMA 16x16x32 streaming GEMV / skinny GEMM, M <= 16 */
 #define AWQ_GEMM_KERNEL_TILED 4u     /* LDS-tiled MFMA GEMM with fused dequant, large M */
+#define AWQ_GEMM_KERNEL_REGB 5u      /* MFMA GEMM, weights decoded in registers, activations by LDS-DMA: prefill (NLOG: 1 = 128-, 2 = 256-row tile) */
 #define AWQ_GEMM_FLAG_KERNEL(f) ((f)&0xFu)
 #define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto; VALU: log2 column lanes (2..4); MFMA_GEMV: words per lane (2|4); TILED: 1 = 128-, 2 = 256-column tile */
 #define AWQ_GEMM_FLAG_SPLITK(f) (((f) >> 8) & 0xFFu) /* 0 = auto */

@@ -197,6 +197,40 @@ def test_tiled_gemm_vs_oracle(ops, oracle, K, N, g, M, bn):
     assert diff.numel() == 0, f"one-hot rows differ at {diff[:48].tolist()} ({diff.shape[0]} elements)"
 
 
+@pytest.mark.parametrize("K,N,g", [(512, 256, 128), (1024, 384, 64), (256, 136, 64), (4096, 512, 128), (2048, 2048, 2048), (192, 264, 192)])
+@pytest.mark.parametrize("M", [17, 128, 300, 1000])
+@pytest.mark.parametrize("bm", [1, 2])
+def test_regb_gemm_vs_oracle(ops, oracle, K, N, g, M, bm):
+    """Prefill GEMM with the weight operand decoded in registers (csrc/gemm_regb.hip): the same numerics as the
+    reference's dequantise-then-matmul (exact fp16 weights, fp32 accumulation) -- against the oracle with bias, ragged
+    M and N tiles, groups of 64 / 128 / 192 / K rows; row-exact against the bit-exact dequantised W with one-hot
+    activations (which would expose a wrong K slot, byte selector, swizzle or column order), and bitwise repeatable."""
+    qw, qz, s, x, bias = fullrange_case(K, N, g, M, seed=K + N + M, realistic=(N % 64 == 0))
+    y32, _ = oracle.linear_gemm(x.numpy(), qw.numpy(), qz.numpy(), s.numpy(), g, bias.numpy())
+    fl = ops.gemm_flags(ops.KERNEL_REGB, nlog=bm)
+    y = ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), flags=fl)
+    assert ops.last_kernel() == "gemm_regb"
+    assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"regb K{K} N{N} g{g} M{M} bm{bm}")
+    assert torch.equal(y, ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), flags=fl))
+    W = ops.dequantize_weights(qw.cuda(), s.cuda(), qz.cuda())
+    e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    ks = (torch.arange(M, device="cuda") * 7 + 3) % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    out = ops.gemm_forward(e, qw.cuda(), s.cuda(), qz.cuda(), flags=fl)
+    diff = torch.nonzero(out != W[ks])
+    assert diff.numel() == 0, f"one-hot rows differ at {diff[:48].tolist()} ({diff.shape[0]} elements)"
+
+
+def test_regb_gemm_refuses_what_it_cannot_run(ops):
+    """K not a multiple of 64 / groups of 32 rows: the launcher says UNSUPPORTED (the caller's fallback is gemm_tiled)."""
+    from autoawq_amd import _lib
+
+    for K, N, g in [(160, 64, 32), (96, 64, 32)]:
+        qw, qz, s, x, _ = fullrange_case(K, N, g, 32, seed=3, realistic=True)
+        with pytest.raises(_lib.AwqHipError):
+            ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), flags=ops.gemm_flags(ops.KERNEL_REGB))
+
+
 def test_tiled_splitk_more_blocks_than_cus(ops):
     """M = 300 at 2048 x 2048 with a workspace large enough for S = 8: 48 tiles x 8 slices = 384
     blocks, every producer wave streams 16 chunks of 16 bytes into the exchange.  This is the
@@ -249,6 +283,11 @@ def test_auto_dispatch_by_m(ops):
     for M, want in [(1, "gemv_mfma"), (16, "gemv_mfma"), (17, "gemm_tiled"), (40, "gemm_tiled")]:
         ops.gemm_forward(x[:M].cuda(), dq, ds, dz)
         assert ops.last_kernel() == want, (M, ops.last_kernel())
+        assert ops.auto_kernel(M, 512, 256, 128) == {"gemv_mfma": ops.KERNEL_MFMA_GEMV, "gemm_tiled": ops.KERNEL_TILED}[want]
+    # prefill sizes whose 128 x 256 tiles give every CU a block go to the register-decoded kernel (host-only query)
+    assert ops.auto_kernel(1024, 4096, 11008, 128) == ops.KERNEL_REGB and ops.auto_kernel(512, 4096, 11008, 128) == ops.KERNEL_TILED
+    assert ops.auto_kernel(2048, 11008, 4096, 128) == ops.KERNEL_REGB and ops.auto_kernel(1024, 11008, 4096, 128) == ops.KERNEL_TILED
+    assert ops.auto_kernel(4096, 4096, 4096, 32) == ops.KERNEL_TILED   # groups of 32 rows: not the register-decoded kernel
 
 
 def test_gemm_deterministic_and_counters_rearmed(ops):

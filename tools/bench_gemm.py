@@ -26,13 +26,15 @@ def timeit(fn, reps):
 
 for K, N in [(4096, 11008), (11008, 4096)]:
     qw, qz, sc = rand_packed(K, N, 128, dev, gen)
-    for M in [1024, 4096, 16384]:
+    for M in ([int(v) for v in os.environ['MS'].split(',')] if os.environ.get('MS') else [1024, 4096, 16384]):
         x = torch.randn((M, K), device=dev, generator=gen).half()
         reps = 20 if M <= 1024 else 5
         fl = 2.0 * M * K * N
         row = f"K{K} N{N} M{M:6d}:"
         for nm, f in [("tiled128", lambda: ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=1))),
                       ("tiled256", lambda: ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2))),
+                      ("regb128", lambda: ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_REGB, nlog=1))),
+                      ("regb256", lambda: ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_REGB, nlog=2))),
                       ("2pass", lambda: torch.matmul(x, ops.dequantize_weights(qw, sc, qz)))]:
             us = timeit(f, reps)
             row += f"  {nm} {us:9.1f} us {fl / us / 1e6:7.1f} TF"
@@ -42,4 +44,7 @@ for K, N in [(4096, 11008), (11008, 4096)]:
         a = ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=1)).float()
         b = torch.matmul(x, W).float()
         row += f"  maxrel {float((a - b).abs().max() / b.abs().max()):.1e}"
+        for nl in (1, 2):  # the register-decoded kernel multiplies exactly the same fp16 weights
+            a = ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_REGB, nlog=nl)).float()
+            row += f"  regb{128 * nl} maxrel {float((a - b).abs().max() / b.abs().max()):.1e}"
         print(row, flush=True)
