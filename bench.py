@@ -40,6 +40,17 @@ MODELS = {  # hidden, intermediate, layers, heads, kv heads
 HIDDEN, INTER, LAYERS = 4096, 11008, 32  # the headline model (kept as names for tools/ that import them)
 
 
+def pmc_traffic_per_launch():
+    """Mean HBM bytes per launch of the headline kernels from the committed FETCH_SIZE pass (profiles/, tools/prof_r02.sh)."""
+    import re
+
+    try:
+        txt = open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.txt")).read()
+        return float(re.search(r"per launch \(weighted mean\): traffic ([0-9.]+) MB", txt).group(1)) * 1e6
+    except (OSError, AttributeError):
+        return None
+
+
 def algorithmic_bytes(K, N, M, g, bias=False):
     """packed weights + zeros + scales read once, x read once, y written once."""
     return K * N // 2 + (K // g) * (N // 8) * 4 + (K // g) * N * 2 + M * K * 2 + M * N * 2 + (N * 2 if bias else 0)
@@ -185,18 +196,23 @@ def leg_gemm_prefill(dev, ops):
     x = torch.randn((M, K), device=dev, generator=gen).half()
     fl = 2.0 * M * K * N
 
-    def timeit(fn, reps=6):
+    def timeit(fn, reps=5, batches=3):  # median of three batches: these MFMA-bound calls move the clock (DVFS) as they run
         fn()
         fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / reps
+        out = []
+        for _ in range(batches):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1) * 1e3 / reps)
+        return statistics.median(out)
 
+    for _ in range(10):  # bring the part to its sustained clock before the first measurement
+        ops.gemm_forward(x, qw, sc, qz)
     us_f = timeit(lambda: ops.gemm_forward(x, qw, sc, qz))
     kernel = ops.last_kernel()
     us_t = timeit(lambda: ops.gemm_forward(x, qw, sc, qz, flags=ops.gemm_flags(ops.KERNEL_TILED, nlog=2)))
@@ -465,7 +481,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          # HBM bytes per launch need the TCC fabric counters of a separate rocprofv3 --pmc pass
                          # (MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950): not measurable from inside this process
-                         "traffic": None, "traffic_measured_in": "profiles/r02_pmc_fetch_size.txt (own --pmc FETCH_SIZE pass of this command)",
+                         "traffic": pmc_traffic_per_launch() if (world == 1 and a.model == "7b" and a.layout == "gemm" and layers == cfg["layers"]) else None,
+                         "traffic_unit": "bytes per launch",
+                         "traffic_measured_in": "profiles/r02_pmc_fetch_size.txt (own rocprofv3 --pmc FETCH_SIZE pass of this command, x 2 gfx950 correction, calibrated on a linear read)",
                          "bytes_per_launch": bytes_step / launches, "avg_launch_us": ms_step * 1e3 / launches,
                          "kernel": "awq_gemv_mfma_kernel (4 shapes per layer: qkv, o, gate+up, down)",
                          "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "
