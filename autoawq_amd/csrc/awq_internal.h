@@ -75,7 +75,8 @@ int awq_launch_dequant_fast(const int16_t* qweight, const uint16_t* scales, cons
                             int N, int g, hipStream_t st);
 // MoE routing (softmax + top-k + block alignment) in one launch; T tokens, E <= 64 experts, k <= 8.
 int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int* sorted_ids, int* expert_ids,
-                         int* num_post_pad, int T, int E, int k, int renorm, int block, hipStream_t st);
+                         int* num_post_pad, int T, int E, int k, int renorm, int block, int first_expert, int num_local,
+                         hipStream_t st);
 
 // decoder.hip: RMSNorm (+ residual add when `residual` is non-null), RoPE + KV-cache append, single-query attention
 int awq_launch_rmsnorm(const uint16_t* x, uint16_t* residual, const uint16_t* w, uint16_t* out, int64_t M, int64_t H,

@@ -264,17 +264,26 @@ int awq_silu_and_mul(const uint16_t* gate_up, uint16_t* out, int64_t rows, int64
     return awq_launch_silu_and_mul(gate_up, out, rows, d, static_cast<hipStream_t>(stream));
 }
 
-int awq_moe_route(const float* gating_logits, float* topk_weights, int32_t* topk_ids, int32_t* sorted_token_ids,
-                  int32_t* expert_ids, int32_t* num_tokens_post_padded, int64_t num_tokens, int64_t num_experts,
-                  int64_t topk, int renormalize, int64_t block_rows, void* stream) {
+int awq_moe_route_local(const float* gating_logits, float* topk_weights, int32_t* topk_ids, int32_t* sorted_token_ids,
+                        int32_t* expert_ids, int32_t* num_tokens_post_padded, int64_t num_tokens, int64_t num_experts,
+                        int64_t topk, int renormalize, int64_t block_rows, int64_t first_expert, int64_t num_local,
+                        void* stream) {
     if (num_tokens < 0 || num_experts < 1 || topk < 1 || block_rows < 1) return AWQ_ERR_BAD_SHAPE;
+    if (first_expert < 0 || num_local < 1 || first_expert + num_local > num_experts) return AWQ_ERR_BAD_SHAPE;
     if (num_tokens == 0) return AWQ_OK;
     if (!gating_logits || !topk_weights || !topk_ids || !sorted_token_ids || !expert_ids || !num_tokens_post_padded)
         return AWQ_ERR_NULL;
     if (num_tokens * topk > (1 << 24)) return AWQ_ERR_UNSUPPORTED;
     return awq_launch_moe_route(gating_logits, topk_weights, topk_ids, sorted_token_ids, expert_ids,
                                 num_tokens_post_padded, (int)num_tokens, (int)num_experts, (int)topk, renormalize,
-                                (int)block_rows, static_cast<hipStream_t>(stream));
+                                (int)block_rows, (int)first_expert, (int)num_local, static_cast<hipStream_t>(stream));
+}
+
+int awq_moe_route(const float* gating_logits, float* topk_weights, int32_t* topk_ids, int32_t* sorted_token_ids,
+                  int32_t* expert_ids, int32_t* num_tokens_post_padded, int64_t num_tokens, int64_t num_experts,
+                  int64_t topk, int renormalize, int64_t block_rows, void* stream) {
+    return awq_moe_route_local(gating_logits, topk_weights, topk_ids, sorted_token_ids, expert_ids, num_tokens_post_padded,
+                               num_tokens, num_experts, topk, renormalize, block_rows, 0, num_experts, stream);
 }
 
 size_t awq_grouped_gemm_workspace_bytes(int64_t max_blocks, int64_t K, int64_t N) {

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restr
                                                            int* __restrict__ topk_ids, int* __restrict__ sorted_ids,
                                                            int* __restrict__ expert_ids, int* __restrict__ num_post_pad,
                                                            int T, int E, int k, int renorm, int block, int cap_sorted,
-                                                           int cap_blocks) {
+                                                           int cap_blocks, int e0, int nl) {
     __shared__ int counts[ROUTE_MAX_E], pad_start[ROUTE_MAX_E + 1];
     const int tid = threadIdx.x;
     const int P = T * k;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restr
             wsel[j] = bv * inv;
             isel[j] = best;
             wsum += wsel[j];
-            atomicAdd(&counts[best], 1);
+            if (best >= e0 && best < e0 + nl) atomicAdd(&counts[best - e0], 1);  // pairs of experts outside [e0, e0 + nl) are not placed
         }
         for (int j = 0; j < k; ++j) {
             topk_w[(int64_t)t * k + j] = renorm ? wsel[j] / wsum : wsel[j];
@@ -97,35 +97,37 @@ __global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restr
     __syncthreads();
     if (tid == 0) {
         int pos = 0;
-        for (int e = 0; e < E; ++e) {
+        for (int e = 0; e < nl; ++e) {
             pad_start[e] = pos;
             pos += (counts[e] + block - 1) / block * block;
         }
-        pad_start[E] = pos;
+        pad_start[nl] = pos;
         *num_post_pad = pos;
     }
     __syncthreads();
     for (int i = tid; i < cap_sorted; i += 256) sorted_ids[i] = P;
     for (int b = tid; b < cap_blocks; b += 256) {
         int e = 0;
-        while (e < E - 1 && b * block >= pad_start[e + 1]) ++e;
-        expert_ids[b] = e;
+        while (e < nl - 1 && b * block >= pad_start[e + 1]) ++e;
+        expert_ids[b] = e;  // relative to e0
     }
     __syncthreads();  // the fill above and the id tables written in phase 1 are visible to the block
-    if (tid < E) {  // stable placement: one thread per expert walks the pairs in order
+    if (tid < nl) {  // stable placement: one thread per (local) expert walks the pairs in order
         int pos = pad_start[tid];
         for (int p = 0; p < P; ++p)
-            if (topk_ids[p] == tid) sorted_ids[pos++] = p;
+            if (topk_ids[p] == e0 + tid) sorted_ids[pos++] = p;
     }
 }
 }  // namespace
 
 int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int* sorted_ids, int* expert_ids,
-                         int* num_post_pad, int T, int E, int k, int renorm, int block, hipStream_t st) {
+                         int* num_post_pad, int T, int E, int k, int renorm, int block, int first_expert, int num_local,
+                         hipStream_t st) {
     if (T < 1 || E < 1 || E > ROUTE_MAX_E || k < 1 || k > ROUTE_MAX_K || k > E || block < 1) return AWQ_ERR_UNSUPPORTED;
+    if (first_expert < 0 || num_local < 1 || first_expert + num_local > E) return AWQ_ERR_BAD_SHAPE;
     const int P = T * k;
     hipLaunchKernelGGL(awq_moe_route_kernel, dim3(1), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,
-                       num_post_pad, T, E, k, renorm, block, P + E * (block - 1), P + E);
+                       num_post_pad, T, E, k, renorm, block, P + num_local * (block - 1), P + num_local, first_expert, num_local);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 

@@ -268,7 +268,7 @@ _moe_workspaces = {}
 
 
 def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_ids, expert_ids,
-                         num_tokens_post_padded, mul_weights, split_k_iters=8, block_rows=16):
+                         num_tokens_post_padded, mul_weights, split_k_iters=8, block_rows=16, zero_init=False):
     """awq_ext.grouped_gemm_forward semantics (awq/modules/fused/moe.py:60-89): x [T, 1 | topk, K] fp16,
     stacked GEMM-layout expert tensors [E, ...]; returns [T, topk, N] fp16.  Nothing is read back
     to the host: the routing tensors are consumed on the device.  block_rows = the block size the
@@ -284,7 +284,8 @@ def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_
         raise _lib.AwqHipError(f"grouped_gemm_forward: x{tuple(x.shape)} does not match {T} tokens x top-{topk}")
     qweight, scales, qzeros = qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
     sorted_token_ids = sorted_token_ids.contiguous()
-    y = torch.empty((T, topk, N), dtype=torch.float16, device=x.device)
+    # zero_init: rows of pairs that no block covers (expert-parallel routing places only the local experts' pairs) read as 0
+    y = (torch.zeros if zero_init else torch.empty)((T, topk, N), dtype=torch.float16, device=x.device)
     max_blocks = expert_ids.numel()
     L = _lib.lib()
     with torch.cuda.device(x.device):
@@ -307,21 +308,25 @@ def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_
     return y
 
 
-def moe_route(gating_output, topk, renormalize, block_size):
+def moe_route(gating_output, topk, renormalize, block_size, first_expert=0, num_local=None):
     """softmax + top-k (+ renormalise) + block alignment in ONE launch (awq_moe_route): returns
-    (topk_weights [T, k] fp32, topk_ids [T, k] i32, sorted_token_ids, expert_ids, num_tokens_post_padded)."""
+    (topk_weights [T, k] fp32, topk_ids [T, k] i32, sorted_token_ids, expert_ids, num_tokens_post_padded).
+    first_expert / num_local (expert parallel, awq_moe_route_local): only the pairs of experts
+    [first_expert, first_expert + num_local) are placed, expert_ids are relative to first_expert; topk_ids stay global."""
     _require_gpu(gating_output)
     g = gating_output.float().contiguous()
     T, E = g.shape
+    nl = E if num_local is None else num_local
     dev = g.device
     w = torch.empty((T, topk), dtype=torch.float32, device=dev)
     ids = torch.empty((T, topk), dtype=torch.int32, device=dev)
-    sorted_ids = torch.empty((T * topk + E * (block_size - 1),), dtype=torch.int32, device=dev)
-    expert_ids = torch.empty((T * topk + E,), dtype=torch.int32, device=dev)
+    sorted_ids = torch.empty((T * topk + nl * (block_size - 1),), dtype=torch.int32, device=dev)
+    expert_ids = torch.empty((T * topk + nl,), dtype=torch.int32, device=dev)
     npad = torch.empty((1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().awq_moe_route(_ptr(g), _ptr(w), _ptr(ids), _ptr(sorted_ids), _ptr(expert_ids), _ptr(npad), T, E,
-                                            topk, 1 if renormalize else 0, block_size, _stream()), "awq_moe_route")
+        _lib.check(_lib.lib().awq_moe_route_local(_ptr(g), _ptr(w), _ptr(ids), _ptr(sorted_ids), _ptr(expert_ids), _ptr(npad), T, E,
+                                                  topk, 1 if renormalize else 0, block_size, first_expert, nl, _stream()),
+                   "awq_moe_route_local")
     return w, ids, sorted_ids, expert_ids, npad
 
 

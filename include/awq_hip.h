@@ -123,6 +123,16 @@ AWQ_EXPORT int awq_moe_route(const float* gating_logits, float* topk_weights, in
                              int64_t num_tokens, int64_t num_experts, int64_t topk, int renormalize,
                              int64_t block_rows, void* stream);
 
+/* Expert-parallel form (new: the reference keeps every expert on one device, awq/models/mixtral.py:130-158): the routing
+ * (topk_weights, topk_ids: GLOBAL expert ids) is computed over all num_experts, but only the pairs of experts
+ * [first_expert, first_expert + num_local) are placed: sorted_token_ids [T*k + num_local*(block_rows-1)], expert_ids
+ * [T*k + num_local] RELATIVE to first_expert, num_tokens_post_padded counts the local blocks only.  The rows of the other
+ * pairs are never written by awq_grouped_gemm_forward: zero its output first (autoawq_amd/ep.py). */
+AWQ_EXPORT int awq_moe_route_local(const float* gating_logits, float* topk_weights, int32_t* topk_ids,
+                                   int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_padded,
+                                   int64_t num_tokens, int64_t num_experts, int64_t topk, int renormalize,
+                                   int64_t block_rows, int64_t first_expert, int64_t num_local, void* stream);
+
 /* Replaces awq_ext.grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_ids,
  * expert_ids, num_tokens_post_padded, mul_weights, split_k_iters) (moe.py:60-89).
  * qweight [E, K, N/8], qzeros [E, K/g, N/8], scales [E, K/g, N]; sorted_token_ids / expert_ids /

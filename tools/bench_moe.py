@@ -85,5 +85,80 @@ def run(dev=None, verbose=True, layers=2, reps=20):
             "checked_against": f"per-(token, expert) awq_gemm_forward calls, max rel diff {rel:.1e}"}
 
 
+def run_ep(world, dev=None, layers=2, reps=20, verbose=True):
+    """Expert-parallel split of the same block (autoawq_amd/ep.py) with the ranks run one after the other on THIS GPU:
+    per-rank time of the local part (routing + the two grouped GEMMs over the owned experts that were hit, without the
+    final all-reduce of 32 KiB), and the sum over ranks checked against the unsharded block."""
+    from autoawq_amd import ep, ops
+    from autoawq_amd.modules.fused.moe import apply_moe_weights
+    from bench import algorithmic_bytes
+
+    dev = dev or torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(0)
+    lim = 0x7FFFFFFF
+
+    def experts(K, N):
+        s = Stack()
+        s.group_size = g
+        s.qweight = torch.randint(-lim - 1, lim, (E, K, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        s.qzeros = torch.randint(-lim - 1, lim, (E, K // g, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        s.scales = (torch.rand((E, K // g, N), device=dev, generator=gen) * 0.02 + 0.005).half()
+        return s
+
+    stacks = [(experts(H, 2 * I), experts(I, H)) for _ in range(layers)]
+    x = torch.randn((T, H), device=dev, generator=gen).half()
+    logits = torch.randn((T, E), device=dev, generator=gen)
+    _, ids = ops.fused_topk(logits, topk, True)
+    full = apply_moe_weights(stacks[0][0], stacks[0][1], x, logits, topk, True).float()
+    total = torch.zeros_like(full)
+    per_rank = []
+    for r in range(world):
+        e0, e1 = ep.expert_bounds(E, r, world)
+        shards = [(ep.ExpertShard(a, e0, e1), ep.ExpertShard(b, e0, e1)) for a, b in stacks]
+        total += ep.apply_moe_weights_local(shards[0][0], shards[0][1], x, logits, topk, True, e0).float()
+        hit = len({int(v) for v in ids.reshape(-1).tolist() if e0 <= int(v) < e1})
+
+        def step():
+            for a, b in shards:
+                ep.apply_moe_weights_local(a, b, x, logits, topk, True, e0)
+
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            step()
+            st.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                step()
+            gr.replay()
+            st.synchronize()
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record(st)
+            for _ in range(reps):
+                gr.replay()
+            t1.record(st)
+            t1.synchronize()
+        us = t0.elapsed_time(t1) * 1e3 / (reps * len(shards))
+        by = hit * (algorithmic_bytes(H, 2 * I, 1, g) + algorithmic_bytes(I, H, 1, g))
+        per_rank.append({"rank": r, "experts": [e0, e1], "experts_hit": hit, "us_per_block": us, "MB": by / 1e6})
+        if verbose:
+            print(f"  EP={world} rank {r}: experts [{e0}, {e1}), {hit} hit, {us:6.1f} us per block, {by / 1e6:5.0f} MB"
+                  + (f" -> {by / us / 1e3:.0f} GB/s" if hit else ""), flush=True)
+        del gr, shards
+        torch.cuda.empty_cache()
+    rel = float((total - full).abs().max() / full.abs().max())
+    assert rel < 5e-3, f"sum over the expert-parallel ranks differs from the unsharded block by {rel}"
+    worst = max(p["us_per_block"] for p in per_rank)
+    if verbose:
+        print(f"  EP={world}: busiest rank {worst:.1f} us per block (+ one 32 KiB all-reduce); sum over ranks within {rel:.1e} of the unsharded block")
+    return {"world": world, "per_rank": per_rank, "busiest_rank_us": worst, "sum_vs_unsharded_max_rel": rel}
+
+
 if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ep", type=int, nargs="*", default=[], help="also time the expert-parallel split on W ranks (run one after the other here)")
+    a = ap.parse_args()
     run()
+    for w_ in a.ep:
+        run_ep(w_)
