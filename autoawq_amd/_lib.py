@@ -82,7 +82,10 @@ SIGNATURES = {
 
 
 class AwqHipError(RuntimeError):
-    pass
+    code = 0  # the AWQ_ERR_* value when the error came from the library
+
+
+ERR_UNSUPPORTED = -3  # AWQ_ERR_UNSUPPORTED: a valid AWQ tensor, but no kernel for it
 
 
 def available():
@@ -115,4 +118,6 @@ def lib():
 def check(rc, what=""):
     if rc != 0:
         msg = lib().awq_hip_error_string(rc).decode()
-        raise AwqHipError(f"{what}: {msg} (code {rc})")
+        err = AwqHipError(f"{what}: {msg} (code {rc})")
+        err.code = rc
+        raise err

@@ -21,12 +21,6 @@ class QuantFusedMLP(nn.Module):
 
     def __init__(self, gate_proj, down_proj, up_proj, activation=F.silu):
         super().__init__()
-        self.register_buffer("gate_proj_qweight", gate_proj.qweight)
-        self.register_buffer("gate_proj_scales", gate_proj.scales)
-        self.register_buffer("gate_proj_qzeros", gate_proj.qzeros)
-        self.register_buffer("up_proj_qweight", up_proj.qweight)
-        self.register_buffer("up_proj_scales", up_proj.scales)
-        self.register_buffer("up_proj_qzeros", up_proj.qzeros)
         self.in_features = gate_proj.in_features
         self.intermediate_size = gate_proj.out_features
         self.out_features = down_proj.out_features
@@ -35,19 +29,42 @@ class QuantFusedMLP(nn.Module):
         self.gemv_layout = isinstance(down_proj, WQLinear_GEMV)
         self.group_size = down_proj.group_size
         self.activation = activation
-        self._fused = None  # (key, qweight, scales, qzeros) of the gate|up concatenation
+        self._fused = None
+        self._adopt(gate_proj.qweight, gate_proj.scales, gate_proj.qzeros, up_proj.qweight, up_proj.scales, up_proj.qzeros)
+
+    def _adopt(self, gq, gs, gz, uq, us, uz):
+        """ONE resident copy of the gate / up weights: the [gate | up] concatenation the fused projection reads; the six
+        buffers the reference registers (mlp.py:25-32: `gate_proj_qweight` ... `up_proj_qzeros`, the names checkpoints and
+        `state_dict()` use) are views into it, so loading into them, or reading them, touches the same memory."""
+        dim = 0 if self.gemv_layout else 1  # GEMV layout stacks output rows, GEMM layout columns
+        fused = tuple(torch.cat([g, u], dim=dim).contiguous() for g, u in ((gq, uq), (gs, us), (gz, uz)))
+        self._fused = fused
+        for name, f, g in (("qweight", fused[0], gq), ("scales", fused[1], gs), ("qzeros", fused[2], gz)):
+            n = g.shape[dim]
+            for proj, view in (("gate_proj_", f.narrow(dim, 0, n)), ("up_proj_", f.narrow(dim, n, f.shape[dim] - n))):
+                if proj + name in self._buffers:
+                    self._buffers[proj + name] = view
+                else:
+                    self.register_buffer(proj + name, view)
+
+    def _apply(self, fn, recurse=True):
+        # .to() / .cuda() / .half() give every buffer a storage of its own: fuse the moved tensors again
+        super()._apply(fn, recurse)
+        self._adopt(self.gate_proj_qweight, self.gate_proj_scales, self.gate_proj_qzeros,
+                    self.up_proj_qweight, self.up_proj_scales, self.up_proj_qzeros)
+        return self
 
     def _gate_up_fused(self):
-        """Concatenated [gate | up] buffers, rebuilt if a caller re-assigned the registered ones."""
-        key = (self.gate_proj_qweight.data_ptr(), self.up_proj_qweight.data_ptr(), self.gate_proj_qweight._version,
-               self.up_proj_qweight._version)
-        if self._fused is None or self._fused[0] != key:
-            dim = 0 if self.gemv_layout else 1  # GEMV layout stacks output rows, GEMM layout columns
-            self._fused = (key,
-                           torch.cat([self.gate_proj_qweight, self.up_proj_qweight], dim=dim).contiguous(),
-                           torch.cat([self.gate_proj_scales, self.up_proj_scales], dim=dim).contiguous(),
-                           torch.cat([self.gate_proj_qzeros, self.up_proj_qzeros], dim=dim).contiguous())
-        return self._fused[1:]
+        """Concatenated [gate | up] buffers (re-fused if a caller re-assigned one of the registered views)."""
+        base = self._fused[0].untyped_storage().data_ptr()
+        if (self.gate_proj_qweight.untyped_storage().data_ptr() != base or self.up_proj_qweight.untyped_storage().data_ptr() != base
+                or self.gate_proj_scales.untyped_storage().data_ptr() != self._fused[1].untyped_storage().data_ptr()
+                or self.up_proj_scales.untyped_storage().data_ptr() != self._fused[1].untyped_storage().data_ptr()
+                or self.gate_proj_qzeros.untyped_storage().data_ptr() != self._fused[2].untyped_storage().data_ptr()
+                or self.up_proj_qzeros.untyped_storage().data_ptr() != self._fused[2].untyped_storage().data_ptr()):
+            self._adopt(self.gate_proj_qweight, self.gate_proj_scales, self.gate_proj_qzeros,
+                        self.up_proj_qweight, self.up_proj_scales, self.up_proj_qzeros)
+        return self._fused
 
     def forward(self, x, routing_weights=None, gate_up=None):
         """`gate_up` [rows, 2 * intermediate]: the fused gate|up projection already computed by the caller

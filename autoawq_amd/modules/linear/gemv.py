@@ -15,7 +15,7 @@ raises.
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import _lib, ops
 from ...utils.packing import (GEMV_ORDER, calculate_zeros_width, pack_rows_int4, pack_zeros_nk,
                               quantize_int_weights_nk)
 
@@ -76,7 +76,12 @@ class WQLinear_GEMV(nn.Module):
             Wt = ops.dequantize_weights_gemv(self.qweight, self.scales, self.qzeros, self.group_size)  # [N, K]
             out = torch.matmul(inputs, Wt.t())
         else:
-            out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
+            try:
+                out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
+            except _lib.AwqHipError as e:  # a shape the decode kernel does not take (K % 128, unusual group sizes): the
+                if e.code != _lib.ERR_UNSUPPORTED:  # dequant kernel + vendor GEMM handle every valid tensor
+                    raise
+                out = torch.matmul(inputs, ops.dequantize_weights_gemv(self.qweight, self.scales, self.qzeros, self.group_size).t())
         if input_dtype != torch.float16:
             out = out.to(dtype=input_dtype)
         out = out + self.bias if self.bias is not None else out

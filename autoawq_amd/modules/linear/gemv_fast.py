@@ -13,7 +13,7 @@ bit-exact dequant + vendor fp16 GEMM.
 """
 import torch
 
-from ... import ops
+from ... import _lib, ops
 from ...utils.packing import calculate_zeros_width, pack_intweight_fast, quantize_int_weights_nk
 
 DEQUANT_MATMUL_MIN_ROWS = 65
@@ -77,7 +77,12 @@ class WQLinear_GEMVFast(torch.nn.Module):
             Wt = ops.dequantize_weights_gemv_fast(self.qweight, self.scales, self.qzeros, self.group_size)
             out = torch.matmul(inputs, Wt.t())
         else:
-            out = ops.gemv_fast_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
+            try:
+                out = ops.gemv_fast_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
+            except _lib.AwqHipError as e:  # a shape the decode kernel does not take (K % 128, unusual group sizes): the
+                if e.code != _lib.ERR_UNSUPPORTED:  # dequant kernel + vendor GEMM handle every valid tensor
+                    raise
+                out = torch.matmul(inputs, ops.dequantize_weights_gemv_fast(self.qweight, self.scales, self.qzeros, self.group_size).t())
         if in_dtype != torch.float16:
             out = out.to(in_dtype)
         out = out.reshape(batch_size, n_tokens, self.out_features)

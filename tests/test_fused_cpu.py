@@ -67,3 +67,45 @@ def test_fuse_linears_builds_the_mixtral_expert_stacks():
     for e in range(E):
         assert torch.equal(ws.qweight[e, :, I // 8:], keep[e][1][0]) and torch.equal(w2s.scales[e], keep[e][2][2])
     assert set(ws.state_dict()) == {"qweight", "qzeros", "scales"}
+
+
+def test_fused_mlp_keeps_one_copy_of_gate_up():
+    """QuantFusedMLP (awq/modules/fused/mlp.py:14-70): the six registered buffers the reference names are views into the
+    ONE [gate | up] concatenation the fused projection reads -- same state_dict, half the resident gate/up memory; loading,
+    moving and re-assigning them keeps the fused tensors in step."""
+    from autoawq_amd import WQLinear_GEMM
+    from autoawq_amd.modules.fused.mlp import QuantFusedMLP
+
+    gen = torch.Generator().manual_seed(4)
+    lim = 0x7FFFFFFF
+
+    def lin(K, N):
+        m = WQLinear_GEMM(4, 128, K, N, False, "cpu")
+        m.qweight = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, generator=gen)
+        m.qzeros = torch.randint(-lim - 1, lim, (K // 128, N // 8), dtype=torch.int32, generator=gen)
+        m.scales = torch.rand((K // 128, N), generator=gen).half()
+        return m
+
+    gate, up, down = lin(256, 512), lin(256, 512), lin(512, 256)
+    gq, uq, us = gate.qweight.clone(), up.qweight.clone(), up.scales.clone()
+    mlp = QuantFusedMLP(gate, down, up)
+    fq, fs, fz = mlp._gate_up_fused()
+    assert torch.equal(fq, torch.cat([gq, uq], 1)) and fq.shape == (256, 128)
+    for name in ("gate_proj_qweight", "up_proj_qweight"):
+        assert getattr(mlp, name).untyped_storage().data_ptr() == fq.untyped_storage().data_ptr()   # views, not copies
+    sd = mlp.state_dict()
+    assert {"gate_proj_qweight", "gate_proj_scales", "gate_proj_qzeros", "up_proj_qweight", "up_proj_scales", "up_proj_qzeros"} <= set(sd)
+    assert torch.equal(sd["up_proj_qweight"], uq) and torch.equal(sd["up_proj_scales"], us)
+    # load into another instance: the copy lands in the fused tensors
+    other = QuantFusedMLP(lin(256, 512), lin(512, 256), lin(256, 512))
+    other.load_state_dict(sd)
+    assert torch.equal(other._gate_up_fused()[0], fq) and torch.equal(other._gate_up_fused()[1], fs)
+    # module-wide conversions re-fuse
+    other = other.to(torch.device("cpu"))
+    assert other.gate_proj_qweight.untyped_storage().data_ptr() == other._gate_up_fused()[0].untyped_storage().data_ptr()
+    assert torch.equal(other._gate_up_fused()[0], fq)
+    # a caller that re-assigns a registered buffer (what a loader may do) is picked up at the next use
+    new_up = torch.randint(-lim - 1, lim, (256, 64), dtype=torch.int32, generator=gen)
+    other.up_proj_qweight = new_up
+    assert torch.equal(other._gate_up_fused()[0], torch.cat([gq, new_up], 1))
+    assert other.up_proj_qweight.untyped_storage().data_ptr() == other._gate_up_fused()[0].untyped_storage().data_ptr()

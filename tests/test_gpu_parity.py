@@ -710,6 +710,34 @@ def test_gemvfast_module_forward(ops, oracle):
     assert (np.abs(out[:, 0].cpu().numpy().astype(np.float64) - y32) <= product_tol_(y32) + 6 * wsig + 2 * ulp).all()
 
 
+@pytest.mark.parametrize("K,N,g", [(320, 64, 64), (192, 32, 32)])
+def test_gemv_layout_modules_fall_back_where_the_decode_kernels_refuse(ops, oracle, K, N, g):
+    """K % 128 != 0: awq_gemv_forward and
+    awq_gemv_fast_forward answer UNSUPPORTED; the modules then dequantise (bit-exact HIP kernels) and multiply, so every
+    valid tensor of the two layouts has a forward (the reference's kernels take these shapes, gemv.py:168-180)."""
+    from autoawq_amd import WQLinear_GEMV, WQLinear_GEMVFast, _lib
+
+    M = 3
+    qw, qz, sc, x = gemv_case(K, N, g, M, seed=K + N)
+    with pytest.raises(_lib.AwqHipError) as ei:
+        ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g)
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
+    m = WQLinear_GEMV(4, g, K, N, False, "cuda")
+    m.qweight, m.qzeros, m.scales = qw.cuda(), qz.cuda(), sc.cuda()
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+    y32, _ = oracle.matmul(x.numpy(), W)
+    assert_product_close(m(x.cuda()).cpu().numpy().astype(np.float64), y32, f"gemv module fallback K{K} g{g}")
+    fq, fs, fz, fx = gemvfast_case(K, N, g, M, seed=K + N + 1)
+    with pytest.raises(_lib.AwqHipError) as ei:
+        ops.gemv_fast_forward(fx.cuda(), fq.cuda(), fs.cuda(), fz.cuda(), g)
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
+    mf = WQLinear_GEMVFast(4, g, K, N, False, "cuda")
+    mf.qweight, mf.scales, mf.qzeros = fq.cuda(), fs.cuda(), fz.cuda()
+    Wf = oracle.dequant_gemvfast(fq.numpy(), fs.numpy(), fz.numpy(), g)
+    yf, _ = oracle.matmul(fx.numpy(), Wf)
+    assert_product_close(mf(fx.cuda().view(M, 1, K))[:, 0].cpu().numpy().astype(np.float64), yf, f"gemvfast module fallback K{K} g{g}")
+
+
 @pytest.mark.parametrize("T,E,k,blk", [(4, 8, 2, 8), (1, 8, 2, 16), (37, 8, 2, 16), (64, 16, 4, 16), (200, 64, 8, 8), (5, 3, 1, 4)])
 def test_moe_route_kernel_vs_torch_and_oracle(ops, oracle, T, E, k, blk):
     """one-launch routing == softmax/topk (torch, the reference's ROCm branch moe.py:152-156) + the
