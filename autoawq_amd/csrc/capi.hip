@@ -205,7 +205,7 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
             }
         }
         if (a.x_gated || extras) return AWQ_ERR_UNSUPPORTED;
-        kern = auto_kernel_large(a.M, a.K, a.N, a.g);
+        kern = M > 16 ? auto_kernel_large(a.M, a.K, a.N, a.g) : AWQ_GEMM_KERNEL_NAIVE;  // M <= 16 that the decode kernel refused: odd shapes
     }
     switch (kern) {
         case AWQ_GEMM_KERNEL_NAIVE:
@@ -241,7 +241,7 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
 int awq_gemm_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     if (M <= 0 || K <= 0 || N <= 0 || M > INT32_MAX || check_gemm_layout(K, N, group_size)) return -1;
     if (M <= 16 && awq_gemv_mfma_supports((int)M, (int)K, (int)N, (int)group_size, 2)) return AWQ_GEMM_KERNEL_MFMA_GEMV;
-    return (int)auto_kernel_large((int)M, (int)K, (int)N, (int)group_size);
+    return M > 16 ? (int)auto_kernel_large((int)M, (int)K, (int)N, (int)group_size) : (int)AWQ_GEMM_KERNEL_NAIVE;
 }
 
 int awq_gemm_workspace_status(const void* workspace, void* stream, int32_t* err_out) {
