@@ -52,14 +52,15 @@ struct RegbParams {
     half_t* y;
     int M, K, N, g;
     int tiles_m, tiles_n;
-    int mp, patches;  // patches of 8 x 4 tiles: mp along M, `patches` in all
+    int mp, patches;  // patches of pm x pn tiles: mp along M, `patches` in all
+    int pm, pn;       // tile patch one XCD runs at a time (pm * pn = 32)
 };
 
 constexpr int BK = 64, NBUF = 4, BN = 256;
 constexpr int PM = 8, PN = 4;  // tile patch per XCD round
 
 // DBG (tools/regb_experiments.py, -DAWQ_REGB_EXPERIMENTS builds only; results are WRONG, timing only): 1 = weights fetched
-// once, 2 = activations fetched once, 4 = no barrier, 8 = no decode arithmetic
+// once, 2 = activations fetched once, 4 = no barrier, 8 = no decode arithmetic, 16 = every output row stored into rows 0..127 (stores issued, nothing reaches HBM)
 template <int WGM, int DBG = 0>  // waves along M: BM = 128 * WGM
 __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams p) {
     constexpr int BM = 128 * WGM;
@@ -77,10 +78,10 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
     int mt, nt;
     {
         const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
-        const int patch = (i / (PM * PN)) * 8 + xcd, local = i % (PM * PN);
+        const int patch = (i / (p.pm * p.pn)) * 8 + xcd, local = i % (p.pm * p.pn);
         if (patch >= p.patches) return;
-        mt = (patch % p.mp) * PM + local % PM;
-        nt = (patch / p.mp) * PN + local / PM;
+        mt = (patch % p.mp) * p.pm + local % p.pm;
+        nt = (patch / p.mp) * p.pn + local / p.pm;
         if (mt >= p.tiles_m || nt >= p.tiles_n) return;
     }
     const int m0 = mt * BM, n0 = nt * BN;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
                 half4_t o;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[c] = (half_t)(acc[i][c][e] + b4[c]);
-                *reinterpret_cast<half4_t*>(p.y + (int64_t)row * p.N + col) = o;
+                *reinterpret_cast<half4_t*>(p.y + (int64_t)((DBG & 16) ? (row & 127) : row) * p.N + col) = o;
             }
         }
 }
@@ -328,9 +329,13 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
     p.tiles_m = (a.M + bm - 1) / bm;
     p.tiles_n = (a.N + BN - 1) / BN;
-    p.mp = (p.tiles_m + PM - 1) / PM;
-    p.patches = p.mp * ((p.tiles_n + PN - 1) / PN);
-    const int grid = ((p.patches + 7) / 8) * 8 * (PM * PN);
+    p.pm = PM; p.pn = PN;
+#ifdef AWQ_REGB_EXPERIMENTS
+    if (const char* e = getenv("AWQ_REGB_PM")) { p.pm = atoi(e); p.pn = 32 / p.pm; }
+#endif
+    p.mp = (p.tiles_m + p.pm - 1) / p.pm;
+    p.patches = p.mp * ((p.tiles_n + p.pn - 1) / p.pn);
+    const int grid = ((p.patches + 7) / 8) * 8 * (p.pm * p.pn);
     const size_t lds = (size_t)NBUF * bm * BK * 2;
 #ifdef AWQ_REGB_EXPERIMENTS
     {
@@ -346,7 +351,10 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
             else if (dbg == 2) hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 2>), dim3(grid), dim3(512), lds, a.stream, p);
             else if (dbg == 4) hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 4>), dim3(grid), dim3(512), lds, a.stream, p);
             else if (dbg == 8) hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 8>), dim3(grid), dim3(512), lds, a.stream, p);
-            else hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 15>), dim3(grid), dim3(512), lds, a.stream, p);
+            else if (dbg == 16) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 16>), dim3(grid), dim3(512), lds, a.stream, p);
+            } else hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 15>), dim3(grid), dim3(512), lds, a.stream, p);
             return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
         }
     }

@@ -38,8 +38,25 @@ if __name__ == "__main__":
     qw, qz, sc = rand_packed(K, N, 128, dev, gen)
     x = torch.randn((M, K), device=dev, generator=gen).half()
     fl = ops.gemm_flags(ops.KERNEL_REGB, nlog=2)
+    fl1 = ops.gemm_flags(ops.KERNEL_REGB, nlog=1)
+    for pm in (1, 2, 4, 8, 16, 32):  # shape of the tile patch an XCD runs at a time (pm M-tiles x 32/pm N-tiles), 128-row tiles
+        os.environ["AWQ_REGB_PM"] = str(pm)
+        for M2 in (8192, 16384):
+            xs = x[:M2]
+            for _ in range(3):
+                ops.gemm_forward(xs, qw, sc, qz, flags=fl1)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.gemm_forward(xs, qw, sc, qz, flags=fl1)
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 5
+            print(f"patch {pm:2d} x {32 // pm:2d}  M={M2:5d}  {us:8.1f} us  {2.0 * M2 * K * N / us / 1e6:7.1f} TF", flush=True)
+    del os.environ["AWQ_REGB_PM"]
     for dbg, what in ((0, "the kernel"), (1, "weights fetched once"), (2, "activations fetched once"), (4, "no barrier"),
-                      (8, "no decode arithmetic"), (15, "1+2+4+8"), (0, "the kernel")):
+                      (8, "no decode arithmetic"), (16, "output stores kept in L2"), (15, "1+2+4+8"), (0, "the kernel")):
         os.environ["AWQ_REGB_DBG"] = str(dbg)
         for _ in range(2):
             ops.gemm_forward(x, qw, sc, qz, flags=fl)
