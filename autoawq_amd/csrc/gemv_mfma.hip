@@ -76,6 +76,9 @@ struct GemvMfmaParams {
     const float* pair_weights;  // [num_pairs] routing weights, applied to the output if non-null
     int num_pairs, x_div;     // activation row of pair i = i / x_div
     int64_t expert_qw_words, expert_z_words, expert_s_halfs;  // per-expert strides
+    // (k * g_magic) >> 32 == k / g and (c * xc_magic) >> 32 == c / (rows_per_block / 8) for every k < K, c <= 17 * rows_per_block / 8
+    // (checked by the launcher): no integer division in the prologue, the staging or the K loop.  Last in the struct: see above.
+    uint32_t g_magic, xc_magic;
 };
 
 template <int WPL>
@@ -107,7 +110,7 @@ __device__ unsigned long long* g_awq_trace = nullptr;
 #define AWQ_STAMP(slot)                                                                                  \
     do {                                                                                                 \
         if (g_awq_trace && lane == 0)                                                                    \
-            g_awq_trace[((size_t)blockIdx.x * NWAVES + wave) * 16 + (slot)] = wall_clock64();             \
+            g_awq_trace[((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NWAVES + wave) * 16 + (slot)] = wall_clock64();             \
     } while (0)
 #else
 #define AWQ_STAMP(slot) do { } while (0)
@@ -140,8 +143,9 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kb = lane >> 4;
-    const int tile = blockIdx.x % p.tiles, slice = (blockIdx.x / p.tiles) % p.S;
-    const int tblk = MOE ? blockIdx.x / (p.tiles * p.S) : 0;  // 16-row token block (grouped mode)
+    // grid = (tiles, K slices, token blocks): the hardware hands over all three indices, no integer division in the prologue
+    const int tile = blockIdx.x, slice = blockIdx.y;
+    const int tblk = MOE ? blockIdx.z : 0;  // 16-row token block (grouped mode)
     if constexpr (MOE) {
         if (p.M * tblk >= *p.num_post_pad) return;  // uniform for every block of this token block (p.M rows each)
         const int64_t e = p.expert_ids[tblk];
@@ -159,8 +163,8 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     const int r0 = slice * p.rows_per_block;
     const int r1 = min(p.K, r0 + p.rows_per_block);
     const int RS = p.rows_per_block;             // LDS row pitch of xs (multiple of 16*UNIT)
-    const int g0 = r0 / p.g;                     // first group of the slice
-    const int ng = (r1 - 1) / p.g - g0 + 1;      // groups touched by the slice
+    const int g0 = (int)__umulhi((uint32_t)r0, p.g_magic);                    // first group of the slice
+    const int ng = (int)__umulhi((uint32_t)(r1 - 1), p.g_magic) - g0 + 1;     // groups touched by the slice
     half_t* xs = reinterpret_cast<half_t*>(smem);
     uint32_t* zq = reinterpret_cast<uint32_t*>(smem + (size_t)(M + 1) * RS * 2);
     half_t* zsc = reinterpret_cast<half_t*>(reinterpret_cast<unsigned char*>(zq) + (size_t)p.ng_max * (CW / 2));
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         return __builtin_bit_cast(u32x4, o);
     };
     auto x_chunk = [&](int c, bool up = false) -> u32x4 {
-        const int m = c / xchunks, cc = c % xchunks;
+        const int m = (int)__umulhi((uint32_t)c, p.xc_magic), cc = c - m * xchunks;
         const int row = r0 + 8 * cc;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (m < M && row < r1) {
@@ -219,7 +223,10 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         if (col < p.N) v = *reinterpret_cast<const u32x4*>(p.scales + (int64_t)(g0 + gl) * p.N + col);
         return v;
     };
-    auto x_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(xs + (size_t)(c / xchunks) * RS + 8 * (c % xchunks)) = v; };
+    auto x_store = [&](int c, u32x4 v) {
+        const int m = (int)__umulhi((uint32_t)c, p.xc_magic);
+        *reinterpret_cast<u32x4*>(xs + (size_t)m * RS + 8 * (c - m * xchunks)) = v;
+    };
     auto q_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(zq + (c / QC) * (CW / 8) + 4 * (c % QC)) = v; };
     auto s_store = [&](int c, u32x4 v) { *reinterpret_cast<u32x4*>(zsc + (c / SC) * CW + 8 * (c % SC)) = v; };
     constexpr bool LATE = NREG == 4 || NORM;  // batch > 1 (the plain M = 1 instantiations keep their register budget)
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                 }
                 __syncthreads();
                 for (int c = tid; c < (M + 1) * xchunks; c += NTHR) {
-                    const int m = c / xchunks, row = r0 + 8 * (c % xchunks);
+                    const int m = (int)__umulhi((uint32_t)c, p.xc_magic), row = r0 + 8 * (c - m * xchunks);
                     u32x4 v = {0u, 0u, 0u, 0u};
                     if (m < M && row < r1) {
                         const half8_t h = load_h(m, row);
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
                     }
                 }
                 // y += s * (acc - (16 + z) * sx) over the rows of this fold (inside one group)
-                const int gl = ((int)urow + 16 * SPF * f) / p.g - g0;
+                const int gl = (int)__umulhi(urow + 16u * SPF * f, p.g_magic) - g0;
                 const WV qzv = *reinterpret_cast<const WV*>(zq + gl * (CW / 8) + j * WPL);
 #pragma unroll
                 for (int wd = 0; wd < WPL; ++wd) {
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     // S instead of S - 1 in the two lines below: 866 -> 846 / 854 tok/s on the headline), code placement, not work.
     if (NREG != 4 || p.combine == 0) {  // ---- one reducer: the block of the tile's LAST K slice (its own partial never leaves the block)
         const uint32_t tb0 = (uint32_t)tblk * (uint32_t)(S - 1) * (uint32_t)p.tiles;  // this token block's slabs: [S-1][tiles]
-        const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)((gridDim.x / (p.tiles * S)) * (S - 1)) * (uint32_t)p.tiles * slab_bytes);
+        const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)(gridDim.z * (S - 1)) * (uint32_t)p.tiles * slab_bytes);
         if (slice != S - 1) {
             for (int qd = tid; qd < quads; qd += NWAVES * 64) {
                 u32x4 b = __builtin_bit_cast(u32x4, block_sum4(qd));
@@ -582,7 +589,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
     }
     if constexpr (NREG == 4) {  // batch rows > 1 only: the M = 1 instantiations do not carry this code
         const uint32_t tb0 = (uint32_t)tblk * (uint32_t)S * (uint32_t)p.tiles;  // this token block's slabs: [S][tiles]
-        const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)((gridDim.x / (p.tiles * S)) * S) * (uint32_t)p.tiles * slab_bytes);
+        const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)(gridDim.z * S) * (uint32_t)p.tiles * slab_bytes);
         // Reducer ranges are whole 64-quad blocks (quads = 64 M with 256-column tiles), so a wave is either all
         // "store" or all "reduce" in an iteration; a reducer walks the quads starting AFTER its own range, i.e.
         // stores everything the other reducers wait for before it starts waiting itself.
@@ -766,6 +773,25 @@ int reducers_per_tile(int S, int tile_blocks, int M, bool whole_tile) {
     return rlog;  // log2 of the count
 }
 
+// exact for the ranges the kernel divides: x < limit, magic = floor(2^32 / d) + 1 is exact while x * (d - 2^32 % d) < 2^32
+bool magic_for(uint32_t d, uint32_t limit, uint32_t* out) {
+    if (d == 0) return false;
+    const uint64_t m = ((uint64_t)1 << 32) / d + 1;
+    if (m >> 32) {  // d == 1
+        *out = 0;
+        return false;
+    }
+    const uint64_t e = m * d - ((uint64_t)1 << 32);  // 1 .. d
+    if ((uint64_t)limit * e >= ((uint64_t)1 << 32)) return false;
+    *out = (uint32_t)m;
+    return true;
+}
+
+bool set_magics(GemvMfmaParams& p) {
+    return magic_for((uint32_t)p.g, (uint32_t)p.K + 64u, &p.g_magic) &&
+           magic_for((uint32_t)(p.rows_per_block >> 3), 17u * (uint32_t)(p.rows_per_block >> 3) + 1u, &p.xc_magic);
+}
+
 size_t gemv_lds_bytes(int M, int CW, int nwaves, int rows_per_block, int ng_max) {
     const size_t staging = (size_t)(M + 1) * rows_per_block * 2 + (size_t)ng_max * (CW / 2 + 2 * CW);
     const size_t red = (size_t)nwaves * M * (CW + 16) * 4;
@@ -914,6 +940,7 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     const int rlog = reducers_per_tile(c.S, tiles * max_blocks, a.M, a.ssq_out != nullptr);
     p.rows_per_block = c.rows_per_block;
     p.ng_max = c.ng_max;
+    if (!set_magics(p)) return AWQ_ERR_UNSUPPORTED;
     p.combine = rlog ? 1 + rlog : 0;
     p.slabs = a.exchange;
     p.scratch = nullptr;
@@ -922,7 +949,7 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     p.pair_weights = pair_weights;
     p.num_pairs = num_pairs; p.x_div = x_div;
     p.expert_qw_words = expert_qw_words; p.expert_z_words = expert_z_words; p.expert_s_halfs = expert_s_halfs;
-    dim3 grid((unsigned)(tiles * c.S * max_blocks));
+    dim3 grid((unsigned)tiles, (unsigned)c.S, (unsigned)max_blocks);
     if (a.M == 8) {
         if (c.unit == 2) launch_moe<2, true>(p, grid, c.lds, a.stream);
         else if (c.unit == 4) launch_moe<4, true>(p, grid, c.lds, a.stream);
@@ -964,6 +991,7 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
     const int rlog = reducers_per_tile(c.S, tiles, a.M, a.ssq_out != nullptr);
     p.rows_per_block = c.rows_per_block;
     p.ng_max = c.ng_max;
+    if (!set_magics(p)) return AWQ_ERR_UNSUPPORTED;
     p.combine = two_pass ? 1 : (rlog ? 1 + rlog : 0);
     p.slabs = a.exchange;
     p.scratch = a.partial;
@@ -972,7 +1000,7 @@ int awq_launch_gemv_mfma(const AwqGemmArgs& a, int wpl, int nwaves, int unit, in
     p.num_pairs = 0; p.x_div = 1; p.expert_qw_words = p.expert_z_words = p.expert_s_halfs = 0;
     if (c.S > 1 && !two_pass && (!a.exchange || !a.counters)) return AWQ_ERR_WORKSPACE;
     if (c.S > 1 && two_pass && !a.partial) return AWQ_ERR_WORKSPACE;
-    dim3 grid((unsigned)(tiles * c.S));
+    dim3 grid((unsigned)tiles, (unsigned)c.S, 1u);
     bool ok = false;
 #define AWQ_GEMV_CASE(W, V, U) \
     if (c.wpl == W && c.nwaves == V && c.unit == U) ok = launch3<W, V, U>(p, grid, c.lds, a.stream);
