@@ -11,6 +11,17 @@ int awq_launch_dequant(const int32_t* qweight, const uint16_t* scales, const int
                        int64_t K, int64_t N, int64_t g, hipStream_t stream);
 int awq_launch_unpack(const int32_t* q, uint8_t* out, int64_t rows, int64_t words, hipStream_t stream);
 
+// Division by a run-time constant without an integer divide on the device: (x * magic) >> 32 == x / d for every x < limit.
+// magic = floor(2^32 / d) + 1 is exact while x * (magic * d - 2^32) < 2^32.  False if d == 1 or the range is too large.
+inline bool awq_magic_u32(uint32_t d, uint32_t limit, uint32_t* out) {
+    if (d < 2) return false;
+    const uint64_t m = ((uint64_t)1 << 32) / d + 1;
+    const uint64_t e = m * d - ((uint64_t)1 << 32);  // 1 .. d
+    if ((uint64_t)limit * e >= ((uint64_t)1 << 32)) return false;
+    *out = (uint32_t)m;
+    return true;
+}
+
 struct AwqGemmArgs {
     const uint16_t* x;       // [M, K] fp16
     const int32_t* qweight;  // [K, N/8]

@@ -28,6 +28,7 @@ struct GemvFastParams {
     half_t* y;
     int M, K, N, g;
     int GP;       // padded group rows of scales / qzeros (8*ZW)
+    uint32_t g_magic, xb_magic;  // (v * magic) >> 32 == v / {g, K/32} for the values divided (awq_magic_u32)
     int xpitch;   // halfs per staged activation row in LDS (K + 8)
 };
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_fast_kernel(GemvFastPara
     const int j = lane & 15, kb = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int M = p.M, K = p.K;
-    const int G = K / p.g;
+    const int G = (int)__umulhi((uint32_t)K, p.g_magic);
 
     FAST_STAMP(0);
     half_t* xs = reinterpret_cast<half_t*>(smem);
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_fast_kernel(GemvFastPara
     {
         const int xb = K >> 5;  // 32-K blocks per activation row
         for (int c = tid; c < (M + 1) * xb; c += NTHR) {
-            const int m = c / xb, b = c % xb;
+            const int m = (int)__umulhi((uint32_t)c, p.xb_magic), b = c - m * xb;
             u32x4 in[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_fast_kernel(GemvFastPara
             // fold: y[m][n] += s*(acc - 16*sx) + qzeros*sx; D reg r = batch row 4*kb + r
 #pragma unroll
             for (int h = 0; h < NG; ++h) {
-                const int grp = (128 * it + (128 / NG) * h) / p.g;
+                const int grp = (int)__umulhi((uint32_t)(128 * it + (128 / NG) * h), p.g_magic);
                 const float sc = (float)zsc[grp * 16 + j];
                 const float zc = __builtin_fmaf(-16.f, sc, (float)zqz[grp * 16 + j]);
 #pragma unroll
@@ -274,6 +275,8 @@ int awq_launch_gemv_fast(const uint16_t* x, const int16_t* qweight, const uint16
     p.M = M; p.K = K; p.N = N; p.g = g;
     p.GP = GP;
     p.xpitch = K + 8;
+    if (!awq_magic_u32((uint32_t)g, (uint32_t)K + 128u, &p.g_magic) || !awq_magic_u32((uint32_t)(K / 32), 17u * (uint32_t)(K / 32) + 1u, &p.xb_magic))
+        return AWQ_ERR_UNSUPPORTED;
     if (nwaves == 4 && unroll == 4) launch_fast<4, 4>(p, lds, st);
     else if (nwaves == 4 && unroll == 8) launch_fast<4, 8>(p, lds, st);
     else if (nwaves == 8 && unroll == 4) launch_fast<8, 4>(p, lds, st);

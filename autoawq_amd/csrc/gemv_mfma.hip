@@ -773,23 +773,9 @@ int reducers_per_tile(int S, int tile_blocks, int M, bool whole_tile) {
     return rlog;  // log2 of the count
 }
 
-// exact for the ranges the kernel divides: x < limit, magic = floor(2^32 / d) + 1 is exact while x * (d - 2^32 % d) < 2^32
-bool magic_for(uint32_t d, uint32_t limit, uint32_t* out) {
-    if (d == 0) return false;
-    const uint64_t m = ((uint64_t)1 << 32) / d + 1;
-    if (m >> 32) {  // d == 1
-        *out = 0;
-        return false;
-    }
-    const uint64_t e = m * d - ((uint64_t)1 << 32);  // 1 .. d
-    if ((uint64_t)limit * e >= ((uint64_t)1 << 32)) return false;
-    *out = (uint32_t)m;
-    return true;
-}
-
 bool set_magics(GemvMfmaParams& p) {
-    return magic_for((uint32_t)p.g, (uint32_t)p.K + 64u, &p.g_magic) &&
-           magic_for((uint32_t)(p.rows_per_block >> 3), 17u * (uint32_t)(p.rows_per_block >> 3) + 1u, &p.xc_magic);
+    return awq_magic_u32((uint32_t)p.g, (uint32_t)p.K + 64u, &p.g_magic) &&
+           awq_magic_u32((uint32_t)(p.rows_per_block >> 3), 17u * (uint32_t)(p.rows_per_block >> 3) + 1u, &p.xc_magic);
 }
 
 size_t gemv_lds_bytes(int M, int CW, int nwaves, int rows_per_block, int ng_max) {

@@ -37,6 +37,7 @@ struct GemvNkParams {
     int M, K, N, g;
     int KW, ZW;   // words per qweight / qzeros row
     int xpitch;   // halfs per staged activation row in LDS (K + 8)
+    uint32_t g_magic, xc1_magic, zw_magic;  // (v * magic) >> 32 == v / {g, K/8 + 1, ZW} for the values divided (awq_magic_u32); zw_magic 0: ZW == 1
 };
 
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_nk_kernel(GemvNkParams p
     {
         const int xc = K >> 3;  // 16-byte chunks per activation row
         for (int c = tid; c < (M + 1) * (xc + 1); c += NTHR) {
-            const int m = c / (xc + 1), cc = c % (xc + 1);
+            const int m = (int)__umulhi((uint32_t)c, p.xc1_magic), cc = c - m * (xc + 1);
             u32x4 v = {0u, 0u, 0u, 0u};
             if (m < M && cc < xc) {
                 const u32x4 d = *reinterpret_cast<const u32x4*>(p.x + (int64_t)m * K + 8 * cc);
@@ -106,11 +107,11 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_nk_kernel(GemvNkParams p
             *reinterpret_cast<u32x4*>(xs + (size_t)m * p.xpitch + 8 * cc) = v;
         }
         for (int c = tid; c < 16 * p.ZW; c += NTHR) {
-            const int r = c / p.ZW, w = c % p.ZW;
+            const int r = p.zw_magic ? (int)__umulhi((uint32_t)c, p.zw_magic) : c, w = c - r * p.ZW;
             zq[c] = (n0 + r < p.N) ? p.qzeros[(int64_t)(n0 + r) * p.ZW + w] : 0u;
         }
         for (int c = tid; c < 16 * p.ZW; c += NTHR) {  // 8 scales = 16 bytes per chunk
-            const int r = c / p.ZW, w = c % p.ZW;
+            const int r = p.zw_magic ? (int)__umulhi((uint32_t)c, p.zw_magic) : c, w = c - r * p.ZW;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (n0 + r < p.N) v = *reinterpret_cast<const u32x4*>(p.scales + (int64_t)(n0 + r) * SW + 8 * w);
             *reinterpret_cast<u32x4*>(zsc + r * SW + 8 * w) = v;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_nk_kernel(GemvNkParams p
 #pragma unroll
             for (int h = 0; h < NG; ++h) {
                 acc[h] = accz[h] = float4_t{0.f, 0.f, 0.f, 0.f};
-                const int grp = (128 * it + (128 / NG) * h) / p.g;
+                const int grp = (int)__umulhi((uint32_t)(128 * it + (128 / NG) * h), p.g_magic);
                 scl[h] = (float)zsc[j * SW + grp];
                 const uint32_t z = (zq[j * p.ZW + (grp >> 3)] >> (4 * (grp & 7))) & 15u;
                 const uint32_t zz = z | (z << 16);
@@ -282,6 +283,10 @@ int awq_launch_gemv_nk(const uint16_t* x, const int32_t* qweight, const uint16_t
     p.M = M; p.K = K; p.N = N; p.g = g;
     p.KW = K / 8; p.ZW = ZW;
     p.xpitch = K + 8;
+    p.zw_magic = 0;
+    if (!awq_magic_u32((uint32_t)g, (uint32_t)K + 128u, &p.g_magic) || !awq_magic_u32((uint32_t)(K / 8 + 1), 17u * (uint32_t)(K / 8 + 1) + 1u, &p.xc1_magic) ||
+        (ZW > 1 && !awq_magic_u32((uint32_t)ZW, 16u * (uint32_t)ZW + 1u, &p.zw_magic)))
+        return AWQ_ERR_UNSUPPORTED;
     const size_t lds = awq_gemv_nk_lds_bytes(M, K, ZW, nwaves);
     if (nwaves == 4 && unroll == 4) launch_nk<4, 4>(p, lds, st);
     else if (nwaves == 4 && unroll == 8) launch_nk<4, 8>(p, lds, st);
