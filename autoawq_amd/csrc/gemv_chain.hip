@@ -94,8 +94,11 @@ struct ChainLinkDev {  // one (sub-)link; 128 bytes
     int last_sub;             // 1 on the last sub-link of a Linear
     int tiles_full;           // column tiles of the whole Linear
     int pad_;
+    // (v * magic) >> 32 == v / {R, per, g} for every value the kernel divides (awq_magic_u32); per_magic 0: per == 1
+    uint32_t r_magic, per_magic, g_magic;
+    uint32_t pad2_[5];
 };
-static_assert(sizeof(ChainLinkDev) == 128, "ChainLinkDev layout");
+static_assert(sizeof(ChainLinkDev) == 160, "ChainLinkDev layout");
 
 struct ChainHeader {  // 128 bytes, followed by the links
     uint32_t magic, n_links, G, M;
@@ -105,7 +108,8 @@ struct ChainHeader {  // 128 bytes, followed by the links
     unsigned long long* trace;  // debug: [n_links][G][NWAVES][4] wall_clock64 stamps, or null
     uint32_t inflight;          // fills the loader keeps in flight (1 .. 3)
     uint32_t slack;             // slabs a gather may still miss when it starts (0 | 1)
-    uint32_t pad_[18];
+    uint32_t ns_magic;          // (f * ns_magic) >> 32 == f / ring_slots(M) for every fill number f
+    uint32_t pad_[17];
 };
 static_assert(sizeof(ChainHeader) == 128, "ChainHeader layout");
 
@@ -170,7 +174,7 @@ struct SlabRange {
 };
 AWQ_DEV SlabRange slab_range(const ChainLinkDev& P, int M, int col) {
     const int tp = col >> 8;                 // tile of the Linear
-    const int tl = tp % P.per;               // tile within its sub-link: unit numbering restarts there
+    const int tl = P.per_magic ? tp - (int)__umulhi((uint32_t)tp, P.per_magic) * P.per : 0;  // tile within its sub-link: unit numbering restarts there
     const int b_lo = (tl * P.R) / UPB, b_hi = ((tl + 1) * P.R - 1) / UPB;
     SlabRange r;
     r.S = b_hi - b_lo + 1;
@@ -322,6 +326,9 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
     const int G = (int)plan->G;
     const int n_links = (int)plan->n_links;
     const int NS = ring_slots(M);
+    const uint32_t ns_magic = plan->ns_magic;
+    auto ring_div = [&](uint32_t f) -> uint32_t { return __umulhi(f, ns_magic); };              // f / NS
+    auto ring_mod = [&](uint32_t f) -> uint32_t { return f - __umulhi(f, ns_magic) * (uint32_t)NS; };  // f % NS
     const ChainLinkDev* __restrict__ links = reinterpret_cast<const ChainLinkDev*>(plan + 1);
     ChainCtrl* ctrl = reinterpret_cast<ChainCtrl*>(ws);
     const rsrc_t slres = mk_rsrc(ws + CTRL_BYTES, (uint32_t)plan->slab_bytes);
@@ -382,11 +389,11 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
             const int nblk = units_here(L);
             const uint32_t row_bytes = (uint32_t)(L.N >> 3) * 4u;
             for (int i = 0; i < nblk; ++i, ++f) {
-                const int slot = (int)(f % (uint32_t)NS);
+                const int slot = (int)ring_mod(f);
                 if (f >= (uint32_t)NS) {  // the slot's previous tenant has been read by both of its waves
                     unsigned spins = 0;
                     unsigned long long t0 = 0;
-                    while (lds_read(freed_a + 4u * slot) != (uint32_t)WPU * (f / (uint32_t)NS)) {
+                    while (lds_read(freed_a + 4u * slot) != (uint32_t)WPU * ring_div(f)) {
                         __builtin_amdgcn_s_sleep(2);
                         if ((++spins & 63u) == 0) {
                             const unsigned long long now = wall_clock64();
@@ -398,7 +405,8 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
                 }
                 if (i == 0) stamp(l, 0);
                 const int u = b * UPB + i;
-                const int tile = L.tile0 + u / L.R, row0 = (u % L.R) * 128;
+                const int uq = (int)__umulhi((uint32_t)u, L.r_magic);
+                const int tile = L.tile0 + uq, row0 = (u - uq * L.R) * 128;
                 unsigned char* const dst = ring + (size_t)slot * SLOT_BYTES;
                 // 16 x 1 KiB: instruction k moves rows row0 + 8k .. + 7, 128 bytes each (lane = row rr, 16-byte chunk cc)
                 const uint32_t coff = min((uint32_t)tile * 128u + (uint32_t)cc * 16u, row_bytes - 16u);  // ragged last tile: stay inside the row
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
                 for (int k = 0; k < 16; ++k)
                     __builtin_amdgcn_global_load_lds((gl_ptr_t)(src + (size_t)k * 8u * row_bytes), (lds_ptr_t)(dst + k * 1024), 16, 0, 2 /* nt */);
                 {   // the group's zeros (lanes 0-7: 128 bytes) and scales (lanes 8-39: 512 bytes) behind the weights
-                    const int grp = row0 / L.g;
+                    const int grp = (int)__umulhi((uint32_t)row0, L.g_magic);
                     const unsigned char* zs;
                     if (lane < 8) zs = reinterpret_cast<const unsigned char*>(L.qzeros) + (size_t)grp * row_bytes +
                                        min((uint32_t)tile * 128u + (uint32_t)lane * 16u, row_bytes - 16u);
@@ -419,15 +427,15 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
                 if (lag == 2u) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
                 else if (lag == 1u) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (f >= lag) lds_write(ready_a + 4u * ((f - lag) % (uint32_t)NS), f - lag + 1u);
+                if (f >= lag) lds_write(ready_a + 4u * ring_mod(f - lag), f - lag + 1u);
             }
         }
         if (lag == 2u) {
             asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-            if (f >= 2u) lds_write(ready_a + 4u * ((f - 2u) % (uint32_t)NS), f - 1u);
+            if (f >= 2u) lds_write(ready_a + 4u * ring_mod(f - 2u), f - 1u);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lag >= 1u && f >= 1u) lds_write(ready_a + 4u * ((f - 1u) % (uint32_t)NS), f);
+        if (lag >= 1u && f >= 1u) lds_write(ready_a + 4u * ring_mod(f - 1u), f);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         return;
     }
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
 #pragma unroll
             for (int i = 0; i < UPP; ++i) {
                 has[i] = pw * UPP + i < nblk;
-                kg[i] = (b * UPB + pw * UPP + i) % L.R;
+                kg[i] = (b * UPB + pw * UPP + i) - (int)__umulhi((uint32_t)(b * UPB + pw * UPP + i), L.r_magic) * L.R;
                 any |= has[i];
             }
             if (any) {
@@ -561,9 +569,9 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
         const int nblk = units_here(L);
         const bool has = ui < nblk;
         const int u0 = b * UPB;
-        const int tloc = (u0 + ui) / R;  // tile within the sub-link
+        const int tloc = (int)__umulhi((uint32_t)(u0 + ui), L.r_magic);  // tile within the sub-link
         // the block's units u0 .. u0 + nblk - 1 touch at most two tiles (R >= UPB): group 0 = the first unit's tile
-        const int t_first = u0 / R;
+        const int t_first = (int)__umulhi((uint32_t)u0, L.r_magic);
         const int n0 = min(nblk, (t_first + 1) * R - u0);
         const int n1 = nblk - n0;
         const int grp = (has && tloc != t_first) ? 1 : 0;
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(NTHR, (NWAVES + 3) / 4) void awq_chain_kernel(const
         if (has) {
             stamp(l, 0);
             const uint32_t f = fbase + (uint32_t)ui;
-            const int slot = (int)(f % (uint32_t)NS);
+            const int slot = (int)ring_mod(f);
             const unsigned char* const wb = ring + (size_t)slot * SLOT_BYTES;
             {   // the unit's weights have landed in the ring, the poll wave has staged its 128 activations per batch row
                 unsigned spins = 0;
@@ -834,6 +842,10 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
             d.tiles = (sidx + 1) * L.per <= L.tiles ? L.per : L.tiles - sidx * L.per;
             d.tiles_full = L.tiles;
             d.R = L.R;
+            d.per_magic = 0;
+            if (!awq_magic_u32((uint32_t)L.R, 1u << 20, &d.r_magic) || !awq_magic_u32((uint32_t)a.group_size, (uint32_t)a.K + 128u, &d.g_magic) ||
+                (L.per > 1 && !awq_magic_u32((uint32_t)L.per, 1u << 20, &d.per_magic)))
+                return AWQ_ERR_UNSUPPORTED;
             d.units = d.tiles * L.R;
             d.per = L.per;
             d.smax = L.smax;
@@ -858,6 +870,7 @@ int awq_chain_build(const AwqChainLink* links, int64_t n, int64_t M, void* works
     {
         const char* e = getenv("AWQ_CHAIN_INFLIGHT");
         const int v = e ? atoi(e) : 3;
+        if (!awq_magic_u32((uint32_t)ring_slots((int)M), 1u << 20, &H->ns_magic)) return AWQ_ERR_UNSUPPORTED;
         H->inflight = (uint32_t)(v < 1 ? 1 : (v > 3 ? 3 : v));
         const char* e2 = getenv("AWQ_CHAIN_SLACK");
         H->slack = e2 ? (uint32_t)(atoi(e2) != 0) : 1u;
