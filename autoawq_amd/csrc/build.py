@@ -18,7 +18,7 @@ OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-         "-fvisibility-inlines-hidden", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+         "-fvisibility-inlines-hidden", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include")]
 
 

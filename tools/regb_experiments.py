@@ -19,7 +19,7 @@ def build():
     if os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-                           "-fno-slp-vectorize", "-DAWQ_REGB_EXPERIMENTS", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", OUT])
+                           "-fno-slp-vectorize", "-Wno-inline-asm", "-DAWQ_REGB_EXPERIMENTS", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", OUT])
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ def build():
     if os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-fno-slp-vectorize", "-DAWQ_GEMV_TRACE", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", OUT]
+           "-fno-slp-vectorize", "-Wno-inline-asm", "-DAWQ_GEMV_TRACE", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", OUT]
     subprocess.check_call(cmd)
 
 
