@@ -62,6 +62,9 @@ int awq_launch_gemm_tiled(const AwqGemmArgs& a, int bn, int splitk);
 // Prefill GEMM with the weight operand decoded in registers (gemm_regb.hip).  bm: rows per block tile (128|256, 0 = auto).
 bool awq_gemm_regb_supports(int M, int K, int N, int g);
 int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm);
+// Batched-decode GEMM, 17 <= M <= 64, weights decoded in registers, no barrier in the K loop (gemm_skinny.hip).
+bool awq_gemm_skinny_supports(int M, int K, int N, int g);
+int awq_launch_gemm_skinny(const AwqGemmArgs& a, int splitk);
 // GEMV layout (qweight [N, K/8], qzeros [N, ZW], scales [N, 8*ZW]): MFMA GEMV, M <= 16, and the
 // bit-exact dequant to W^T [N, K].  nwaves (4|8|16) / unroll (4|8): 0 = auto.
 bool awq_gemv_nk_supports(int M, int K, int N, int g);

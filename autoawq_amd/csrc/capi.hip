@@ -142,6 +142,7 @@ namespace {
 // profiles/r02_regb_by_m.txt: 4096 x 11008 from M = 768, 11008 x 4096 from M = 2048); below that the LDS-tiled kernel with
 // split-K (smaller tiles, in-launch combine) fills the chip better.
 unsigned auto_kernel_large(int M, int K, int N, int g) {
+    if (M <= 64 && awq_gemm_skinny_supports(M, K, N, g)) return AWQ_GEMM_KERNEL_SKINNY;
     if (awq_gemm_regb_supports(M, K, N, g) && (int64_t)((M + 127) / 128) * ((N + 255) / 256) >= 256) return AWQ_GEMM_KERNEL_REGB;
     if (awq_gemm_tiled_supports(M, K, N, g)) return AWQ_GEMM_KERNEL_TILED;
     return AWQ_GEMM_KERNEL_NAIVE;  // odd shapes
@@ -226,6 +227,10 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
         case AWQ_GEMM_KERNEL_TILED: {
             g_last_kernel = "gemm_tiled";
             return awq_launch_gemm_tiled(a, nlog == 2 ? 256 : (nlog == 1 ? 128 : 0), splitk);
+        }
+        case AWQ_GEMM_KERNEL_SKINNY: {
+            g_last_kernel = "gemm_skinny";
+            return awq_launch_gemm_skinny(a, splitk);
         }
         case AWQ_GEMM_KERNEL_REGB: {
             g_last_kernel = "gemm_regb";

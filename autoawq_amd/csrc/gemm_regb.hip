@@ -114,22 +114,36 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
     const u32x4 zsrd = srd(p.qzeros, (uint32_t)(p.K / p.g) * row_bytes);
     const u32x4 ssrd = srd(p.scales, (uint32_t)(p.K / p.g) * (uint32_t)p.N * 2u);
     const u32x4 xsrd = srd(p.x, (uint32_t)((int64_t)p.M * p.K * 2));
+// Eight weight words / the group's zero word and scales in ONE asm statement each, opened by s_nop 4: an SGPR written by
+// the SALU (the scalar offsets, a rematerialised descriptor) needs five wait states before a VMEM instruction may read
+// it, and hipcc pads nothing for the operands of an asm statement -- without the nop a load now and then used the
+// PREVIOUS value of its offset register (rare wrong tiles that came and went with the schedule).
+#define AWQ_BLOAD8(W, voff, rs, so)                                                                                          \
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %8, %9, %10 offen\n\tbuffer_load_dword %1, %8, %9, %11 offen\n\t"                \
+                 "buffer_load_dword %2, %8, %9, %12 offen\n\tbuffer_load_dword %3, %8, %9, %13 offen\n\t"                          \
+                 "buffer_load_dword %4, %8, %9, %14 offen\n\tbuffer_load_dword %5, %8, %9, %15 offen\n\t"                          \
+                 "buffer_load_dword %6, %8, %9, %16 offen\n\tbuffer_load_dword %7, %8, %9, %17 offen"                              \
+                 : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]), "=v"(W[4]), "=v"(W[5]), "=v"(W[6]), "=v"(W[7])                  \
+                 : "v"(voff), "s"(rs), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]), "s"(so[4]), "s"(so[5]), "s"(so[6]), "s"(so[7]))
+#define AWQ_BLOADZS(Z, S2, zvoff, zrs, zso, svoff, srs, sso)                                                                  \
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %5, %6, %7 offen"                        \
+                 : "=v"(Z), "=v"(S2)                                                                                        \
+                 : "v"(zvoff), "s"(zrs), "s"(zso), "v"(svoff), "s"(srs), "s"(sso))
 #define AWQ_BLOAD1(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff))
 #define AWQ_BLOAD2(dst, voff, rs, soff) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff))
     constexpr int B_OPS = 18;  // vector-memory operations of one fetch_b
     auto fetch_b = [&](BRegs& R, int t) {
         const uint32_t k0 = (uint32_t)t * BK;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+            uint32_t so[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t so = (k0 + 32u * kk + r) * row_bytes;
-                AWQ_BLOAD1(R.w[kk][r], w_voff, wsrd, so);
-            }
+            for (int r = 0; r < 8; ++r) so[r] = (k0 + 32u * kk + r) * row_bytes;
+            AWQ_BLOAD8(R.w[kk], w_voff, wsrd, so);
+        }
         const uint32_t grp = __umulhi(k0, g_magic);
         const uint32_t zo = grp * row_bytes, so2 = grp * (uint32_t)p.N * 2u;
-        AWQ_BLOAD1(R.z, z_voff, zsrd, zo);
-        AWQ_BLOAD2(R.s, s_voff, ssrd, so2);
+        AWQ_BLOADZS(R.z, R.s, z_voff, zsrd, zo, s_voff, ssrd, so2);
     };
     // everything up to and including R's requests has returned once at most `newer` later operations are outstanding
 #define AWQ_WAIT_B(R, newer)                                                                                              \
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
     const uint32_t a_dst0 = lds0 + (uint32_t)(PIECES * wave) * 1024u;
     // s_nop: an SALU write of M0 needs one wait state before an LDS-DMA reads it
 #define AWQ_DMA16(ldsaddr, voff, rs, soff)                                                                    \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsaddr), "v"(voff), \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsaddr), "v"(voff), \
                  "s"(rs), "s"(soff)                                                                            \
                  : "m0")
     auto fetch_a = [&](int t, int buf) {
@@ -282,7 +296,11 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         step(t + 1, B1, B0);
     }
     if (t < T) step(t, B0, B1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in LDS after this block has released it
+    // no DMA may land in LDS after this block has released it -- and the last weight request (a repeat nobody consumes)
+    // must have landed before its destination registers, dead to the compiler since they were requested, are re-used:
+    // the waits NAME both register sets
+    AWQ_WAIT_B(B0, 0);
+    AWQ_WAIT_B(B1, 0);
 
     // ---- epilogue: lane (j, kb) holds rows 16 i + 4 kb + e, columns 8 j + 4 ph + c of its wave tile
     const int col = n0 + set * 128 + 8 * j + 4 * ph;

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 # kernel-selection flags (mirror include/awq_hip.h)
-KERNEL_AUTO, KERNEL_NAIVE, KERNEL_VALU, KERNEL_MFMA_GEMV, KERNEL_TILED, KERNEL_REGB = 0, 1, 2, 3, 4, 5
+KERNEL_AUTO, KERNEL_NAIVE, KERNEL_VALU, KERNEL_MFMA_GEMV, KERNEL_TILED, KERNEL_REGB, KERNEL_SKINNY = 0, 1, 2, 3, 4, 5, 6
 FLAG_TWO_PASS = 1 << 16
 FLAG_NO_NT = 1 << 17
 

@@ -95,6 +95,7 @@ AWQ_EXPORT int awq_gemm_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t gro
 #define AWQ_GEMM_KERNEL_MFMA_GEMV 3u /* MFMA 16x16x32 streaming GEMV / skinny GEMM, M <= 16 */
 #define AWQ_GEMM_KERNEL_TILED 4u     /* LDS-tiled MFMA GEMM with fused dequant, large M */
 #define AWQ_GEMM_KERNEL_REGB 5u      /* MFMA GEMM, weights decoded in registers, activations by LDS-DMA: prefill (NLOG: 1 = 128-, 2 = 256-row tile) */
+#define AWQ_GEMM_KERNEL_SKINNY 6u    /* batched decode, 17 <= M <= 64: weights decoded in registers, activations of the K slice in LDS, no barrier in the K loop */
 #define AWQ_GEMM_FLAG_KERNEL(f) ((f)&0xFu)
 #define AWQ_GEMM_FLAG_NLOG(f) (((f) >> 4) & 0xFu)   /* 0 = auto; VALU: log2 column lanes (2..4); MFMA_GEMV: words per lane (2|4); TILED: 1 = 128-, 2 = 256-column tile */
 #define AWQ_GEMM_FLAG_SPLITK(f) (((f) >> 8) & 0xFFu) /* 0 = auto */

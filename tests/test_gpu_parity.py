@@ -221,6 +221,38 @@ def test_regb_gemm_vs_oracle(ops, oracle, K, N, g, M, bm):
     assert diff.numel() == 0, f"one-hot rows differ at {diff[:48].tolist()} ({diff.shape[0]} elements)"
 
 
+@pytest.mark.parametrize("K,N,g", [(512, 256, 128), (1024, 384, 64), (256, 136, 64), (4096, 512, 128), (2048, 2048, 2048), (192, 264, 192), (4096, 4096, 128)])
+@pytest.mark.parametrize("M", [17, 32, 33, 50, 64])
+def test_skinny_gemm_vs_oracle(ops, oracle, K, N, g, M):
+    """Batched-decode GEMM (csrc/gemm_skinny.hip, 17 <= M <= 64): exact fp16 weights, fp32 accumulation -- against the
+    oracle with bias for the auto split and forced K splits (one slice, as many as the reducers, more), ragged M / N tiles,
+    groups of 64 / 128 / 192 / K rows; row-exact against the bit-exact dequantised W with one-hot activations; bitwise
+    repeatable; exchange region back in its initial state."""
+    qw, qz, s, x, bias = fullrange_case(K, N, g, M, seed=K + N + M, realistic=(N % 64 == 0))
+    y32, _ = oracle.linear_gemm(x.numpy(), qw.numpy(), qz.numpy(), s.numpy(), g, bias.numpy())
+    ran = 0
+    for sk in (0, 1, 2, 4, 5, 8):
+        fl = ops.gemm_flags(ops.KERNEL_SKINNY, splitk=sk)
+        try:
+            y = ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), flags=fl)
+        except Exception as e:  # a split the shape cannot take (fewer 64-row steps than slices, fewer slices than reducers)
+            assert "no kernel" in str(e) or "unsupported" in str(e).lower(), e
+            continue
+        ran += 1
+        assert ops.last_kernel() == "gemm_skinny"
+        assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"skinny K{K} N{N} g{g} M{M} s{sk}")
+        assert torch.equal(y, ops.gemm_forward(x.cuda(), qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), flags=fl))
+    assert ran >= 2
+    assert ops.workspace_is_clean(y.device)
+    W = ops.dequantize_weights(qw.cuda(), s.cuda(), qz.cuda())
+    e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    ks = (torch.arange(M, device="cuda") * 7 + 3) % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    out = ops.gemm_forward(e, qw.cuda(), s.cuda(), qz.cuda(), flags=ops.gemm_flags(ops.KERNEL_SKINNY))
+    diff = torch.nonzero(out != W[ks])
+    assert diff.numel() == 0, f"one-hot rows differ at {diff[:48].tolist()} ({diff.shape[0]} elements)"
+
+
 def test_regb_gemm_refuses_what_it_cannot_run(ops):
     """K not a multiple of 64 / groups of 32 rows: the launcher says UNSUPPORTED (the caller's fallback is gemm_tiled)."""
     from autoawq_amd import _lib
