@@ -229,8 +229,13 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
             return awq_launch_gemm_tiled(a, nlog == 2 ? 256 : (nlog == 1 ? 128 : 0), splitk);
         }
         case AWQ_GEMM_KERNEL_SKINNY: {
-            g_last_kernel = "gemm_skinny";
-            return awq_launch_gemm_skinny(a, splitk);
+            rc = awq_launch_gemm_skinny(a, splitk);
+            if (rc != AWQ_ERR_UNSUPPORTED || AWQ_GEMM_FLAG_KERNEL(flags) != AWQ_GEMM_KERNEL_AUTO || !awq_gemm_tiled_supports(a.M, a.K, a.N, a.g)) {
+                g_last_kernel = "gemm_skinny";
+                return rc;
+            }
+            g_last_kernel = "gemm_tiled";  // AUTO: a slice that does not fit (very wide matrices at M > 32): the LDS-tiled kernel
+            return awq_launch_gemm_tiled(a, 0, 0);
         }
         case AWQ_GEMM_KERNEL_REGB: {
             g_last_kernel = "gemm_regb";

@@ -354,12 +354,12 @@ int awq_launch_gemm_skinny(const AwqGemmArgs& a, int splitk) {
     const int MI = a.M <= 32 ? 2 : 4, BM = 16 * MI, R = MI >= 4 ? 4 : 2;
     const int tiles = (a.N + 255) / 256, T = a.K / 64;
     const size_t tile_bytes = (size_t)4 * MI * 4 * 1024;
-    // as many slices as give every CU two blocks, while the exchange stays below the weight bytes (S M N 4 <= K N / 2),
-    // every K half keeps a step, the activation slice fits 96 KB of LDS and the slabs fit the workspace
-    int S = splitk > 0 ? splitk : (512 + tiles - 1) / tiles;
+    // K split (r02 sweep, profiles/r02_skinny_sweep.txt): wide matrices (>= 32 column tiles) want FOUR long slices (4096 x
+    // 11008, M = 32: 14.1 us at S = 4, 18.8-20.7 at 6-8; the exchange grows with S M N), narrow ones a slice of ~512 rows
+    // (4096 x 4096: S = 8; 11008 x 4096: S = 16); the activation slice has to fit 96 KB of LDS (below)
+    int S = splitk > 0 ? splitk : (tiles >= 32 ? 4 : a.K / 512);
     if (splitk <= 0) {
-        const int cap = a.K / (8 * BM);
-        if (S > cap) S = cap;
+        if (S < 4) S = 4;
         if (S > 16) S = 16;
     }
     if (S > T / 2) S = T / 2;
@@ -368,11 +368,16 @@ int awq_launch_gemm_skinny(const AwqGemmArgs& a, int splitk) {
     const int sps_max = (96 * 1024) / (BM * 128);
     if (sps > sps_max) sps = sps_max;  // more slices than asked for: the slice has to fit
     S = (T + sps - 1) / sps;
-    if (S > 1 && S < R) {  // the reducers are the last R slices
-        if (T / 2 < R) return AWQ_ERR_UNSUPPORTED;
-        sps = (T + R - 1) / R;
-        S = (T + sps - 1) / sps;
-        if (S < R) return AWQ_ERR_UNSUPPORTED;
+    if (S > 1 && S < R) {  // the reducers are the last R slices: fewer slices than that -> exactly R, or no split at all
+        if (T / 2 >= R) {
+            sps = (T + R - 1) / R;
+            S = (T + sps - 1) / sps;
+        }
+        if (S < R) {
+            S = 1;
+            sps = T;
+            if (sps > sps_max) return AWQ_ERR_UNSUPPORTED;
+        }
     }
     if (S > 1) {
         if (!a.exchange || !a.counters) return AWQ_ERR_WORKSPACE;

@@ -312,10 +312,11 @@ def test_tiled_large_grid_k32_tile(ops, M):
 def test_auto_dispatch_by_m(ops):
     qw, qz, s, x, _ = fullrange_case(512, 256, 128, 40, seed=9, realistic=True)
     dq, dz, ds = qw.cuda(), qz.cuda(), s.cuda()
-    for M, want in [(1, "gemv_mfma"), (16, "gemv_mfma"), (17, "gemm_tiled"), (40, "gemm_tiled")]:
+    for M, want in [(1, "gemv_mfma"), (16, "gemv_mfma"), (17, "gemm_skinny"), (40, "gemm_skinny")]:
         ops.gemm_forward(x[:M].cuda(), dq, ds, dz)
         assert ops.last_kernel() == want, (M, ops.last_kernel())
-        assert ops.auto_kernel(M, 512, 256, 128) == {"gemv_mfma": ops.KERNEL_MFMA_GEMV, "gemm_tiled": ops.KERNEL_TILED}[want]
+        assert ops.auto_kernel(M, 512, 256, 128) == {"gemv_mfma": ops.KERNEL_MFMA_GEMV, "gemm_skinny": ops.KERNEL_SKINNY}[want]
+    assert ops.auto_kernel(100, 512, 256, 128) == ops.KERNEL_TILED and ops.auto_kernel(40, 512, 256, 32) == ops.KERNEL_TILED
     # prefill sizes whose 128 x 256 tiles give every CU a block go to the register-decoded kernel (host-only query)
     assert ops.auto_kernel(1024, 4096, 11008, 128) == ops.KERNEL_REGB and ops.auto_kernel(512, 4096, 11008, 128) == ops.KERNEL_TILED
     assert ops.auto_kernel(2048, 11008, 4096, 128) == ops.KERNEL_REGB and ops.auto_kernel(1024, 11008, 4096, 128) == ops.KERNEL_TILED
