@@ -141,6 +141,8 @@ namespace {
 // M > 16.  The register-decoded prefill kernel wins once its 128 x 256 tiles give every CU a block (r02 sweep,
 // profiles/r02_regb_by_m.txt: 4096 x 11008 from M = 768, 11008 x 4096 from M = 2048); below that the LDS-tiled kernel with
 // split-K (smaller tiles, in-launch combine) fills the chip better.
+bool skinny_before_decode(int64_t M, int64_t K, int64_t N) { return M >= 9 && M <= 16 && K < 8192 && (N + 255) / 256 < 64; }
+
 unsigned auto_kernel_large(int M, int K, int N, int g) {
     if (M <= 64 && awq_gemm_skinny_supports(M, K, N, g)) return AWQ_GEMM_KERNEL_SKINNY;
     if (awq_gemm_regb_supports(M, K, N, g) && (int64_t)((M + 127) / 128) * ((N + 255) / 256) >= 256) return AWQ_GEMM_KERNEL_REGB;
@@ -198,7 +200,10 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
     if ((int64_t)K * N / 2 >= ((int64_t)1 << 31)) return AWQ_ERR_UNSUPPORTED;  // 32-bit buffer offsets
 
     if (kern == AWQ_GEMM_KERNEL_AUTO) {
-        if (M <= 16 && awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2)) {
+        // 9 .. 16 rows: the register-decoded batched kernel is already ahead of the decode kernel on matrices of up to 8191
+        // rows and fewer than 64 column tiles (plain calls only; r02: 13.8 vs 15.6 us at 4096 x 11008, M = 16)
+        const bool skinny_first = skinny_before_decode(M, K, N) && !a.x_gated && !extras && awq_gemm_skinny_supports(a.M, a.K, a.N, a.g);
+        if (M <= 16 && !skinny_first && awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2)) {
             rc = awq_launch_gemv_mfma(a, 0, 0, 0, 0, false);
             if (rc != AWQ_ERR_UNSUPPORTED) {
                 g_last_kernel = "gemv_mfma";
@@ -206,7 +211,7 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
             }
         }
         if (a.x_gated || extras) return AWQ_ERR_UNSUPPORTED;
-        kern = M > 16 ? auto_kernel_large(a.M, a.K, a.N, a.g) : AWQ_GEMM_KERNEL_NAIVE;  // M <= 16 that the decode kernel refused: odd shapes
+        kern = (M > 16 || skinny_first) ? auto_kernel_large(a.M, a.K, a.N, a.g) : AWQ_GEMM_KERNEL_NAIVE;  // M <= 16 that the decode kernel refused: odd shapes
     }
     switch (kern) {
         case AWQ_GEMM_KERNEL_NAIVE:
@@ -250,6 +255,7 @@ int gemm_forward_impl(const uint16_t* x, const int32_t* qweight, const uint16_t*
 
 int awq_gemm_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     if (M <= 0 || K <= 0 || N <= 0 || M > INT32_MAX || check_gemm_layout(K, N, group_size)) return -1;
+    if (skinny_before_decode(M, K, N) && awq_gemm_skinny_supports((int)M, (int)K, (int)N, (int)group_size)) return AWQ_GEMM_KERNEL_SKINNY;
     if (M <= 16 && awq_gemv_mfma_supports((int)M, (int)K, (int)N, (int)group_size, 2)) return AWQ_GEMM_KERNEL_MFMA_GEMV;
     return M > 16 ? (int)auto_kernel_large((int)M, (int)K, (int)N, (int)group_size) : (int)AWQ_GEMM_KERNEL_NAIVE;
 }

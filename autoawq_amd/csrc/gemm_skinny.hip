@@ -1,4 +1,4 @@
-// gemm_skinny.hip -- batched decode GEMM (17 <= M <= 64) on the GEMM layout, weights decoded in registers, gfx950.
+// gemm_skinny.hip -- batched decode GEMM (9 <= M <= 64) on the GEMM layout, weights decoded in registers, gfx950.
 //
 // Replaces awq_ext.gemm_forward_cuda (awq/modules/linear/gemm.py:56-58) for the batch sizes between the decode kernel
 // (gemv_mfma.hip, M <= 16) and the prefill kernel (gemm_regb.hip).  HBM-bound like the decode kernel (the matrix is
@@ -15,7 +15,9 @@
 //     the S K-slices of a tile are combined in-launch through the sentinel slabs of gemv_mfma.hip / gemm_tiled.hip,
 //     with one reducer block per group of row tiles (the last R slices), so the poll is one round trip.
 // Algorithmic bytes as in gemm_tiled.hip; roofline: HBM.  Constraints (else AWQ_ERR_UNSUPPORTED -> gemm_tiled):
-// 17 <= M <= 64, K % 64 == 0, group_size % 64 == 0, N % 8 == 0.
+// 9 <= M <= 64, K % 64 == 0, group_size % 64 == 0, N % 8 == 0.  (From 9 rows, where the decode kernel needs a second MFMA per
+// fragment and a 16-row exchange, this kernel is ahead on the 4096-row matrices -- 4096 x 11008, M = 16: 13.8 vs 15.6 us,
+// 4096 x 4096: 11.8 vs 12.9 -- and level or slightly behind on 11008 x 4096 / 4096 x 22016, which the dispatch leaves alone.)
 #include "awq_device.h"
 #include "awq_internal.h"
 #include "awq_mfma_decode.h"
@@ -343,7 +345,7 @@ int launch_skinny(const SkinnyParams& p, dim3 grid, size_t lds, hipStream_t st) 
 
 bool awq_gemm_skinny_supports(int M, int K, int N, int g) {
     uint32_t magic;
-    return M >= 17 && M <= 64 && K >= 128 && K % 64 == 0 && g % 64 == 0 && K % g == 0 && N % 8 == 0 && K < 65536 &&
+    return M >= 9 && M <= 64 && K >= 128 && K % 64 == 0 && g % 64 == 0 && K % g == 0 && N % 8 == 0 && K < 65536 &&
            (int64_t)K * (N / 8) * 4 < ((int64_t)1 << 31) && (int64_t)(K / g) * N * 2 < ((int64_t)1 << 31) &&
            awq_magic_u32((uint32_t)g, (uint32_t)K + 64u, &magic);
 }

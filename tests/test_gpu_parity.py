@@ -157,7 +157,7 @@ def test_gemm_vs_oracle_all_variants(ops, oracle, K, N, g, M):
             continue
         ran += 1
         yn = y.cpu().numpy().astype(np.float64)
-        if ops.last_kernel() in ("naive", "gemv_valu"):  # reference-order numerics: fp16-rounded weights
+        if ops.last_kernel() in ("naive", "gemv_valu", "gemm_skinny"):  # reference-order numerics: fp16-rounded weights
             assert_product_close(yn, y32, f"K{K} N{N} g{g} M{M} {vname}")
         else:
             # MFMA kernels: exact integer dot product, scale applied in fp32 -> within the
@@ -222,7 +222,7 @@ def test_regb_gemm_vs_oracle(ops, oracle, K, N, g, M, bm):
 
 
 @pytest.mark.parametrize("K,N,g", [(512, 256, 128), (1024, 384, 64), (256, 136, 64), (4096, 512, 128), (2048, 2048, 2048), (192, 264, 192), (4096, 4096, 128)])
-@pytest.mark.parametrize("M", [17, 32, 33, 50, 64])
+@pytest.mark.parametrize("M", [9, 13, 16, 17, 32, 33, 50, 64])
 def test_skinny_gemm_vs_oracle(ops, oracle, K, N, g, M):
     """Batched-decode GEMM (csrc/gemm_skinny.hip, 17 <= M <= 64): exact fp16 weights, fp32 accumulation -- against the
     oracle with bias for the auto split and forced K splits (one slice, as many as the reducers, more), ragged M / N tiles,
@@ -312,11 +312,12 @@ def test_tiled_large_grid_k32_tile(ops, M):
 def test_auto_dispatch_by_m(ops):
     qw, qz, s, x, _ = fullrange_case(512, 256, 128, 40, seed=9, realistic=True)
     dq, dz, ds = qw.cuda(), qz.cuda(), s.cuda()
-    for M, want in [(1, "gemv_mfma"), (16, "gemv_mfma"), (17, "gemm_skinny"), (40, "gemm_skinny")]:
+    for M, want in [(1, "gemv_mfma"), (8, "gemv_mfma"), (9, "gemm_skinny"), (16, "gemm_skinny"), (17, "gemm_skinny"), (40, "gemm_skinny")]:
         ops.gemm_forward(x[:M].cuda(), dq, ds, dz)
         assert ops.last_kernel() == want, (M, ops.last_kernel())
         assert ops.auto_kernel(M, 512, 256, 128) == {"gemv_mfma": ops.KERNEL_MFMA_GEMV, "gemm_skinny": ops.KERNEL_SKINNY}[want]
     assert ops.auto_kernel(100, 512, 256, 128) == ops.KERNEL_TILED and ops.auto_kernel(40, 512, 256, 32) == ops.KERNEL_TILED
+    assert ops.auto_kernel(16, 11008, 4096, 128) == ops.KERNEL_MFMA_GEMV and ops.auto_kernel(16, 4096, 22016, 128) == ops.KERNEL_MFMA_GEMV
     # prefill sizes whose 128 x 256 tiles give every CU a block go to the register-decoded kernel (host-only query)
     assert ops.auto_kernel(1024, 4096, 11008, 128) == ops.KERNEL_REGB and ops.auto_kernel(512, 4096, 11008, 128) == ops.KERNEL_TILED
     assert ops.auto_kernel(2048, 11008, 4096, 128) == ops.KERNEL_REGB and ops.auto_kernel(1024, 11008, 4096, 128) == ops.KERNEL_TILED
@@ -670,7 +671,7 @@ def test_gated_silu_staging_equals_separate_kernel(ops, M, K, N):
     gen = torch.Generator().manual_seed(M)
     gu = (torch.randn((M, 2 * K), generator=gen) * 2).half().cuda()
     dq, ds, dz, db = qw.cuda(), s.cuda(), qz.cuda(), bias.cuda()
-    want = ops.gemm_forward(ops.silu_and_mul(gu), dq, ds, dz, db)
+    want = ops.gemm_forward(ops.silu_and_mul(gu), dq, ds, dz, db, flags=ops.gemm_flags(ops.KERNEL_MFMA_GEMV))  # the same kernel, plain
     got = ops.gemm_forward(gu, dq, ds, dz, db, flags=ops.X_GATED_SILU)
     assert ops.last_kernel() == "gemv_mfma"
     assert torch.equal(got, want)
