@@ -19,8 +19,8 @@ from ... import ops
 from ...utils.packing import pack_rows_int4, quantize_int_weights_kn
 
 # Dispatch by token count M (measured on MI355X, profiles/r02_regb_by_m.txt, r01_gemm_tiled_vs_two_pass.txt, r01_small_m.txt):
-# M <= 16 decode kernel (csrc/gemv_mfma.hip);  17..128 fused dequant + MFMA GEMM with split-K (csrc/gemm_tiled.hip: 21-37 us
-# vs 42-53 us for the two-pass route at 4096x11008);  prefill sizes whose 128 x 256 tiles fill the chip: the fused
+# M <= 8 decode kernel (csrc/gemv_mfma.hip);  9..64 the batched register-decoded kernel (csrc/gemm_skinny.hip: 14-25 us at
+# 4096x11008);  65..128 fused dequant + MFMA GEMM with split-K (csrc/gemm_tiled.hip: 37 us vs 42-53 us for the two-pass route);  prefill sizes whose 128 x 256 tiles fill the chip: the fused
 # register-decoded kernel (csrc/gemm_regb.hip; 4096x11008: 975 / 1071 / 1140 TF at M = 2048 / 4096 / 8192 vs 600 / 976 / 1043
 # for the two-pass route, 11008x4096: 924 / 1123 / 1162 vs 932 / 1198 / 1267 -- one launch, no 90 MB fp16 copy of W);
 # in between, dequant (bit-exact HIP kernel) + vendor fp16 GEMM, the reference's own large-batch route
