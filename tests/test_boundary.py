@@ -192,3 +192,31 @@ def test_no_wide_buffer_store_with_sgpr_soffset():
     rc, res = mod.main([os.path.join(csrc, "gemm_tiled.hip"), os.path.join(csrc, "gemv_mfma.hip")])
     assert rc == 0, res
     assert sum(stores for _, stores, _ in res) > 100  # the audit really saw the exchange stores
+
+
+def test_auto_dispatch_table_host_only():
+    """awq_gemm_auto_kernel is a host-only query (no launch, no GPU): which kernel awq_gemm_forward's AUTO dispatch takes
+    for the BASELINE shapes, by token count -- the table DESIGN.md section 1 (row a4/a5) describes."""
+    from autoawq_amd import _lib, ops
+
+    L = _lib.lib()
+    q = lambda M, K, N, g=128: L.awq_gemm_auto_kernel(M, K, N, g)
+    for K, N in [(4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288), (4096, 22016)]:
+        for M in (1, 2, 4, 8):
+            assert q(M, K, N) == ops.KERNEL_MFMA_GEMV
+        for M in (17, 32, 64):
+            assert q(M, K, N) == ops.KERNEL_SKINNY
+        for M in (65, 128):
+            assert q(M, K, N) == ops.KERNEL_TILED
+        assert q(16384, K, N) == ops.KERNEL_REGB
+    # 9 .. 16 rows: the batched kernel where it is ahead (up to 8191 rows, fewer than 64 column tiles), else the decode kernel
+    assert q(16, 4096, 11008) == ops.KERNEL_SKINNY and q(9, 4096, 4096) == ops.KERNEL_SKINNY
+    assert q(16, 11008, 4096) == ops.KERNEL_MFMA_GEMV and q(12, 4096, 22016) == ops.KERNEL_MFMA_GEMV
+    # the prefill kernel once 128 x 256 tiles give every CU a block
+    assert q(512, 4096, 11008) == ops.KERNEL_TILED and q(768, 4096, 11008) == ops.KERNEL_REGB
+    assert q(1024, 11008, 4096) == ops.KERNEL_TILED and q(2048, 11008, 4096) == ops.KERNEL_REGB
+    # groups of 32 rows, K not a multiple of 64: neither register-decoded kernel
+    assert q(32, 4096, 4096, 32) == ops.KERNEL_TILED and q(4096, 4096, 4096, 32) == ops.KERNEL_TILED
+    # shapes only the naive kernel takes (N % 32 != 0 at decode sizes), invalid shapes
+    assert q(1, 256, 40) == ops.KERNEL_NAIVE
+    assert q(0, 4096, 4096) == -1 and q(4, 4096, 4100) == -1
