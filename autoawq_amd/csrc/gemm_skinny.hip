@@ -8,7 +8,7 @@
 //     v_perm + v_and_or give K-pair fp16 registers, (t - (bias + z)) * s is the reference's fp16 weight exactly; the
 //     two waves that share a word column split its bytes (ph), each 64 logical columns wide.  Three 64-row steps of
 //     weight words are in flight per wave (inline asm, counted s_waitcnt);
-//   * the activations of the block's whole K slice are brought into LDS ONCE by LDS-DMA (<= 90 KB: 64 rows x 704
+//   * the activations of the block's whole K slice are brought into LDS ONCE by LDS-DMA (<= 128 KB: 64 rows x 1024
 //     columns), in 64-wide steps of 128 B rows with gemm_regb's XOR swizzle -- after that single barrier the K loop
 //     has no barrier at all: eight waves per block run free;
 //   * block = 256 columns x (K / S) rows on 8 waves: 4 column waves x 2 halves of the K slice, folded through LDS;
@@ -18,6 +18,8 @@
 // 9 <= M <= 64, K % 64 == 0, group_size % 64 == 0, N % 8 == 0.  (From 9 rows, where the decode kernel needs a second MFMA per
 // fragment and a 16-row exchange, this kernel is ahead on the 4096-row matrices -- 4096 x 11008, M = 16: 13.8 vs 15.6 us,
 // 4096 x 4096: 11.8 vs 12.9 -- and level or slightly behind on 11008 x 4096 / 4096 x 22016, which the dispatch leaves alone.)
+#include <cstdlib>
+
 #include "awq_device.h"
 #include "awq_internal.h"
 #include "awq_mfma_decode.h"
@@ -358,7 +360,7 @@ int awq_launch_gemm_skinny(const AwqGemmArgs& a, int splitk) {
     const size_t tile_bytes = (size_t)4 * MI * 4 * 1024;
     // K split (r02 sweep, profiles/r02_skinny_sweep.txt): wide matrices (>= 32 column tiles) want FOUR long slices (4096 x
     // 11008, M = 32: 14.1 us at S = 4, 18.8-20.7 at 6-8; the exchange grows with S M N), narrow ones a slice of ~512 rows
-    // (4096 x 4096: S = 8; 11008 x 4096: S = 16); the activation slice has to fit 96 KB of LDS (below)
+    // (4096 x 4096: S = 8; 11008 x 4096: S = 16); the activation slice has to fit 128 KB of LDS (below)
     int S = splitk > 0 ? splitk : (tiles >= 32 ? 4 : a.K / 512);
     if (splitk <= 0) {
         if (S < 4) S = 4;
@@ -367,7 +369,10 @@ int awq_launch_gemm_skinny(const AwqGemmArgs& a, int splitk) {
     if (S > T / 2) S = T / 2;
     if (S < 1) S = 1;
     int sps = (T + S - 1) / S;
-    const int sps_max = (96 * 1024) / (BM * 128);
+    // 128 KB of LDS for the activation slice (one block per CU at M > 32): with 96 KB a 64-row batch had to take six
+    // slices instead of four: 4096 x 11008, M = 64: 25.2 -> 17.9 us (AWQ_SKINNY_LDS_KB overrides, for sweeps)
+    static const int lds_kb = [] { const char* e = getenv("AWQ_SKINNY_LDS_KB"); const int v = e ? atoi(e) : 128; return v < 32 ? 32 : (v > 144 ? 144 : v); }();
+    const int sps_max = (lds_kb * 1024) / (BM * 128);
     if (sps > sps_max) sps = sps_max;  // more slices than asked for: the slice has to fit
     S = (T + sps - 1) / sps;
     if (S > 1 && S < R) {  // the reducers are the last R slices: fewer slices than that -> exactly R, or no split at all
