@@ -189,9 +189,24 @@ def test_no_wide_buffer_store_with_sgpr_soffset():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     csrc = os.path.join(ROOT, "autoawq_amd", "csrc")
-    rc, res = mod.main([os.path.join(csrc, "gemm_tiled.hip"), os.path.join(csrc, "gemv_mfma.hip")])
+    rc, res = mod.main([os.path.join(csrc, "gemm_tiled.hip"), os.path.join(csrc, "gemv_mfma.hip"), os.path.join(csrc, "gemm_skinny.hip")])
     assert rc == 0, res
-    assert sum(stores for _, stores, _ in res) > 100  # the audit really saw the exchange stores
+    assert sum(stores for _, stores, _ in res) > 200  # the audit really saw the exchange stores
+
+
+def test_hand_counted_asm_loads_are_hazard_safe():
+    """Regression guard for the two traps recorded in DESIGN.md 3.1f: in the ISA of the register-decoded kernels every
+    asm block with a buffer load opens with s_nop 4, an LDS-DMA block sets M0 itself, and nothing goes through scratch."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    csrc = os.path.join(ROOT, "autoawq_amd", "csrc")
+    for f, min_blocks in (("gemm_regb.hip", 10), ("gemm_skinny.hip", 10)):
+        name, blocks, bad = mod.audit_asm_loads(os.path.join(csrc, f))
+        assert not bad, (name, bad[:5])
+        assert blocks >= min_blocks, (name, blocks)
 
 
 def test_auto_dispatch_table_host_only():

@@ -34,6 +34,40 @@ def audit(src):
     return os.path.basename(src), stores, bad
 
 
+def audit_asm_loads(src):
+    """The hand-written loads of the register-decoded kernels (gemm_regb.hip, gemm_skinny.hip): every asm block that
+    holds a buffer load opens with s_nop 4 (SALU-written SGPR operands need five wait states before a VMEM instruction
+    reads them; hipcc pads nothing for asm operands), an LDS-DMA block writes M0 itself and waits before using it, and
+    the kernels touch no scratch memory (scratch traffic counts in vmcnt and would break the counted waits).
+    Returns (file, blocks seen, list of problems)."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                               "-fno-slp-vectorize", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"), "-S",
+                               "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+        lines = open(out).read().splitlines()
+    blocks, bad, cur = 0, [], None
+    for i, l in enumerate(lines):
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            cur = []
+        elif t.startswith(";;#ASMEND"):
+            body = [x for x in cur if x and not x.startswith(";")]
+            if any(x.startswith("buffer_load") for x in body):
+                blocks += 1
+                first_load = next(k for k, x in enumerate(body) if x.startswith("buffer_load"))
+                if not any(x.startswith("s_nop 4") for x in body[:first_load]):
+                    bad.append((i + 1, "buffer load without a leading s_nop 4: " + " | ".join(body[:3])))
+                if any(" lds" in x for x in body) and not body[0].startswith("s_mov_b32 m0"):
+                    bad.append((i + 1, "LDS-DMA block does not set M0 itself: " + " | ".join(body[:3])))
+            cur = None
+        elif cur is not None:
+            cur.append(t)
+        elif t.startswith("scratch_"):
+            bad.append((i + 1, "scratch access: " + t))
+    return os.path.basename(src), blocks, bad
+
+
 def main(files):
     files = files or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     with cf.ThreadPoolExecutor(max_workers=min(8, len(files))) as ex:
