@@ -71,6 +71,11 @@ bool awq_gemv_nk_supports(int M, int K, int N, int g);
 size_t awq_gemv_nk_lds_bytes(int M, int K, int ZW, int nwaves);
 int awq_launch_gemv_nk(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                        uint16_t* y, int M, int K, int N, int g, int ZW, int nwaves, int unroll, hipStream_t st);
+// GEMV layout, row-streaming VALU kernel (gemv_rows.hip), M <= 4: waves per block (<= 8), super-units in flight per wave
+// (1|2), blocks per CU, 1-KiB slots of a row per wave (1|2|3|4|6|8); 0 = auto each.
+bool awq_gemv_rows_supports(int M, int K, int N, int g);
+int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                         uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st);
 int awq_launch_dequant_nk(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out, int K,
                           int N, int g, int ZW, hipStream_t st);
 // Grouped (MoE) GEMM over stacked expert tensors (awq/modules/fused/moe.py:60-89), M = 16-row token blocks.

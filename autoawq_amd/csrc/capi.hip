@@ -350,6 +350,15 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     if (M == 0 || N == 0) return AWQ_OK;
     if (!x || !qweight || !scales || !qzeros || !y) return AWQ_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales)) return AWQ_ERR_BAD_ALIGNMENT;
+    const uint32_t kern = AWQ_GEMM_FLAG_KERNEL(flags);
+    if (kern != AWQ_GEMV_KERNEL_TILE16 && awq_gemv_rows_supports((int)M, (int)K, (int)N, (int)group_size)) {
+        g_last_kernel = "gemv_rows";
+        return awq_launch_gemv_rows(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,
+                                    (int)AWQ_GEMM_FLAG_WAVES(flags), (int)AWQ_GEMM_FLAG_UNIT(flags),
+                                    (int)AWQ_GEMM_FLAG_SPLITK(flags), (int)AWQ_GEMM_FLAG_NLOG(flags),
+                                    static_cast<hipStream_t>(stream));
+    }
+    if (kern == AWQ_GEMV_KERNEL_ROWS) return AWQ_ERR_UNSUPPORTED;
     if (!awq_gemv_nk_supports((int)M, (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
     g_last_kernel = "gemv_nk";
     return awq_launch_gemv_nk(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,

@@ -1,0 +1,535 @@
+// gemv_rows.hip -- decode GEMV (1 <= M <= 4) on the GEMV layout as a ROW-STREAMING kernel, gfx950.
+//
+// Replaces awq_ext.gemv_forward_cuda(x, qweight, scales, qzeros, group_size) as called by
+// awq/modules/linear/gemv.py:178-180 (the layout the reference itself recommends for batch 1,
+// README.md:96-97).  Layout (packer gemv.py:94-153):
+//   qweight [N, K/8] int32, nibble i of word c = w[n, 8c+i];  qzeros [N, ZW] int32, nibble i of word c =
+//   z[n, group 8c+i];  scales [N, 8*ZW] fp16.
+//
+// Roofline: HBM.  Algorithmic bytes per call: K*N/2 + (K/g)*N/2 + (K/g)*N*2 + M*K*2 + M*N*2.
+//
+// Design (no exchange, K-contiguous rows, weights requested first; measured floors in
+// profiles/r03_stream_probe3.txt: a wave instruction that reads 1 KiB of ONE row streams as fast as a bare linear
+// read, the 16-rows-x-64-bytes pattern a direct MFMA fragment load needs does not):
+//  * A UNIT is 1 KiB of one row = one `global_load_dwordx4 ... nt` of a wave (64 lanes x 16 bytes, eight whole
+//    128-byte lines).  A wave covers SL units (slots) of a row; at batch 1 that is the WHOLE row for K <= 16384
+//    (K = 4096: 2 slots, K = 11008: 6), so a lane's K ranges never change: its 32 SL activations live in 16 SL
+//    REGISTERS for the whole launch, already in the (t, t+4) pair order the nibble decode produces.  They reach the
+//    block once, by LDS-DMA (`global_load_lds_dwordx4`, no VGPRs), requested just ahead of the first weights; one
+//    barrier, and from there a wave shares nothing with anybody: no barrier at the end, no exchange, no workspace.
+//    (Larger batches or K: wk waves side by side on a row, and one barrier before y is written.)
+//  * Per unit a lane spends 5 VALU ops per packed word on the decode (nibbles stay in place under the fp16
+//    exponents 2^10 / 2^6, see gemv_mfma.hip) and 16 v_dot2c_f32_f16 (exact products, fp32 accumulation).
+//  * Four units form a ROUND.  Group scale and zero point come off once per round and lane: a 4 x 4 transpose-reduce
+//    inside each lane quad (a quad = the four chunks of one 128-wide group) leaves lane j of the quad with the group
+//    sum of unit j, so ONE 2-byte scale load and ONE zero-word load per lane serve four units:
+//        y[n] += s[n,g] * (P - C0 - z[n,g] * SX),   P = sum x*(bias + w),  C0 = sum bias*x,  SX = sum x  over the group,
+//    C0 / SX constants of the launch.  One-hot and zero inputs stay exact (tests).
+//  * A super-unit (SU) is RPU whole rows = SL * RPU units = R rounds with a compile-time (row, slot) pattern
+//    (SL 1: 4 rows, 2: 2 rows, 3: 4 rows / 3 rounds, 4: 1 row, 6: 2 rows / 3 rounds, 8: 1 row / 2 rounds).
+//  * Every load of the stream is inline asm with hand-counted `s_waitcnt vmcnt(N)` (vector-memory operations retire
+//    in order; hipcc falls back to vmcnt(0) at the loop head for a ring it cannot see through): D super-units
+//    stay in flight per wave, a round is re-requested right after it is consumed.
+//  * Cross-lane: two DPP rotations per round, then lanes 12-15 of each 16-lane row park four partial sums per unit in
+//    LDS; at the end a lane adds the 4 * SL (* wk) partials of a row and writes y.  Bitwise reproducible.
+//  * Static partition: SUs dealt evenly to (block, row group); the grid is a multiple of the CU count.
+#include "awq_device.h"
+#include "awq_internal.h"
+
+// Debug builds only (tools/rows_experiments.py): -DAWQ_ROWS_DBG=bits switches parts of the kernel off (results are wrong
+// by design): 1 = no decode / dot products, 2 = no activation DMA, barrier or LDS reads, 4 = no scale / zero arithmetic and
+// no transpose-reduce, 8 = no final fold (no y stores), 16 = no scale / zero loads, 32 = activations requested AFTER the
+// first weights (an ordering experiment: measured slower, every wave then preps x only after its whole ring has landed),
+// 64 = dot products by v_dot2c_f32_f16 on the VALU instead of v_mfma_f32_4x4x4_16b_f16.
+#ifndef AWQ_ROWS_DBG
+#define AWQ_ROWS_DBG 0
+#endif
+
+namespace {
+
+struct RowsParams {
+    const uint32_t* qweight;
+    const uint32_t* qzeros;
+    const half_t* scales;
+    const half_t* x;
+    half_t* y;
+    int M, K, N;
+    int KW, ZW, SW;             // words per qweight / qzeros row, halfs per scales row
+    int C, Cp;                  // 16-byte chunks per row (K / 32); the same rounded up to whole 64-chunk blocks
+    int wk, rg;                 // waves side by side on a row, row groups per block (blockDim = (64 * wk, rg))
+    int lines_base, lines_rem;  // 128-byte lines per (wave, slot): base (+1 for the first rem of the wk * SL slots)
+    int su_total;               // super-units of the matrix: ceil(N / RPU)
+    int su_base, su_rem;        // super-units per row group: base (+1 for the first rem groups)
+    int su_max;                 // most SUs any row group gets
+    uint32_t g_magic;           // (k * g_magic) >> 32 == k / g
+    unsigned long long* trace;  // debug builds only
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int CTRL>
+AWQ_DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+AWQ_DEV float dot2(uint32_t a, uint32_t b, float c) { return __builtin_amdgcn_fdot2(u2h2(a), u2h2(b), c, false); }
+AWQ_DEV float4_t mfma4(u32x2 a, u32x2 b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, a), __builtin_bit_cast(half4_t, b), c, 0, 0, 0);
+}
+
+// One round's request: four weight units (non-temporal), the lane's scale (2 bytes) and zero word.  The bases are fresh
+// SALU results: five wait states before a vector-memory instruction may read them (cdna_hip_programming.md 5.7).
+#if AWQ_ROWS_DBG & 16
+#define AWQ_ROWS_LPR 4
+#define AWQ_ROWS_REQUEST(R, vw0, vw1, vw2, vw3, b0, b1, b2, b3, vs, bs, vz, bz)                                              \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %6, %10 nt\n\tglobal_load_dwordx4 %1, %7, %11 nt\n\t"                     \
+                 "global_load_dwordx4 %2, %8, %12 nt\n\tglobal_load_dwordx4 %3, %9, %13 nt\n\tv_mov_b32 %4, 0x3c00\n\tv_mov_b32 %5, 0" \
+                 : "=&v"(R.q[0]), "=&v"(R.q[1]), "=&v"(R.q[2]), "=&v"(R.q[3]), "=&v"(R.sc), "=&v"(R.zw)                        \
+                 : "v"(vw0), "v"(vw1), "v"(vw2), "v"(vw3), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "v"(vs), "s"(bs), "v"(vz),      \
+                   "s"(bz)                                                                                                     \
+                 : "memory")
+#else
+#define AWQ_ROWS_LPR 6
+#define AWQ_ROWS_REQUEST(R, vw0, vw1, vw2, vw3, b0, b1, b2, b3, vs, bs, vz, bz)                                              \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %6, %10 nt\n\tglobal_load_dwordx4 %1, %7, %11 nt\n\t"                     \
+                 "global_load_dwordx4 %2, %8, %12 nt\n\tglobal_load_dwordx4 %3, %9, %13 nt\n\t"                                \
+                 "global_load_ushort %4, %14, %15\n\tglobal_load_dword %5, %16, %17"                                           \
+                 : "=&v"(R.q[0]), "=&v"(R.q[1]), "=&v"(R.q[2]), "=&v"(R.q[3]), "=&v"(R.sc), "=&v"(R.zw)                        \
+                 : "v"(vw0), "v"(vw1), "v"(vw2), "v"(vw3), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "v"(vs), "s"(bs), "v"(vz),      \
+                   "s"(bz)                                                                                                     \
+                 : "memory")
+#endif
+// The wait names every register of the round (they stay allocated until the data has landed) and prints them as a comment:
+// tools/isa_audit.py checks that they ARE the registers the request wrote (no compiler copy of a register whose load is
+// still in flight) and that nothing between request and wait touches them.
+#define AWQ_ROWS_WAIT(R, newer)                                                                       \
+    asm volatile("s_waitcnt vmcnt(%6) ; releases %0 %1 %2 %3 %4 %5"                                    \
+                 : "+v"(R.q[0]), "+v"(R.q[1]), "+v"(R.q[2]), "+v"(R.q[3]), "+v"(R.sc), "+v"(R.zw)      \
+                 : "n"(newer))
+
+// Phase stamps for tools/trace_gemv_rows.py (debug build only: -DAWQ_GEMV_TRACE); kept in registers, stored at the very end
+// (a store inside the stream would count in vmcnt)
+#ifdef AWQ_GEMV_TRACE
+#define ROWS_STAMP(slot) ts[slot] = wall_clock64()
+#else
+#define ROWS_STAMP(slot) do { } while (0)
+#endif
+
+struct Round {  // four units in flight + the lane's scale and zero word for the unit it finishes
+    u32x4 q[4];
+    uint32_t sc, zw;
+};
+
+constexpr int rows_per_su(int SL) { return SL == 1 || SL == 3 ? 4 : (SL == 2 || SL == 6 ? 2 : 1); }
+
+// Branch-free select by the lane's position in its quad (hipcc turns a ?: chain on a per-lane condition into exec-masked
+// branches): m0 / m1 / m2 are all-ones in the lanes with (lane & 3) == 0 / 1 / 2; (m & a) | (~m & b) is one v_bfi_b32.
+struct QuadSel {
+    uint32_t m0, m1, m2;
+    AWQ_DEV uint32_t bits(uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
+        const uint32_t cd = (m2 & c) | (~m2 & d), bcd = (m1 & b) | (~m1 & cd);
+        return (m0 & a) | (~m0 & bcd);
+    }
+    AWQ_DEV int operator()(int a, int b, int c, int d) const { return (int)bits((uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d); }
+    AWQ_DEV float operator()(float a, float b, float c, float d) const {
+        return __builtin_bit_cast(float, bits(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b),
+                                              __builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d)));
+    }
+};
+
+// SL: 1-KiB slots of a row per wave (1, 2, 3, 4, 6, 8); D: super-units in flight per wave (1 | 2); MM: batch rows
+template <int SL, int D, int MM>
+__global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
+    constexpr int RPU = rows_per_su(SL);  // rows per super-unit
+    constexpr int R = SL * RPU / 4;       // rounds per super-unit; unit u of an SU = (row u / SL, slot u % SL)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS: xs[MM][4 pieces][Cp] x 16 bytes (piece j of chunk c at (j * Cp + c) * 16) | red[MM][rows of the block][wk * SL][4]
+    const int lane = threadIdx.x & 63;
+    const int wki = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rgi = __builtin_amdgcn_readfirstlane(threadIdx.y);
+#ifdef AWQ_GEMV_TRACE
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ROWS_STAMP(0);
+    const int gi = blockIdx.x * p.rg + rgi;
+    const int t0 = gi * p.su_base + min(gi, p.su_rem);  // first SU of this wave's row group
+    const int nt = p.su_base + (gi < p.su_rem ? 1 : 0);
+    const int last_row = p.N - 1;
+
+    // ---- this lane's chunk of a row, per slot
+    int woff[SL], grp[SL], cidx[SL];
+    bool act[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int ws = s * p.wk + wki;
+        const int l0 = ws * p.lines_base + min(ws, p.lines_rem);
+        const int nl = p.lines_base + (ws < p.lines_rem ? 1 : 0);
+        const int c = 8 * l0 + lane;
+        act[s] = lane < 8 * nl && c < p.C;
+        cidx[s] = act[s] ? c : 0;
+        woff[s] = nl > 0 ? 16 * cidx[s] : 0;  // bytes; a slot without lines (padding) reads one 16-byte piece per request
+        grp[s] = (int)__umulhi((uint32_t)(32 * cidx[s]), p.g_magic);
+    }
+    // lane j of a quad finishes unit 4 r + j of every SU in round r: that unit's row within the SU, slot and group
+    const int uj = lane & 3;
+    const QuadSel sel4{uj == 0 ? ~0u : 0u, uj == 1 ? ~0u : 0u, uj == 2 ? ~0u : 0u};
+    int myslot[R], myrow[R], mygrp[R];
+    uint32_t zsh[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        myslot[r] = sel4((4 * r + 0) % SL, (4 * r + 1) % SL, (4 * r + 2) % SL, (4 * r + 3) % SL);
+        myrow[r] = sel4((4 * r + 0) / SL, (4 * r + 1) / SL, (4 * r + 2) / SL, (4 * r + 3) / SL);
+        mygrp[r] = sel4(grp[(4 * r + 0) % SL], grp[(4 * r + 1) % SL], grp[(4 * r + 2) % SL], grp[(4 * r + 3) % SL]);
+        zsh[r] = 4u * (uint32_t)(mygrp[r] & 7);
+    }
+
+    // ---- the ring: D super-units of R rounds each
+    Round ring[D][R];
+    auto request = [&](Round& Rd, int t, int r) {  // round r of SU t of this row group
+        const bool live = t < nt;  // past the last SU the request is kept (the counted waits need it) but reads 16 bytes
+        const int row0 = min((t0 + t) * RPU, last_row);
+        const int ra = min(row0 + (4 * r + 0) / SL, last_row), rb = min(row0 + (4 * r + 1) / SL, last_row);
+        const int rc = min(row0 + (4 * r + 2) / SL, last_row), rd = min(row0 + (4 * r + 3) / SL, last_row);
+        const uint32_t* ba = p.qweight + (int64_t)ra * p.KW;
+        const uint32_t* bb = p.qweight + (int64_t)rb * p.KW;
+        const uint32_t* bc = p.qweight + (int64_t)rc * p.KW;
+        const uint32_t* bd = p.qweight + (int64_t)rd * p.KW;
+        const int wa = live ? woff[(4 * r + 0) % SL] : 0, wb = live ? woff[(4 * r + 1) % SL] : 0;
+        const int wc = live ? woff[(4 * r + 2) % SL] : 0, wd = live ? woff[(4 * r + 3) % SL] : 0;
+        const int myr = min(row0 + myrow[r], last_row) - row0;
+        const uint32_t vs = (uint32_t)((myr * p.SW + mygrp[r]) * 2), vz = (uint32_t)((myr * p.ZW + (mygrp[r] >> 3)) * 4);
+        const half_t* bs = p.scales + (int64_t)row0 * p.SW;
+        const uint32_t* bz = p.qzeros + (int64_t)row0 * p.ZW;
+        AWQ_ROWS_REQUEST(Rd, wa, wb, wc, wd, ba, bb, bc, bd, vs, bs, vz, bz);
+    };
+    // this wave's share of the block's LDS-DMA copy of the activations (piece j of 64 chunks per instruction)
+    auto copy_x = [&]() {
+        const uint32_t xlds = (uint32_t)(uintptr_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic segment
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int cb = s * p.wk + wki;
+            const int c = min(cb * 64 + lane, p.C - 1);
+            for (int jm = rgi; jm < 4 * MM; jm += p.rg) {
+                const int j = jm & 3, m = jm >> 2;
+                const half_t* src = p.x + (int64_t)m * p.K + 32 * c + 8 * j;
+                const uint32_t dst = xlds + (uint32_t)(((m * 4 + j) * p.Cp + cb * 64) * 16);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+            }
+        }
+    };
+    if constexpr (!(AWQ_ROWS_DBG & 2) && !(AWQ_ROWS_DBG & 32)) copy_x();  // activations first: they must be ready when the first weights land
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int r = 0; r < R; ++r) request(ring[d][r], d, r);
+    ROWS_STAMP(1);
+    if constexpr (!(AWQ_ROWS_DBG & 2) && (AWQ_ROWS_DBG & 32)) copy_x();  // experiment: weights requested first
+
+    // ---- activations: the LDS-DMA pieces have landed (they are older than the ring), barrier
+    if constexpr (!(AWQ_ROWS_DBG & 2)) {
+        if constexpr (AWQ_ROWS_DBG & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AWQ_ROWS_LPR * R * D) : "memory");  // everything older than the ring
+        __builtin_amdgcn_s_barrier();
+    }
+    ROWS_STAMP(2);
+
+    // ---- activations LDS -> registers: (t, t+4) pairs; group constants C0 = sum bias * x, SX = sum x
+    const int NC = p.wk * SL;
+    const int rows_blk = p.su_max * p.rg * RPU;
+    float* red = reinterpret_cast<float*>(smem + (size_t)MM * 4 * p.Cp * 16);
+    uint32_t xp[MM][SL][16];
+    float c0g[MM][R], sxg[MM][R];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        float c0s[SL], sxs[SL];
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            float se = 0.f, so = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 d = {0x3C003C00u + lane, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+                if constexpr (!(AWQ_ROWS_DBG & 2)) d = *reinterpret_cast<const u32x4*>(smem + (size_t)(((m * 4 + j) * p.Cp + cidx[s]) * 16));
+                if (!act[s]) d = u32x4{0u, 0u, 0u, 0u};
+                xp[m][s][4 * j + 0] = __builtin_amdgcn_perm(d[2], d[0], 0x05040100u);  // (x0, x4)  bias 1024
+                xp[m][s][4 * j + 1] = __builtin_amdgcn_perm(d[2], d[0], 0x07060302u);  // (x1, x5)  bias 64
+                xp[m][s][4 * j + 2] = __builtin_amdgcn_perm(d[3], d[1], 0x05040100u);  // (x2, x6)  bias 1024
+                xp[m][s][4 * j + 3] = __builtin_amdgcn_perm(d[3], d[1], 0x07060302u);  // (x3, x7)  bias 64
+                se = dot2(xp[m][s][4 * j + 0], 0x3C003C00u, se);
+                so = dot2(xp[m][s][4 * j + 1], 0x3C003C00u, so);
+                se = dot2(xp[m][s][4 * j + 2], 0x3C003C00u, se);
+                so = dot2(xp[m][s][4 * j + 3], 0x3C003C00u, so);
+            }
+            float c0 = 1024.f * se + 64.f * so, sx = se + so;
+            c0 += dpp_mov<0xB1>(c0);  // quad_perm [1,0,3,2]
+            sx += dpp_mov<0xB1>(sx);
+            c0 += dpp_mov<0x4E>(c0);  // quad_perm [2,3,0,1]
+            sx += dpp_mov<0x4E>(sx);
+            c0s[s] = c0;
+            sxs[s] = sx;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            c0g[m][r] = sel4(c0s[(4 * r + 0) % SL], c0s[(4 * r + 1) % SL], c0s[(4 * r + 2) % SL], c0s[(4 * r + 3) % SL]);
+            sxg[m][r] = sel4(sxs[(4 * r + 0) % SL], sxs[(4 * r + 1) % SL], sxs[(4 * r + 2) % SL], sxs[(4 * r + 3) % SL]);
+        }
+    }
+    const bool odd = lane & 1, hi = lane & 2, writer = (lane & 12) == 12;
+    // LDS index of this lane's unit in round r of SU 0 of its row group (advances by RPU rows per SU)
+    int red_lane[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) red_lane[r] = (((rgi * p.su_max) * RPU + myrow[r]) * NC + wki * SL + myslot[r]) * 4 + (lane >> 4);
+    const int red_step = RPU * NC * 4;
+    ROWS_STAMP(3);
+
+    // ---- stream the super-units
+    for (int tbase = 0; tbase < nt; tbase += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = tbase + d;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                Round& Rd = ring[d][r];
+                AWQ_ROWS_WAIT(Rd, AWQ_ROWS_LPR * (R * D - 1));  // in flight behind it: every other round of the ring
+#ifdef AWQ_GEMV_TRACE
+                if (t == 0 && r == 0) ROWS_STAMP(4);
+#endif
+                float pu[MM][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = (4 * r + u) % SL;
+                    float pa[MM], pb[MM];
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) pa[m] = pb[m] = 0.f;
+                    if constexpr (AWQ_ROWS_DBG & 1) {
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) pa[m] = __builtin_bit_cast(float, Rd.q[u][0] ^ Rd.q[u][1] ^ Rd.q[u][2] ^ Rd.q[u][3]);
+                    } else if constexpr (!(AWQ_ROWS_DBG & 64)) {
+                        // v_mfma_f32_4x4x4_16b_f16: 16 independent 4 x 4 x 4 products, one per lane quad.  A row i = lane i of the
+                        // quad (4 weights), B column j = lane j (4 activations): D[i][j] = w(lane i) . x(lane j), register i of
+                        // lane j.  The lane's own dot product is the diagonal element, register (lane & 3); the other twelve
+                        // products of the quad are discarded.  Eight MFMAs per unit replace sixteen VALU dot products.
+                        float4_t acc[MM];
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) acc[m] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t w = Rd.q[u][j], w8 = w >> 8;
+                            const u32x2 a0 = {and_or(w, 0x000F000Fu, 0x64006400u), and_or(w, 0x00F000F0u, 0x54005400u)};
+                            const u32x2 a1 = {and_or(w8, 0x000F000Fu, 0x64006400u), and_or(w8, 0x00F000F0u, 0x54005400u)};
+#pragma unroll
+                            for (int m = 0; m < MM; ++m) {
+                                acc[m] = mfma4(a0, u32x2{xp[m][s][4 * j + 0], xp[m][s][4 * j + 1]}, acc[m]);
+                                acc[m] = mfma4(a1, u32x2{xp[m][s][4 * j + 2], xp[m][s][4 * j + 3]}, acc[m]);
+                            }
+                        }
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) pa[m] = sel4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t w = Rd.q[u][j], w8 = w >> 8;
+                            const uint32_t b0 = and_or(w, 0x000F000Fu, 0x64006400u), b1 = and_or(w, 0x00F000F0u, 0x54005400u);
+                            const uint32_t b2 = and_or(w8, 0x000F000Fu, 0x64006400u), b3 = and_or(w8, 0x00F000F0u, 0x54005400u);
+#pragma unroll
+                            for (int m = 0; m < MM; ++m) {
+                                pa[m] = dot2(xp[m][s][4 * j + 0], b0, pa[m]);
+                                pb[m] = dot2(xp[m][s][4 * j + 1], b1, pb[m]);
+                                pa[m] = dot2(xp[m][s][4 * j + 2], b2, pa[m]);
+                                pb[m] = dot2(xp[m][s][4 * j + 3], b3, pb[m]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) pu[m][u] = pa[m] + pb[m];
+                }
+                float scl = (float)__builtin_bit_cast(half_t, (uint16_t)Rd.sc);
+                float zf = (float)((Rd.zw >> zsh[r]) & 15u);
+                // every value derived from the round exists before the round is requested again: the old contents are dead
+                // at the request, so the round keeps its registers (no copy of a register with a load in flight)
+#pragma unroll
+                for (int m = 0; m < MM; ++m) asm volatile("" ::"v"(pu[m][0]), "v"(pu[m][1]), "v"(pu[m][2]), "v"(pu[m][3]));
+                asm volatile("" : "+v"(scl), "+v"(zf));  // opaque: hipcc may not fold the fp16 -> fp32 conversion into a later use
+                request(Rd, t + D, r);
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    float v;
+                    if constexpr (AWQ_ROWS_DBG & 4) {
+                        v = (pu[m][0] + pu[m][1]) + (pu[m][2] + pu[m][3]) + scl + zf;
+                    } else {
+                        // 4 x 4 transpose-reduce inside the quad: lane j ends with the quad (= group) sum of unit j
+                        const float s01 = odd ? pu[m][0] : pu[m][1], k01 = odd ? pu[m][1] : pu[m][0];
+                        const float s23 = odd ? pu[m][2] : pu[m][3], k23 = odd ? pu[m][3] : pu[m][2];
+                        const float r01 = k01 + dpp_mov<0xB1>(s01), r23 = k23 + dpp_mov<0xB1>(s23);
+                        const float snd = hi ? r01 : r23, kp = hi ? r23 : r01;
+                        const float rq = kp + dpp_mov<0x4E>(snd);
+                        v = scl * __builtin_fmaf(-zf, sxg[m][r], rq - c0g[m][r]);
+                        v += dpp_mov<0x124>(v);  // row_ror:4
+                        v += dpp_mov<0x128>(v);  // row_ror:8  -> sum over the four quads of this 16-lane row
+                    }
+                    if (writer && t < nt) red[(m * rows_blk * NC) * 4 + red_lane[r] + t * red_step] = v;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the short repeats past the last SU
+    ROWS_STAMP(5);
+    if constexpr (!(AWQ_ROWS_DBG & 8)) {
+        // ---- add the 4 * wk * SL partials of every row, write y.  wk == 1: a wave folds the rows it produced itself
+        // (its own LDS writes, in order: no barrier); otherwise the block folds all of its rows behind one barrier.
+        if (p.wk == 1) {
+            ROWS_STAMP(6);
+            const int nrows = min((t0 + nt) * RPU, p.N) - t0 * RPU;
+            for (int e = lane; e < nrows * MM; e += 64) {
+                const int m = MM == 1 ? 0 : e / nrows, j = MM == 1 ? e : e - m * nrows;
+                const float4_t* rp = reinterpret_cast<const float4_t*>(red + ((size_t)(m * rows_blk + rgi * p.su_max * RPU + j) * NC) * 4);
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < SL; ++w) {
+                    const float4_t v = rp[w];
+                    sum += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                p.y[(int64_t)m * p.N + t0 * RPU + j] = (half_t)sum;
+            }
+        } else {
+            __syncthreads();
+            ROWS_STAMP(6);
+            const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
+            for (int rgj = 0; rgj < p.rg; ++rgj) {
+                const int gj = blockIdx.x * p.rg + rgj;
+                const int tj0 = gj * p.su_base + min(gj, p.su_rem), ntj = p.su_base + (gj < p.su_rem ? 1 : 0);
+                const int nr = min((tj0 + ntj) * RPU, p.N) - tj0 * RPU;
+                for (int e = tid; e < nr * MM; e += nthr) {
+                    const int m = MM == 1 ? 0 : e / nr, j = MM == 1 ? e : e - m * nr;
+                    const float4_t* rp = reinterpret_cast<const float4_t*>(red + ((size_t)(m * rows_blk + rgj * p.su_max * RPU + j) * NC) * 4);
+                    float sum = 0.f;
+                    for (int w = 0; w < NC; ++w) {
+                        const float4_t v = rp[w];
+                        sum += (v[0] + v[1]) + (v[2] + v[3]);
+                    }
+                    p.y[(int64_t)m * p.N + tj0 * RPU + j] = (half_t)sum;
+                }
+            }
+        }
+    }
+#ifdef AWQ_GEMV_TRACE
+    ROWS_STAMP(7);
+    if (p.trace && lane == 0) {
+        unsigned long long* o = p.trace + ((size_t)blockIdx.x * 8 + (threadIdx.y * (blockDim.x >> 6) + wki)) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = ts[i];
+    }
+#endif
+}
+
+template <int SL, int D, int MM>
+int launch_rows(const RowsParams& p, int blocks, size_t lds, hipStream_t st) {
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemv_rows_kernel<SL, D, MM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((awq_gemv_rows_kernel<SL, D, MM>), dim3((unsigned)blocks), dim3(64 * p.wk, p.rg), lds, st, p);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+// Slots per wave for a row of `slots` 1-KiB units at batch M: the smallest legal SL (1, 2, 3, 4, 6, 8) that covers the whole
+// row if the activations fit the register budget (16 SL M registers: SL <= 8 at M = 1, 3 at 2, 2 at 3, 1 at 4), else the
+// largest that fits (wk waves then share a row).
+int pick_sl(int slots, int M, int forced) {
+    static const int legal[] = {1, 2, 3, 4, 6, 8};
+    if (forced > 0) {
+        for (int s : legal)
+            if (s == forced) return s;
+        return 0;
+    }
+    const int cap = M == 1 ? 8 : (6 / M < 1 ? 1 : 6 / M);
+    int best = 1;
+    for (int s : legal) {
+        if (s > cap) break;
+        best = s;
+        if (s >= slots) break;
+    }
+    return best;
+}
+
+}  // namespace
+
+bool awq_gemv_rows_supports(int M, int K, int N, int g) {
+    if (M < 1 || M > 4 || N < 1 || K < 128) return false;
+    if (g < 128 || g % 128 || K % g) return false;  // a lane quad (4 x 32 weights) never straddles a group
+    const int slots = (K / 32 + 63) / 64;
+    const int SL = pick_sl(slots, M, 0);
+    return (slots + SL - 1) / SL <= 8;  // wk waves side by side, at most 8
+}
+
+#ifdef AWQ_GEMV_TRACE
+static unsigned long long* g_rows_trace = nullptr;
+extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_rows(void* dev_buf) {
+    g_rows_trace = static_cast<unsigned long long*>(dev_buf);
+}
+#endif
+
+// waves: waves per block wanted (0 = auto, <= 8); depth: super-units in flight per wave (1 | 2, 0 = auto);
+// bpc: blocks per CU (0 = auto); sl: slots per wave (0 = auto).
+int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                         uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st) {
+    if (!awq_gemv_rows_supports(M, K, N, g)) return AWQ_ERR_UNSUPPORTED;
+    RowsParams p;
+    p.qweight = reinterpret_cast<const uint32_t*>(qweight);
+    p.qzeros = reinterpret_cast<const uint32_t*>(qzeros);
+    p.scales = reinterpret_cast<const half_t*>(scales);
+    p.x = reinterpret_cast<const half_t*>(x);
+    p.y = reinterpret_cast<half_t*>(y);
+    p.M = M; p.K = K; p.N = N;
+    p.KW = K / 8; p.ZW = ZW; p.SW = 8 * ZW;
+    p.C = K / 32;
+    const int slots = (p.C + 63) / 64;
+    const int SL = pick_sl(slots, M, sl);
+    if (SL == 0 || 16 * SL * M > 128) return AWQ_ERR_UNSUPPORTED;
+    p.wk = (slots + SL - 1) / SL;
+    if (p.wk > 8) return AWQ_ERR_UNSUPPORTED;
+    p.Cp = p.wk * SL * 64;
+    if (waves <= 0 || waves > 8) waves = 8;
+    p.rg = 1;
+    while (p.rg * 2 * p.wk <= waves) p.rg *= 2;
+    const int lines = (p.C + 7) / 8, tslots = p.wk * SL;
+    p.lines_base = lines / tslots;
+    p.lines_rem = lines % tslots;
+    if (!awq_magic_u32((uint32_t)g, (uint32_t)K + 32u, &p.g_magic)) return AWQ_ERR_UNSUPPORTED;
+    const int RPU = rows_per_su(SL);
+    p.su_total = (N + RPU - 1) / RPU;
+    if (bpc <= 0) {  // 1 .. 3 blocks per CU: the smallest maximum number of SUs per row group, then the fewest blocks
+        double best = 1e30;
+        for (int b = 1; b <= 3; ++b) {
+            const int groups = 256 * b * p.rg;
+            const int mx = (p.su_total + groups - 1) / groups;
+            const double cost = (double)mx * groups / p.su_total + 0.02 * b;  // imbalance, mild preference for fewer blocks
+            if (cost < best) { best = cost; bpc = b; }
+        }
+    }
+    int blocks = 256 * bpc;
+    const int max_blocks = (p.su_total + p.rg - 1) / p.rg;  // at least one SU per row group
+    if (blocks > max_blocks) blocks = max_blocks;
+    const int groups = blocks * p.rg;
+    p.su_base = p.su_total / groups;
+    p.su_rem = p.su_total % groups;
+    p.su_max = p.su_base + (p.su_rem ? 1 : 0);
+    const bool one_round = SL * RPU == 4;
+    if (depth < 1 || depth > 2) depth = p.su_max >= 2 && one_round ? 2 : 1;
+    if (!one_round || (SL == 4 && M > 1) || (SL == 2 && M > 3)) depth = 1;  // instantiated combinations (register budget)
+    p.trace = nullptr;
+#ifdef AWQ_GEMV_TRACE
+    p.trace = g_rows_trace;
+#endif
+    const size_t lds = (size_t)M * 4 * p.Cp * 16 + (size_t)M * p.su_max * p.rg * RPU * p.wk * SL * 4 * sizeof(float);
+    if (lds > 160 * 1024) return AWQ_ERR_UNSUPPORTED;
+#define AWQ_ROWS_CASE(SLV, DV, MV) \
+    if (SL == SLV && depth == DV && M == MV) return launch_rows<SLV, DV, MV>(p, blocks, lds, st);
+    AWQ_ROWS_CASE(1, 1, 1) AWQ_ROWS_CASE(1, 1, 2) AWQ_ROWS_CASE(1, 1, 3) AWQ_ROWS_CASE(1, 1, 4)
+    AWQ_ROWS_CASE(1, 2, 1) AWQ_ROWS_CASE(1, 2, 2) AWQ_ROWS_CASE(1, 2, 3) AWQ_ROWS_CASE(1, 2, 4)
+    AWQ_ROWS_CASE(2, 1, 1) AWQ_ROWS_CASE(2, 1, 2) AWQ_ROWS_CASE(2, 1, 3) AWQ_ROWS_CASE(2, 1, 4)
+    AWQ_ROWS_CASE(2, 2, 1) AWQ_ROWS_CASE(2, 2, 2) AWQ_ROWS_CASE(2, 2, 3)
+    AWQ_ROWS_CASE(3, 1, 1) AWQ_ROWS_CASE(3, 1, 2)
+    AWQ_ROWS_CASE(4, 1, 1) AWQ_ROWS_CASE(4, 1, 2) AWQ_ROWS_CASE(4, 2, 1)
+    AWQ_ROWS_CASE(6, 1, 1)
+    AWQ_ROWS_CASE(8, 1, 1)
+#undef AWQ_ROWS_CASE
+    return AWQ_ERR_UNSUPPORTED;
+}

@@ -158,7 +158,14 @@ AWQ_EXPORT int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweigh
  * awq_ext.gemmv2_forward_cuda(..., group_size, split_k_iters) (awq/modules/linear/gemv.py:168-180).
  * y [M, N] fp16 = x [M, K] fp16 @ dequant(qweight)^T, fp32 accumulation, 1 <= M <= 16 per call and
  * awq_gemv_lds_bytes(M, K, ZW) <= 160 KiB (the host wrapper chunks larger M); no bias (the
- * reference adds it afterwards, gemv.py:185).  flags: AWQ_GEMM_FLAG_WAVES / _UNIT (unroll) tuning. */
+ * reference adds it afterwards, gemv.py:185).  AUTO: M <= 4 takes the row-streaming kernel (gemv_rows.hip: a wave
+ * instruction reads 1 KiB of one row, activations in registers, no LDS staging, no cross-CU exchange), 5 <= M <= 16 the
+ * 16-row MFMA tile kernel (gemv_nk.hip).  flags: AWQ_GEMM_FLAG_KERNEL = AWQ_GEMV_KERNEL_*; tuning: _WAVES (waves per
+ * block), _UNIT (TILE16: unroll; ROWS: super-units in flight per wave, 1 | 2), _SPLITK (ROWS: blocks per CU), _NLOG (ROWS:
+ * 1-KiB slots of a row per wave, 1 | 2 | 3 | 4 | 6 | 8). */
+#define AWQ_GEMV_KERNEL_AUTO 0u
+#define AWQ_GEMV_KERNEL_TILE16 1u /* 16 rows per block through v_mfma_f32_16x16x32_f16, M <= 16 */
+#define AWQ_GEMV_KERNEL_ROWS 2u   /* row-streaming VALU (v_dot2_f32_f16) kernel, M <= 4 */
 AWQ_EXPORT int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
                                 const int32_t* qzeros, uint16_t* y, int64_t M, int64_t K, int64_t N,
                                 int64_t group_size, int64_t zeros_width, uint32_t flags, void* stream);

@@ -68,6 +68,92 @@ def audit_asm_loads(src):
     return os.path.basename(src), blocks, bad
 
 
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def audit_inflight_regs(src):
+    """The row-streaming GEMV kernel (gemv_rows.hip) requests a ring slot in one asm block (global loads with VGPR
+    destinations) and releases it in a later asm block `s_waitcnt vmcnt(N) ; releases <regs>`.  hipcc believes the
+    destinations are written when the request block ends, so it MAY copy or reuse them while the loads are in flight
+    (cdna_hip_programming.md 5.7, item 1).  This walks every path from each request block to the first wait block that
+    names one of its registers (or the vmcnt(0) drain) and fails if (a) that wait does not name exactly the request's
+    registers (a compiler copy happened in between) or (b) any instruction on the way touches one of them.
+    Returns (file, request blocks checked, list of problems)."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm",
+                               "-fno-slp-vectorize", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"), "-S",
+                               "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+        lines = [l.strip() for l in open(out).read().splitlines()]
+    labels = {l[:-1].split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^[.\w$]+:", l)}
+    # asm blocks: (start, end, kind, regs)
+    blocks, i = {}, 0
+    while i < len(lines):
+        if lines[i].startswith(";;#ASMSTART"):
+            j = i + 1
+            while not lines[j].startswith(";;#ASMEND"):
+                j += 1
+            body = lines[i + 1:j]
+            loads = [x for x in body if x.startswith("global_load") and " lds" not in x and "_lds_" not in x]
+            waits = [x for x in body if x.startswith("s_waitcnt vmcnt")]
+            if loads:
+                dst = set()
+                for x in loads:
+                    dst |= regs_of(x.split(",")[0])
+                blocks[i] = (j, "request", dst)
+            elif waits:
+                named = regs_of(waits[0].split(";", 1)[1]) if ";" in waits[0] else set()
+                blocks[i] = (j, "drain" if "vmcnt(0)" in waits[0] and not named else "wait", named)
+            i = j
+        i += 1
+    checked, bad = 0, []
+    for start, (end, kind, dst) in blocks.items():
+        if kind != "request":
+            continue
+        checked += 1
+        seen, todo = set(), [end + 1]
+        while todo:
+            k = todo.pop()
+            while k < len(lines) and k not in seen:
+                seen.add(k)
+                t = lines[k]
+                if k in blocks:
+                    e2, kind2, regs2 = blocks[k]
+                    if kind2 == "drain":
+                        break
+                    if kind2 == "wait" and regs2 & dst:
+                        if regs2 != dst:
+                            bad.append((k + 1, f"wait names {sorted(regs2)} but the request at line {start + 1} wrote {sorted(dst)}"))
+                        break
+                    if kind2 == "request" and regs2 & dst:
+                        bad.append((k + 1, f"slot requested again before it was released (request at line {start + 1})"))
+                        break
+                    k = e2 + 1
+                    continue
+                if t.startswith("s_endpgm"):
+                    bad.append((k + 1, f"request at line {start + 1} never released"))
+                    break
+                if t and not t.startswith((";", ".")) and not re.match(r"^[.\w$]+:", t) and regs_of(t) & dst:
+                    bad.append((k + 1, f"touches in-flight registers of the request at line {start + 1}: {t}"))
+                m = re.match(r"s_(c?branch)\w*\s+(\S+)", t)
+                if m and m.group(2) in labels:
+                    todo.append(labels[m.group(2)])
+                    if m.group(1) == "branch":
+                        break
+                k += 1
+    return os.path.basename(src), checked, bad
+
+
 def main(files):
     files = files or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     with cf.ThreadPoolExecutor(max_workers=min(8, len(files))) as ex:
