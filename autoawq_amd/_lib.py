@@ -25,14 +25,6 @@ class AwqGemmEx(ctypes.Structure):
                 ("ssq_in", c_void_p), ("ssq_in_tiles", c_int64), ("add_residual", c_void_p), ("ssq_out", c_void_p)]
 
 
-class AwqChainLink(ctypes.Structure):
-    """struct AwqChainLink of include/awq_hip.h (same field order)."""
-    _fields_ = [("qweight", c_void_p), ("scales", c_void_p), ("qzeros", c_void_p), ("bias", c_void_p),
-                ("K", c_int64), ("N", c_int64), ("group_size", c_int64), ("x", c_void_p), ("x_stride", c_int64),
-                ("x_from", c_int64), ("x_col0", c_int64), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
-                ("y", c_void_p), ("add_residual", c_void_p)]
-
-
 # name -> (restype, argtypes); must list every symbol include/awq_hip.h declares
 # (tests/test_boundary.py cross-checks this table against the header and the .so).
 SIGNATURES = {
@@ -71,13 +63,6 @@ SIGNATURES = {
                                                  c_void_p]),
     "awq_gemm_workspace_status": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "awq_gemm_auto_kernel": (c_int, [c_int64, c_int64, c_int64, c_int64]),
-    "awq_chain_plan_bytes": (c_size_t, [c_int64]),
-    "awq_chain_grid_blocks": (c_int, []),
-    "awq_chain_build": (c_int, [ctypes.POINTER(AwqChainLink), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
-                                ctypes.POINTER(c_size_t)]),
-    "awq_chain_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
-    "awq_chain_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "awq_chain_status": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
 }
 
 

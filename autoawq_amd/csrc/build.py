@@ -58,11 +58,18 @@ def build(force=False, verbose=False, save_temps=False):
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: compile_one(s, force, verbose, save_temps), srcs))
     objs = [o for o, _ in res]
-    if any(c for _, c in res) or not os.path.exists(OUT) or force:
+    manifest = os.path.join(OBJ, "linked.txt")  # relink when a source was added or removed, not only when one changed
+    linked = open(manifest).read().split() if os.path.exists(manifest) else []
+    for stale in set(os.listdir(OBJ)) - {os.path.basename(o) for o in objs} - {"linked.txt"}:
+        if stale.endswith(".o"):
+            os.remove(os.path.join(OBJ, stale))
+    if any(c for _, c in res) or not os.path.exists(OUT) or force or linked != [os.path.basename(o) for o in objs]:
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(manifest, "w") as f:
+            f.write("\n".join(os.path.basename(o) for o in objs))
     return OUT
 
 

@@ -351,7 +351,11 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     if (!x || !qweight || !scales || !qzeros || !y) return AWQ_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales)) return AWQ_ERR_BAD_ALIGNMENT;
     const uint32_t kern = AWQ_GEMM_FLAG_KERNEL(flags);
-    if (kern != AWQ_GEMV_KERNEL_TILE16 && awq_gemv_rows_supports((int)M, (int)K, (int)N, (int)group_size)) {
+    // AUTO: the row-streaming kernel at batch 1, and at batch 2 while a wave still covers whole rows (K <= 6144); the
+    // 16-row MFMA tile kernel otherwise (profiles/r03_gemv_rows_sweep.txt)
+    const bool rows_auto = M == 1 || (M == 2 && K <= 6144);
+    if (kern != AWQ_GEMV_KERNEL_TILE16 && (kern == AWQ_GEMV_KERNEL_ROWS || rows_auto) &&
+        awq_gemv_rows_supports((int)M, (int)K, (int)N, (int)group_size)) {
         g_last_kernel = "gemv_rows";
         return awq_launch_gemv_rows(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,
                                     (int)AWQ_GEMM_FLAG_WAVES(flags), (int)AWQ_GEMM_FLAG_UNIT(flags),

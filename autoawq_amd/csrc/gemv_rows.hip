@@ -22,7 +22,9 @@
 //    exponents 2^10 / 2^6, see gemv_mfma.hip) and 16 v_dot2c_f32_f16 (exact products, fp32 accumulation).
 //  * Four units form a ROUND.  Group scale and zero point come off once per round and lane: a 4 x 4 transpose-reduce
 //    inside each lane quad (a quad = the four chunks of one 128-wide group) leaves lane j of the quad with the group
-//    sum of unit j, so ONE 2-byte scale load and ONE zero-word load per lane serve four units:
+//    sum of unit j, so ONE scale and ONE zero word per lane serve four units (read from LDS: the scales / zeros of all
+//    the rows a wave will touch are contiguous in this layout and arrive by two or three LDS-DMA instructions in the
+//    prologue, so the stream itself carries packed weights only):
 //        y[n] += s[n,g] * (P - C0 - z[n,g] * SX),   P = sum x*(bias + w),  C0 = sum bias*x,  SX = sum x  over the group,
 //    C0 / SX constants of the launch.  One-hot and zero inputs stay exact (tests).
 //  * A super-unit (SU) is RPU whole rows = SL * RPU units = R rounds with a compile-time (row, slot) pattern
@@ -38,7 +40,7 @@
 
 // Debug builds only (tools/rows_experiments.py): -DAWQ_ROWS_DBG=bits switches parts of the kernel off (results are wrong
 // by design): 1 = no decode / dot products, 2 = no activation DMA, barrier or LDS reads, 4 = no scale / zero arithmetic and
-// no transpose-reduce, 8 = no final fold (no y stores), 16 = no scale / zero loads, 32 = activations requested AFTER the
+// no transpose-reduce, 8 = no final fold (no y stores), 16 = no scale / zero DMA or LDS reads, 32 = activations requested AFTER the
 // first weights (an ordering experiment: measured slower, every wave then preps x only after its whole ring has landed),
 // 64 = dot products by v_dot2c_f32_f16 on the VALU instead of v_mfma_f32_4x4x4_16b_f16.
 #ifndef AWQ_ROWS_DBG
@@ -61,6 +63,8 @@ struct RowsParams {
     int su_total;               // super-units of the matrix: ceil(N / RPU)
     int su_base, su_rem;        // super-units per row group: base (+1 for the first rem groups)
     int su_max;                 // most SUs any row group gets
+    int x_bytes;                // LDS: activations [MM][4][Cp] x 16 bytes
+    int sc_pitch, z_pitch;      // LDS per wave: its rows' scales (whole KiB) and zero words (whole 256 bytes)
     uint32_t g_magic;           // (k * g_magic) >> 32 == k / g
     unsigned long long* trace;  // debug builds only
 };
@@ -76,35 +80,26 @@ AWQ_DEV float4_t mfma4(u32x2 a, u32x2 b, float4_t c) {
     return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, a), __builtin_bit_cast(half4_t, b), c, 0, 0, 0);
 }
 
-// One round's request: four weight units (non-temporal), the lane's scale (2 bytes) and zero word.  The bases are fresh
-// SALU results: five wait states before a vector-memory instruction may read them (cdna_hip_programming.md 5.7).
-#if AWQ_ROWS_DBG & 16
+// One round's request: four weight units, non-temporal.  The SGPR base is the tensor pointer itself (a kernel argument,
+// never a fresh SALU result: no wait states needed before a vector-memory instruction reads it, cdna_hip_programming.md
+// 5.7); row and lane offsets travel in the 32-bit VGPR offset (the launcher rejects tensors of 4 GiB and more).
 #define AWQ_ROWS_LPR 4
-#define AWQ_ROWS_REQUEST(R, vw0, vw1, vw2, vw3, b0, b1, b2, b3, vs, bs, vz, bz)                                              \
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %6, %10 nt\n\tglobal_load_dwordx4 %1, %7, %11 nt\n\t"                     \
-                 "global_load_dwordx4 %2, %8, %12 nt\n\tglobal_load_dwordx4 %3, %9, %13 nt\n\tv_mov_b32 %4, 0x3c00\n\tv_mov_b32 %5, 0" \
-                 : "=&v"(R.q[0]), "=&v"(R.q[1]), "=&v"(R.q[2]), "=&v"(R.q[3]), "=&v"(R.sc), "=&v"(R.zw)                        \
-                 : "v"(vw0), "v"(vw1), "v"(vw2), "v"(vw3), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "v"(vs), "s"(bs), "v"(vz),      \
-                   "s"(bz)                                                                                                     \
+#define AWQ_ROWS_REQUEST(R, vw0, vw1, vw2, vw3, base)                                                                        \
+    asm volatile("global_load_dwordx4 %0, %4, %8 nt\n\tglobal_load_dwordx4 %1, %5, %8 nt\n\t"                                  \
+                 "global_load_dwordx4 %2, %6, %8 nt\n\tglobal_load_dwordx4 %3, %7, %8 nt"                                      \
+                 : "=&v"(R.q[0]), "=&v"(R.q[1]), "=&v"(R.q[2]), "=&v"(R.q[3])                                                  \
+                 : "v"(vw0), "v"(vw1), "v"(vw2), "v"(vw3), "s"(base)                                                           \
                  : "memory")
-#else
-#define AWQ_ROWS_LPR 6
-#define AWQ_ROWS_REQUEST(R, vw0, vw1, vw2, vw3, b0, b1, b2, b3, vs, bs, vz, bz)                                              \
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %6, %10 nt\n\tglobal_load_dwordx4 %1, %7, %11 nt\n\t"                     \
-                 "global_load_dwordx4 %2, %8, %12 nt\n\tglobal_load_dwordx4 %3, %9, %13 nt\n\t"                                \
-                 "global_load_ushort %4, %14, %15\n\tglobal_load_dword %5, %16, %17"                                           \
-                 : "=&v"(R.q[0]), "=&v"(R.q[1]), "=&v"(R.q[2]), "=&v"(R.q[3]), "=&v"(R.sc), "=&v"(R.zw)                        \
-                 : "v"(vw0), "v"(vw1), "v"(vw2), "v"(vw3), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "v"(vs), "s"(bs), "v"(vz),      \
-                   "s"(bz)                                                                                                     \
-                 : "memory")
-#endif
 // The wait names every register of the round (they stay allocated until the data has landed) and prints them as a comment:
 // tools/isa_audit.py checks that they ARE the registers the request wrote (no compiler copy of a register whose load is
 // still in flight) and that nothing between request and wait touches them.
-#define AWQ_ROWS_WAIT(R, newer)                                                                       \
-    asm volatile("s_waitcnt vmcnt(%6) ; releases %0 %1 %2 %3 %4 %5"                                    \
-                 : "+v"(R.q[0]), "+v"(R.q[1]), "+v"(R.q[2]), "+v"(R.q[3]), "+v"(R.sc), "+v"(R.zw)      \
-                 : "n"(newer))
+#define AWQ_ROWS_WAIT(R, newer) \
+    asm volatile("s_waitcnt vmcnt(%4) ; releases %0 %1 %2 %3" : "+v"(R.q[0]), "+v"(R.q[1]), "+v"(R.q[2]), "+v"(R.q[3]) : "n"(newer))
+// 1 KiB (64 x 16 bytes) / 256 bytes (64 x 4) from global memory straight into LDS at M0 + 16 (4) * lane: no VGPRs
+#define AWQ_ROWS_DMA16(voff, base, ldsaddr) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(ldsaddr) : "memory", "m0")
+#define AWQ_ROWS_DMA4(voff, base, ldsaddr) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(ldsaddr) : "memory", "m0")
 
 // Phase stamps for tools/trace_gemv_rows.py (debug build only: -DAWQ_GEMV_TRACE); kept in registers, stored at the very end
 // (a store inside the stream would count in vmcnt)
@@ -114,9 +109,8 @@ AWQ_DEV float4_t mfma4(u32x2 a, u32x2 b, float4_t c) {
 #define ROWS_STAMP(slot) do { } while (0)
 #endif
 
-struct Round {  // four units in flight + the lane's scale and zero word for the unit it finishes
+struct Round {  // four units in flight
     u32x4 q[4];
-    uint32_t sc, zw;
 };
 
 constexpr int rows_per_su(int SL) { return SL == 1 || SL == 3 ? 4 : (SL == 2 || SL == 6 ? 2 : 1); }
@@ -154,9 +148,37 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     const int t0 = gi * p.su_base + min(gi, p.su_rem);  // first SU of this wave's row group
     const int nt = p.su_base + (gi < p.su_rem ? 1 : 0);
     const int last_row = p.N - 1;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic segment
+    const int sc_off = p.x_bytes + (rgi * p.wk + wki) * (p.sc_pitch + p.z_pitch), z_off = sc_off + p.sc_pitch;
 
-    // ---- this lane's chunk of a row, per slot
-    int woff[SL], grp[SL], cidx[SL];
+    // ---- 1. activations first (they must be in registers when the first weights land): this wave's share of the block's
+    //         LDS-DMA copy, piece j of 64 chunks per instruction
+    if constexpr (!(AWQ_ROWS_DBG & 2)) {
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int cb = s * p.wk + wki;
+            const int c = min(cb * 64 + lane, p.C - 1);
+            for (int jm = rgi; jm < 4 * MM; jm += p.rg) {
+                const int j = jm & 3, m = jm >> 2;
+                const uint32_t src = (uint32_t)((m * p.K + 32 * c + 8 * j) * 2);
+                const uint32_t dst = lds0 + (uint32_t)(((m * 4 + j) * p.Cp + cb * 64) * 16);
+                AWQ_ROWS_DMA16(src, p.x, dst);
+            }
+        }
+    }
+    // ---- 2. scales and zero words of every row this wave will touch: contiguous in this layout, copied as they are
+    if constexpr (!(AWQ_ROWS_DBG & 16)) {
+        const int rows_w = max(min((t0 + nt) * RPU, p.N) - t0 * RPU, 0);
+        const int sc_bytes = rows_w * p.SW * 2, zd = rows_w * p.ZW;
+        const uint32_t sc_src = (uint32_t)(t0 * RPU * p.SW * 2), z_src = (uint32_t)(t0 * RPU * p.ZW * 4);  // byte offsets
+        for (int o = 0; o < sc_bytes; o += 1024)
+            AWQ_ROWS_DMA16(sc_src + (uint32_t)min(o + 16 * lane, sc_bytes - 16), p.scales, lds0 + (uint32_t)(sc_off + o));
+        for (int o = 0; o < zd; o += 64) AWQ_ROWS_DMA4(z_src + 4u * (uint32_t)min(o + lane, zd - 1), p.qzeros, lds0 + (uint32_t)(z_off + 4 * o));
+    }
+
+    // ---- 3. this lane's chunk of a row per slot, then the ring: D super-units of R rounds each
+    uint32_t woff[SL];
+    int cidx[SL];
     bool act[SL];
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
@@ -166,76 +188,54 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
         const int c = 8 * l0 + lane;
         act[s] = lane < 8 * nl && c < p.C;
         cidx[s] = act[s] ? c : 0;
-        woff[s] = nl > 0 ? 16 * cidx[s] : 0;  // bytes; a slot without lines (padding) reads one 16-byte piece per request
-        grp[s] = (int)__umulhi((uint32_t)(32 * cidx[s]), p.g_magic);
+        woff[s] = nl > 0 ? 16u * (uint32_t)cidx[s] : 0u;  // bytes; a slot without lines (padding) reads one 16-byte piece per request
     }
-    // lane j of a quad finishes unit 4 r + j of every SU in round r: that unit's row within the SU, slot and group
-    const int uj = lane & 3;
-    const QuadSel sel4{uj == 0 ? ~0u : 0u, uj == 1 ? ~0u : 0u, uj == 2 ? ~0u : 0u};
-    int myslot[R], myrow[R], mygrp[R];
-    uint32_t zsh[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        myslot[r] = sel4((4 * r + 0) % SL, (4 * r + 1) % SL, (4 * r + 2) % SL, (4 * r + 3) % SL);
-        myrow[r] = sel4((4 * r + 0) / SL, (4 * r + 1) / SL, (4 * r + 2) / SL, (4 * r + 3) / SL);
-        mygrp[r] = sel4(grp[(4 * r + 0) % SL], grp[(4 * r + 1) % SL], grp[(4 * r + 2) % SL], grp[(4 * r + 3) % SL]);
-        zsh[r] = 4u * (uint32_t)(mygrp[r] & 7);
-    }
-
-    // ---- the ring: D super-units of R rounds each
     Round ring[D][R];
     auto request = [&](Round& Rd, int t, int r) {  // round r of SU t of this row group
         const bool live = t < nt;  // past the last SU the request is kept (the counted waits need it) but reads 16 bytes
         const int row0 = min((t0 + t) * RPU, last_row);
         const int ra = min(row0 + (4 * r + 0) / SL, last_row), rb = min(row0 + (4 * r + 1) / SL, last_row);
         const int rc = min(row0 + (4 * r + 2) / SL, last_row), rd = min(row0 + (4 * r + 3) / SL, last_row);
-        const uint32_t* ba = p.qweight + (int64_t)ra * p.KW;
-        const uint32_t* bb = p.qweight + (int64_t)rb * p.KW;
-        const uint32_t* bc = p.qweight + (int64_t)rc * p.KW;
-        const uint32_t* bd = p.qweight + (int64_t)rd * p.KW;
-        const int wa = live ? woff[(4 * r + 0) % SL] : 0, wb = live ? woff[(4 * r + 1) % SL] : 0;
-        const int wc = live ? woff[(4 * r + 2) % SL] : 0, wd = live ? woff[(4 * r + 3) % SL] : 0;
-        const int myr = min(row0 + myrow[r], last_row) - row0;
-        const uint32_t vs = (uint32_t)((myr * p.SW + mygrp[r]) * 2), vz = (uint32_t)((myr * p.ZW + (mygrp[r] >> 3)) * 4);
-        const half_t* bs = p.scales + (int64_t)row0 * p.SW;
-        const uint32_t* bz = p.qzeros + (int64_t)row0 * p.ZW;
-        AWQ_ROWS_REQUEST(Rd, wa, wb, wc, wd, ba, bb, bc, bd, vs, bs, vz, bz);
+        const int rowb = p.KW * 4;  // bytes per row
+        const uint32_t wa = (uint32_t)(ra * rowb) + (live ? woff[(4 * r + 0) % SL] : 0u), wb = (uint32_t)(rb * rowb) + (live ? woff[(4 * r + 1) % SL] : 0u);
+        const uint32_t wc = (uint32_t)(rc * rowb) + (live ? woff[(4 * r + 2) % SL] : 0u), wd = (uint32_t)(rd * rowb) + (live ? woff[(4 * r + 3) % SL] : 0u);
+        AWQ_ROWS_REQUEST(Rd, wa, wb, wc, wd, p.qweight);
     };
-    // this wave's share of the block's LDS-DMA copy of the activations (piece j of 64 chunks per instruction)
-    auto copy_x = [&]() {
-        const uint32_t xlds = (uint32_t)(uintptr_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic segment
-#pragma unroll
-        for (int s = 0; s < SL; ++s) {
-            const int cb = s * p.wk + wki;
-            const int c = min(cb * 64 + lane, p.C - 1);
-            for (int jm = rgi; jm < 4 * MM; jm += p.rg) {
-                const int j = jm & 3, m = jm >> 2;
-                const half_t* src = p.x + (int64_t)m * p.K + 32 * c + 8 * j;
-                const uint32_t dst = xlds + (uint32_t)(((m * 4 + j) * p.Cp + cb * 64) * 16);
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
-            }
-        }
-    };
-    if constexpr (!(AWQ_ROWS_DBG & 2) && !(AWQ_ROWS_DBG & 32)) copy_x();  // activations first: they must be ready when the first weights land
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int r = 0; r < R; ++r) request(ring[d][r], d, r);
     ROWS_STAMP(1);
-    if constexpr (!(AWQ_ROWS_DBG & 2) && (AWQ_ROWS_DBG & 32)) copy_x();  // experiment: weights requested first
 
-    // ---- activations: the LDS-DMA pieces have landed (they are older than the ring), barrier
-    if constexpr (!(AWQ_ROWS_DBG & 2)) {
-        if constexpr (AWQ_ROWS_DBG & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AWQ_ROWS_LPR * R * D) : "memory");  // everything older than the ring
-        __builtin_amdgcn_s_barrier();
+    // ---- 4. off the critical path: lane j of a quad finishes unit 4 r + j of every SU in round r -- that unit's row within
+    //         the SU, slot and group, and where its scale / zero word sit in LDS
+    const int uj = lane & 3;
+    const QuadSel sel4{uj == 0 ? ~0u : 0u, uj == 1 ? ~0u : 0u, uj == 2 ? ~0u : 0u};
+    int grp[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) grp[s] = (int)__umulhi((uint32_t)(32 * cidx[s]), p.g_magic);
+    int myslot[R], myrow[R], sc_at[R], z_at[R];
+    uint32_t zsh[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        myslot[r] = sel4((4 * r + 0) % SL, (4 * r + 1) % SL, (4 * r + 2) % SL, (4 * r + 3) % SL);
+        myrow[r] = sel4((4 * r + 0) / SL, (4 * r + 1) / SL, (4 * r + 2) / SL, (4 * r + 3) / SL);
+        const int g = sel4(grp[(4 * r + 0) % SL], grp[(4 * r + 1) % SL], grp[(4 * r + 2) % SL], grp[(4 * r + 3) % SL]);
+        zsh[r] = 4u * (uint32_t)(g & 7);
+        sc_at[r] = sc_off + (myrow[r] * p.SW + g) * 2;          // + t * RPU * SW * 2 per SU
+        z_at[r] = z_off + (myrow[r] * p.ZW + (g >> 3)) * 4;     // + t * RPU * ZW * 4 per SU
     }
+    const int sc_step = RPU * p.SW * 2, z_step = RPU * p.ZW * 4;
+
+    // ---- 5. the DMA pieces have landed (they are older than the ring); the activations are shared by the block
+    if constexpr (!(AWQ_ROWS_DBG & 2) || !(AWQ_ROWS_DBG & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AWQ_ROWS_LPR * R * D) : "memory");
+    if constexpr (!(AWQ_ROWS_DBG & 2)) __builtin_amdgcn_s_barrier();
     ROWS_STAMP(2);
 
     // ---- activations LDS -> registers: (t, t+4) pairs; group constants C0 = sum bias * x, SX = sum x
     const int NC = p.wk * SL;
     const int rows_blk = p.su_max * p.rg * RPU;
-    float* red = reinterpret_cast<float*>(smem + (size_t)MM * 4 * p.Cp * 16);
+    float* red = reinterpret_cast<float*>(smem + (size_t)p.x_bytes + (size_t)p.rg * p.wk * (p.sc_pitch + p.z_pitch));
     uint32_t xp[MM][SL][16];
     float c0g[MM][R], sxg[MM][R];
 #pragma unroll
@@ -244,10 +244,15 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #pragma unroll
         for (int s = 0; s < SL; ++s) {
             float se = 0.f, so = 0.f;
+            u32x4 dj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // the four LDS reads of a slot are issued together
+                dj[j] = u32x4{0x3C003C00u + lane, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+                if constexpr (!(AWQ_ROWS_DBG & 2)) dj[j] = *reinterpret_cast<const u32x4*>(smem + (size_t)(((m * 4 + j) * p.Cp + cidx[s]) * 16));
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                u32x4 d = {0x3C003C00u + lane, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
-                if constexpr (!(AWQ_ROWS_DBG & 2)) d = *reinterpret_cast<const u32x4*>(smem + (size_t)(((m * 4 + j) * p.Cp + cidx[s]) * 16));
+                u32x4 d = dj[j];
                 if (!act[s]) d = u32x4{0u, 0u, 0u, 0u};
                 xp[m][s][4 * j + 0] = __builtin_amdgcn_perm(d[2], d[0], 0x05040100u);  // (x0, x4)  bias 1024
                 xp[m][s][4 * j + 1] = __builtin_amdgcn_perm(d[2], d[0], 0x07060302u);  // (x1, x5)  bias 64
@@ -341,13 +346,15 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #pragma unroll
                     for (int m = 0; m < MM; ++m) pu[m][u] = pa[m] + pb[m];
                 }
-                float scl = (float)__builtin_bit_cast(half_t, (uint16_t)Rd.sc);
-                float zf = (float)((Rd.zw >> zsh[r]) & 15u);
+                float scl = 1.f, zf = 0.f;
+                if constexpr (!(AWQ_ROWS_DBG & 16)) {
+                    scl = (float)*reinterpret_cast<const half_t*>(smem + sc_at[r] + t * sc_step);
+                    zf = (float)((*reinterpret_cast<const uint32_t*>(smem + z_at[r] + t * z_step) >> zsh[r]) & 15u);
+                }
                 // every value derived from the round exists before the round is requested again: the old contents are dead
                 // at the request, so the round keeps its registers (no copy of a register with a load in flight)
 #pragma unroll
                 for (int m = 0; m < MM; ++m) asm volatile("" ::"v"(pu[m][0]), "v"(pu[m][1]), "v"(pu[m][2]), "v"(pu[m][3]));
-                asm volatile("" : "+v"(scl), "+v"(zf));  // opaque: hipcc may not fold the fp16 -> fp32 conversion into a later use
                 request(Rd, t + D, r);
 #pragma unroll
                 for (int m = 0; m < MM; ++m) {
@@ -471,6 +478,8 @@ extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_rows(
 int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                          uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st) {
     if (!awq_gemv_rows_supports(M, K, N, g)) return AWQ_ERR_UNSUPPORTED;
+    if ((int64_t)N * K / 2 >= ((int64_t)1 << 32) || (int64_t)N * ZW * 16 >= ((int64_t)1 << 32) || (int64_t)M * K * 2 >= ((int64_t)1 << 31))
+        return AWQ_ERR_UNSUPPORTED;  // 32-bit byte offsets
     RowsParams p;
     p.qweight = reinterpret_cast<const uint32_t*>(qweight);
     p.qzeros = reinterpret_cast<const uint32_t*>(qzeros);
@@ -486,7 +495,9 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     p.wk = (slots + SL - 1) / SL;
     if (p.wk > 8) return AWQ_ERR_UNSUPPORTED;
     p.Cp = p.wk * SL * 64;
-    if (waves <= 0 || waves > 8) waves = 8;
+    // Defaults from the sweeps (profiles/r03_gemv_rows_sweep.txt): four waves per block and one block per CU start fastest
+    // (1024 waves: the dispatch ramp and the per-block copy of x are what a short launch pays for); long streams take two.
+    if (waves <= 0 || waves > 8) waves = p.wk > 4 ? 8 : 4;
     p.rg = 1;
     while (p.rg * 2 * p.wk <= waves) p.rg *= 2;
     const int lines = (p.C + 7) / 8, tslots = p.wk * SL;
@@ -495,15 +506,7 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     if (!awq_magic_u32((uint32_t)g, (uint32_t)K + 32u, &p.g_magic)) return AWQ_ERR_UNSUPPORTED;
     const int RPU = rows_per_su(SL);
     p.su_total = (N + RPU - 1) / RPU;
-    if (bpc <= 0) {  // 1 .. 3 blocks per CU: the smallest maximum number of SUs per row group, then the fewest blocks
-        double best = 1e30;
-        for (int b = 1; b <= 3; ++b) {
-            const int groups = 256 * b * p.rg;
-            const int mx = (p.su_total + groups - 1) / groups;
-            const double cost = (double)mx * groups / p.su_total + 0.02 * b;  // imbalance, mild preference for fewer blocks
-            if (cost < best) { best = cost; bpc = b; }
-        }
-    }
+    if (bpc <= 0) bpc = p.su_total > 8 * 256 * p.rg ? 2 : 1;
     int blocks = 256 * bpc;
     const int max_blocks = (p.su_total + p.rg - 1) / p.rg;  // at least one SU per row group
     if (blocks > max_blocks) blocks = max_blocks;
@@ -512,13 +515,17 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     p.su_rem = p.su_total % groups;
     p.su_max = p.su_base + (p.su_rem ? 1 : 0);
     const bool one_round = SL * RPU == 4;
-    if (depth < 1 || depth > 2) depth = p.su_max >= 2 && one_round ? 2 : 1;
+    if (depth < 1 || depth > 2) depth = p.su_max >= 2 && p.su_max <= 8 && bpc == 1 && one_round ? 2 : 1;
     if (!one_round || (SL == 4 && M > 1) || (SL == 2 && M > 3)) depth = 1;  // instantiated combinations (register budget)
     p.trace = nullptr;
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_rows_trace;
 #endif
-    const size_t lds = (size_t)M * 4 * p.Cp * 16 + (size_t)M * p.su_max * p.rg * RPU * p.wk * SL * 4 * sizeof(float);
+    p.x_bytes = M * 4 * p.Cp * 16;
+    p.sc_pitch = (p.su_max * RPU * p.SW * 2 + 1023) / 1024 * 1024;
+    p.z_pitch = (p.su_max * RPU * p.ZW * 4 + 255) / 256 * 256;
+    const size_t lds = (size_t)p.x_bytes + (size_t)p.rg * p.wk * (p.sc_pitch + p.z_pitch) +
+                       (size_t)M * p.su_max * p.rg * RPU * p.wk * SL * 4 * sizeof(float);
     if (lds > 160 * 1024) return AWQ_ERR_UNSUPPORTED;
 #define AWQ_ROWS_CASE(SLV, DV, MV) \
     if (SL == SLV && depth == DV && M == MV) return launch_rows<SLV, DV, MV>(p, blocks, lds, st);

@@ -8,15 +8,20 @@ A "step" = one decode token through every int4 Linear of the model (the hot path
 per layer qkv (fused, 4096->12288), o (4096->4096), gate+up (fused, 4096->22016), down (11008->4096), 32
 layers, batch 1, distinct random packed weights per layer (3.37 GB working set >> the 256 MiB Infinity Cache),
 captured in ONE hipGraph and replayed.  Inputs are resident in HBM before the timed region.  `value` is that
-leg and nothing else.  N > 1: the same model tensor-parallel over N GPUs (column-split qkv / gate+up,
-row-split o / down with one RCCL all-reduce each) -- strong scaling; `--model 70b` = BASELINE configs[3].
+leg and nothing else.  The Linears are in the reference's WQLinear_GEMV checkpoint format (`--layout gemv`, the
+default since round 3: the format the reference itself recommends for batch 1, README.md:96-97; every output row is
+K/2 contiguous bytes, so the decode kernel csrc/gemv_rows.hip needs no cross-CU split-K exchange); `config.layout`
+names it and `by_layout` times the same step on WQLinear_GEMM and WQLinear_GEMVFast buffers.  N > 1: the same
+model tensor-parallel over N GPUs (column-split qkv / gate+up, row-split o / down with one RCCL all-reduce each)
+-- strong scaling; `--model 70b` = BASELINE configs[3].
 
 Secondary objects on the same JSON line (N = 1, never `value`; each guarded so that the headline cannot
-depend on them): `sustained` (the same graph for >= 1 s), `gemm_bs` (configs[2]'s "bs=8 GEMM for 4096x11008":
-M = 1 .. 64, cold weights), `gemm_prefill` (configs[2]: M = 8 x 2048 = 16384, fused MFMA kernel vs HIP dequant
-+ vendor GEMM, which one the module picks), `moe_bs4` (configs[4]), `decode_chain` (the same Linears as ONE
-persistent launch with true data dependencies, csrc/gemv_chain.hip), `whole_model` (the fused decoder), and
-`cpu_baseline` (the reference's CPU path restated in torch, per shape, M = 1 and 8, on this host's cores).
+depend on them): `sustained` (the same graph for >= 1 s), `per_shape` (the four Linear shapes of the headline one by
+one, each with its own roofline), `by_layout`, `gemm_bs` (configs[2]'s "bs=8 GEMM for 4096x11008": M = 1 .. 64, cold
+weights, GEMM and GEMV layouts), `gemm_prefill` (configs[2]: M = 8 x 2048 = 16384, fused MFMA kernel vs HIP dequant
++ vendor GEMM, which one the module picks), `moe_bs4` (configs[4]), `decode_dependent` (the same Linears with TRUE
+data dependencies: each consumes the previous one's output), `whole_model` (the fused decoder), and `cpu_baseline`
+(the reference's CPU path restated in torch, per shape, M = 1 and 8, on this host's cores).
 """
 import argparse
 import json
@@ -38,6 +43,8 @@ MODELS = {  # hidden, intermediate, layers, heads, kv heads
     "70b": dict(hidden=8192, inter=28672, layers=80, heads=64, kv_heads=8, name="Llama-3-70B"),
 }
 HIDDEN, INTER, LAYERS = 4096, 11008, 32  # the headline model (kept as names for tools/ that import them)
+PMC_FILE = "r03_pmc_fetch_size.txt"      # rocprofv3 --pmc FETCH_SIZE pass of the headline command (tools/prof_r03.sh)
+KERNEL_OF_LAYOUT = {"gemv": "awq_gemv_rows_kernel", "gemm": "awq_gemv_mfma_kernel", "gemvfast": "awq_gemv_fast_kernel"}
 
 
 def pmc_traffic_per_launch():
@@ -45,7 +52,7 @@ def pmc_traffic_per_launch():
     import re
 
     try:
-        txt = open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.txt")).read()
+        txt = open(os.path.join(ROOT, "profiles", PMC_FILE)).read()
         return float(re.search(r"per launch \(weighted mean\): traffic ([0-9.]+) MB", txt).group(1)) * 1e6
     except (OSError, AttributeError):
         return None
@@ -180,6 +187,23 @@ def leg_gemm_bs(dev, ops):
     out["bs8"] = out["by_batch"]["8"]
     del sets
     torch.cuda.empty_cache()
+    # the same matrix shape in the WQLinear_GEMV format (awq_gemv_forward: row-streaming kernel at M <= 2, 16-row MFMA tiles to 16)
+    sets = [rand_packed_nk(K, N, GROUP, dev, gen) for _ in range(nsets)]
+    out["gemv_layout_by_batch"] = {}
+    for M in (1, 2, 4, 8, 16):
+        x = torch.randn((M, K), device=dev, generator=gen).half()
+
+        def fn2():
+            for qw, qz, sc in sets:
+                ops.gemv_forward(x, qw, sc, qz, GROUP)
+
+        us = graph_time(fn2, st, reps=5) / nsets
+        by = algorithmic_bytes(K, N, M, GROUP)
+        out["gemv_layout_by_batch"][str(M)] = {"us": us, "kernel": ops.last_kernel(),
+                                               "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                            "frac": by / us / 1e3 / HBM_PEAK_GBS, "bytes_per_launch": by}}
+    del sets
+    torch.cuda.empty_cache()
     return out
 
 
@@ -255,50 +279,45 @@ def leg_moe(dev):
                          "bytes_per_block": by}}
 
 
-def leg_decode_chain(dev, ops, model, bytes_step):
-    """The headline Linears as ONE dependent chain: qkv -> o (reads q) -> gate|up -> down (reads the first 11008 columns;
-    a 128-link chain of random matrices with the quadratic silu * up in it blows up numerically) -> next qkv.  Timed both
-    as one persistent launch (csrc/gemv_chain.hip) and as one launch per Linear with the SAME data dependencies."""
-    from autoawq_amd.chain import ChainLink, DecodeChain
+def forward_lin(ops, lin, x):
+    if lin["layout"] == "gemm":
+        return ops.gemm_forward(x, lin["qw"], lin["sc"], lin["qz"])
+    if lin["layout"] == "gemv":
+        return ops.gemv_forward(x, lin["qw"], lin["sc"], lin["qz"], GROUP)
+    return ops.gemv_fast_forward(x, lin["qw"], lin["sc"], lin["qz"], GROUP)
 
+
+def leg_decode_dependent(dev, ops, model, bytes_step):
+    """The headline Linears as ONE dependent chain: qkv -> o (reads q) -> gate|up -> down (reads the first 11008 columns;
+    a 128-link chain of random matrices with the quadratic silu * up in it blows up numerically) -> next qkv: one launch
+    per Linear, every launch consuming the previous one's output (the headline replays them with fixed inputs)."""
     lins = [lin for layer in model for lin in layer]
     x0 = lins[0]["x"]
     x = x0
     for lin in lins:  # unit gain per link, or fp16 overflows after a few layers
-        y = ops.gemm_forward(x[:, : lin["K"]].contiguous(), lin["qw"], lin["sc"], lin["qz"])
+        y = forward_lin(ops, lin, x[:, : lin["K"]].contiguous())
         rms = float(y.float().pow(2).mean().sqrt())
         lin["sc"].mul_(1.0 / max(rms, 1e-6))
-        x = ops.gemm_forward(x[:, : lin["K"]].contiguous(), lin["qw"], lin["sc"], lin["qz"])
-    y_last = torch.zeros((1, lins[-1]["N"]), dtype=torch.float16, device=dev)
-    links = [ChainLink(l["qw"], l["sc"], l["qz"], x=x0 if i == 0 else None, y=y_last if i == len(lins) - 1 else None)
-             for i, l in enumerate(lins)]
-    chain = DecodeChain(links, M=1)
+        x = forward_lin(ops, lin, x[:, : lin["K"]].contiguous())
 
-    def sequential():
+    def sequential():  # batch 1: the slice a consumer takes (q of qkv, the first 11008 of gate|up) is a view, no copy launch
         t = x0
         for l in lins:
-            t = ops.gemm_forward(t[:, : l["K"]], l["qw"], l["sc"], l["qz"])
+            t = forward_lin(ops, l, t[:, : l["K"]])
         return t
 
-    ref = sequential()
-    chain()
-    torch.cuda.synchronize()
-    st_ = chain.status()
-    err = float((y_last.float() - ref.float()).abs().max() / ref.float().abs().max())
-    assert st_ == 0 and err < 2e-2, f"persistent chain: status {st_:#x}, final output off by {err}"
     st = torch.cuda.Stream(device=dev)
     us_seq = graph_time(sequential, st, reps=10, min_seconds=0.3)
-    us_chain = graph_time(chain.forward, st, reps=10, min_seconds=0.3)
-    assert chain.status() == 0
 
     def obj(us):
         return {"ms_per_token": us / 1e3, "tok_s": 1e6 / us,
                 "roofline": {"bound": "hbm", "achieved": bytes_step / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_step / us / 1e3 / HBM_PEAK_GBS}}
 
-    return {"what": "the same 128 Linears with TRUE data dependencies (each consumes the previous one's output)",
-            "one_launch_per_linear": obj(us_seq), "persistent_chain": obj(us_chain), "final_output_max_rel_diff": err,
-            "links": len(links), "grid_blocks": chain.grid_blocks()}
+    return {"what": "the same 128 Linears with TRUE data dependencies (each consumes the previous one's output), one launch each",
+            "layout": lins[0]["layout"], "one_launch_per_linear": obj(us_seq), "links": len(lins),
+            "note": "round 2's persistent chain kernel (one launch for the whole token, GEMM layout) measured at parity with launches "
+                    "and left the product library: tools/experimental/README.md"}
 
 
 def leg_whole_model(dev):
@@ -320,8 +339,18 @@ def cpu_baseline(layers_total):
     only).  Bounded sample: the three distinct Linear shapes of one layer, median of 3 after a warm-up."""
     from oracle import awq_oracle
 
-    torch.set_num_threads(os.cpu_count() or 1)
     gen = torch.Generator().manual_seed(7)
+    # 256 threads on this box OVERSUBSCRIBE these memory-bound torch ops (5x slower than 8): take the best of {8, 32, all}
+    ncpu = os.cpu_count() or 1
+    qw0, qz0, sc0 = rand_packed(HIDDEN, HIDDEN, GROUP, "cpu", gen)
+    tries = {}
+    for nthr in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+        torch.set_num_threads(nthr)
+        awq_oracle.torch_dequantize_gemm(qw0, qz0, sc0, GROUP)
+        t0 = time.perf_counter()
+        awq_oracle.torch_dequantize_gemm(qw0, qz0, sc0, GROUP)
+        tries[nthr] = time.perf_counter() - t0
+    torch.set_num_threads(min(tries, key=tries.get))
 
     def med(fn, n=3):
         fn()
@@ -349,6 +378,7 @@ def cpu_baseline(layers_total):
         return 4 * a[key] + 2 * b[key] + c[key]
 
     return {"value": 1.0 / (layer_s("linear_M1_s") * layers_total), "unit": "tok/s", "cores": torch.get_num_threads(), "kind": "port",
+            "thread_counts_tried_dequant_4096x4096_s": {str(k): v for k, v in tries.items()},
             "sample": f"the 3 distinct Linear shapes of 1 of {layers_total} layers, median of 3 (dequant) / 5 (matmul); a layer = 4 x "
                       f"{HIDDEN}x{HIDDEN} + 2 x {HIDDEN}x{INTER} + 1 x {INTER}x{HIDDEN} = {layer_s('linear_M1_s'):.2f} s; "
                       "torch-CPU restatement of dequantize_gemm + fp16 matmul",
@@ -358,6 +388,46 @@ def cpu_baseline(layers_total):
             "cached_dequant_tok_s_M8_per_sequence": 1.0 / (layer_s("matmul_M8_s") * layers_total)}
 
 
+def leg_per_shape(dev, ops, model, shapes):
+    """The four Linear shapes of the headline one by one: the 32 layers' instances of a shape (distinct weights: 0.28 - 1.5 GB,
+    nothing comes from the Infinity Cache) captured in one hipGraph; us per launch (HIP events on the launch stream),
+    algorithmic GB/s, fraction of 8 TB/s."""
+    st = torch.cuda.Stream(device=dev)
+    out = {}
+    for idx, (name, K, N, _) in enumerate(shapes):
+        lins = [layer[idx] for layer in model]
+
+        def fn():
+            for l in lins:
+                forward_lin(ops, l, l["x"])
+
+        us = graph_time(fn, st, reps=20, min_seconds=0.05) / len(lins)
+        by = algorithmic_bytes(K, N, 1, GROUP)
+        out[name] = {"K": K, "N": N, "us_per_launch": us, "bytes_per_launch": by, "kernel": ops.last_kernel(),
+                     "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS}}
+    return out
+
+
+def leg_by_layout(dev, ops, layers, skip):
+    """The headline step (every int4 Linear of the model, batch 1, one hipGraph) on the other two checkpoint formats."""
+    st = torch.cuda.Stream(device=dev)
+    out = {}
+    for layout in ("gemm", "gemv", "gemvfast"):
+        if layout == skip:
+            continue
+        model, _ = build_model(dev, 0, 1, layers, layout=layout)
+        by = sum(algorithmic_bytes(l["K"], l["N"], 1, GROUP) for layer in model for l in layer)
+        if layout == "gemvfast":
+            by += sum((l["K"] // GROUP) * l["N"] * 3 // 2 for layer in model for l in layer)
+        outs = [None] * sum(len(l) for l in model)
+        us = graph_time(lambda: run_step(model, outs, ops, None), st, reps=20, min_seconds=0.3)
+        out[layout] = {"tok_s": 1e6 / us, "ms_per_step": us / 1e3, "kernel": ops.last_kernel(),
+                       "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS}}
+        del model, outs
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -365,8 +435,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", choices=sorted(MODELS), default="7b", help="7b = BASELINE configs[1] (the metric); 70b = configs[3] (TP=8)")
     ap.add_argument("--layers", type=int, default=0, help="debug only; the metric is quoted at the model's full depth")
-    ap.add_argument("--layout", choices=["gemm", "gemv", "gemvfast"], default="gemm",
-                    help="checkpoint format of the Linears: WQLinear_GEMM (default) / _GEMV / _GEMVFast buffers")
+    ap.add_argument("--layout", choices=["gemm", "gemv", "gemvfast"], default="gemv",
+                    help="checkpoint format of the Linears: WQLinear_GEMV (default: the reference's own batch-1 format, README.md:96-97) / "
+                         "WQLinear_GEMM / WQLinear_GEMVFast buffers")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-model", action="store_true", help="skip the secondary whole-decoder figure")
@@ -474,6 +545,8 @@ def main():
             "config": {"workload": f"{cfg['name']}-shape AWQ int4 g128, GEMV bs=1 decode: {layers} layers x {{{shape_txt}}}"
                                    + (" per rank" if world > 1 else ""),
                        "layers": layers, "launches_per_step": launches, "hipgraph": used_graph, "layout": a.layout,
+                       "layout_note": "packed tensors in the reference's WQLinear_" + {"gemm": "GEMM", "gemv": "GEMV", "gemvfast": "GEMVFast"}[a.layout] +
+                                      " checkpoint format (awq/modules/linear/); utils/convert.py repacks between the three, bit-exactly",
                        "parallelism": f"tp{world}" if world > 1 else "single",
                        "collectives_per_step": sum(1 for layer in model for l in layer if l["reduce"]),
                        "algorithmic_bytes_per_step_all_ranks": bytes_all, "kernel": ops.last_kernel()},
@@ -481,15 +554,15 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          # HBM bytes per launch need the TCC fabric counters of a separate rocprofv3 --pmc pass
                          # (MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950): not measurable from inside this process
-                         "traffic": pmc_traffic_per_launch() if (world == 1 and a.model == "7b" and a.layout == "gemm" and layers == cfg["layers"]) else None,
+                         "traffic": pmc_traffic_per_launch() if (world == 1 and a.model == "7b" and a.layout == "gemv" and layers == cfg["layers"]) else None,
                          "traffic_unit": "bytes per launch",
-                         "traffic_measured_in": "profiles/r02_pmc_fetch_size.txt (own rocprofv3 --pmc FETCH_SIZE pass of this command, x 2 gfx950 correction, calibrated on a linear read)",
+                         "traffic_measured_in": "profiles/" + PMC_FILE + " (own rocprofv3 --pmc FETCH_SIZE pass of this command, x 2 gfx950 correction, calibrated on a linear read; the file names the git head it was taken at)",
                          "bytes_per_launch": bytes_step / launches, "avg_launch_us": ms_step * 1e3 / launches,
-                         "kernel": "awq_gemv_mfma_kernel (4 shapes per layer: qkv, o, gate+up, down)",
+                         "kernel": KERNEL_OF_LAYOUT[a.layout] + " (4 shapes per layer: qkv, o, gate+up, down; `per_shape` has each one's own figure)",
                          "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "
                                  "HIP-event-timed replay of the captured stream / launches, i.e. it contains the "
                                  "dispatch gap exactly as rocprofv3's back-to-back kernel durations do "
-                                 "(profiles/r02_bench_kernel_trace_stats.txt)"},
+                                 "(profiles/r03_bench_kernel_trace_stats.txt)"},
         }
         if capture_note:
             out["config"]["capture_note"] = capture_note
@@ -497,11 +570,14 @@ def main():
             ms_s, n_s = sustained
             out["sustained"] = {"seconds": ms_s / 1e3, "steps": n_s, "ms_per_step": ms_s / n_s, "tok_s": 1000.0 * n_s / ms_s,
                                 "GBps": bytes_step * n_s / ms_s / 1e6, "frac": bytes_step * n_s / ms_s / 1e6 / HBM_PEAK_GBS}
-        full = world == 1 and layers == cfg["layers"] and a.layout == "gemm" and a.model == "7b" and not a.no_secondary
+        full = world == 1 and layers == cfg["layers"] and a.model == "7b" and not a.no_secondary
         if full:
             del graph, outs
-            legs = [("gemm_bs", lambda: leg_gemm_bs(dev, ops)), ("gemm_prefill", lambda: leg_gemm_prefill(dev, ops)),
-                    ("moe_bs4", lambda: leg_moe(dev)), ("decode_chain", lambda: leg_decode_chain(dev, ops, model, bytes_step))]
+            legs = [("per_shape", lambda: leg_per_shape(dev, ops, model, shapes)),
+                    ("decode_dependent", lambda: leg_decode_dependent(dev, ops, model, bytes_step)),
+                    ("by_layout", lambda: (model.clear(), torch.cuda.empty_cache(), leg_by_layout(dev, ops, layers, a.layout))[2]),
+                    ("gemm_bs", lambda: leg_gemm_bs(dev, ops)), ("gemm_prefill", lambda: leg_gemm_prefill(dev, ops)),
+                    ("moe_bs4", lambda: leg_moe(dev))]
             if not a.no_whole_model:
                 legs.append(("whole_model", lambda: (model.clear(), torch.cuda.empty_cache(), leg_whole_model(dev))[2]))
             for name, fn in legs:

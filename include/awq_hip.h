@@ -158,9 +158,9 @@ AWQ_EXPORT int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweigh
  * awq_ext.gemmv2_forward_cuda(..., group_size, split_k_iters) (awq/modules/linear/gemv.py:168-180).
  * y [M, N] fp16 = x [M, K] fp16 @ dequant(qweight)^T, fp32 accumulation, 1 <= M <= 16 per call and
  * awq_gemv_lds_bytes(M, K, ZW) <= 160 KiB (the host wrapper chunks larger M); no bias (the
- * reference adds it afterwards, gemv.py:185).  AUTO: M <= 4 takes the row-streaming kernel (gemv_rows.hip: a wave
- * instruction reads 1 KiB of one row, activations in registers, no LDS staging, no cross-CU exchange), 5 <= M <= 16 the
- * 16-row MFMA tile kernel (gemv_nk.hip).  flags: AWQ_GEMM_FLAG_KERNEL = AWQ_GEMV_KERNEL_*; tuning: _WAVES (waves per
+ * reference adds it afterwards, gemv.py:185).  AUTO: M = 1 (and M = 2 for K <= 6144) takes the row-streaming kernel
+ * (gemv_rows.hip: a wave instruction reads 1 KiB of one row, activations in registers, no cross-CU exchange; needs
+ * group_size % 128 == 0 and K <= 65536), everything else up to M = 16 the 16-row MFMA tile kernel (gemv_nk.hip).  flags: AWQ_GEMM_FLAG_KERNEL = AWQ_GEMV_KERNEL_*; tuning: _WAVES (waves per
  * block), _UNIT (TILE16: unroll; ROWS: super-units in flight per wave, 1 | 2), _SPLITK (ROWS: blocks per CU), _NLOG (ROWS:
  * 1-KiB slots of a row per wave, 1 | 2 | 3 | 4 | 6 | 8). */
 #define AWQ_GEMV_KERNEL_AUTO 0u
@@ -285,50 +285,6 @@ AWQ_EXPORT int awq_decode_attention_rope(const uint16_t* qkv, uint16_t* k_cache,
                                          const int32_t* pos_dev, int64_t start_pos, int64_t max_len, int64_t B,
                                          int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq,
                                          float scale, void* workspace, size_t workspace_bytes, void* stream);
-
-/* ---- decode chain: a run of dependent decode-sized projections in ONE persistent launch -------------
- * Decode calls the int4 Linears of a block one after the other, each consuming the previous one's output
- * (awq/modules/fused/block.py:108-119 -> mlp.py:46-70: o_proj -> gate|up -> down -> next block's qkv_proj;
- * call sites awq/modules/linear/gemm.py:56-58, awq/modules/fused/mlp.py:37-62).  A chain runs such a run of
- * awq_gemm_forward calls (M <= 8, group_size % 128 == 0, N % 32 == 0) in one kernel: every Linear's weights
- * are requested while the previous Linear's result is still being combined, activations travel between the
- * links as self-validating tagged words.  Link 0 reads external fp16 rows `x`; link i > 0 reads the output
- * of link i - 1 (x_from = i - 1), K columns starting at column x_col0 -- or 2K columns [gate | up] with
- * AWQ_CHAIN_X_GATED_SILU, staged as silu(gate) * up exactly like awq_silu_and_mul.  `y` (fp16 [M, N]) may be
- * NULL for a link whose output is only consumed inside the chain.  Epilogue per link: + bias, then
- * y = fp16(fp16(x W + bias) + add_residual) if add_residual != NULL.
- *
- * Use: awq_chain_build() turns the host-side link list into a device-format plan in HOST memory
- * (plan_host, awq_chain_plan_bytes(n) bytes) holding the workspace addresses it assigned; the caller copies
- * the plan to device memory once (the library never allocates or copies) and then calls awq_chain_forward()
- * per step (hipGraph-capturable; nothing is reset between calls).  With workspace == NULL awq_chain_build only
- * reports the workspace size.  The workspace (256-byte aligned) is zeroed ONCE with awq_chain_workspace_init and
- * serves one chain launch at a time.  Every in-kernel wait is bounded: a give-up sets a sticky error word,
- * awq_chain_status() reads it back (synchronises the stream; 0 = healthy). */
-#define AWQ_CHAIN_X_GATED_SILU 1u
-typedef struct AwqChainLink {
-    const int32_t* qweight;  /* [K, N/8] */
-    const uint16_t* scales;  /* [K/g, N] */
-    const int32_t* qzeros;   /* [K/g, N/8] */
-    const uint16_t* bias;    /* [N] or NULL */
-    int64_t K, N, group_size;
-    const uint16_t* x;       /* link 0 only: fp16 [M, x_stride] */
-    int64_t x_stride;
-    int64_t x_from;          /* -1 (link 0) or i - 1 */
-    int64_t x_col0;          /* first column taken of the producer's output (multiple of 4) */
-    uint32_t flags;          /* AWQ_CHAIN_X_GATED_SILU */
-    uint32_t reserved;
-    uint16_t* y;             /* [M, N] or NULL */
-    const uint16_t* add_residual; /* [M, N] or NULL */
-} AwqChainLink;
-AWQ_EXPORT size_t awq_chain_plan_bytes(int64_t n_links);
-AWQ_EXPORT int awq_chain_grid_blocks(void);
-AWQ_EXPORT int awq_chain_build(const AwqChainLink* links, int64_t n_links, int64_t M, void* workspace,
-                               size_t workspace_bytes, void* plan_host, size_t plan_bytes, size_t* workspace_needed);
-AWQ_EXPORT int awq_chain_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
-AWQ_EXPORT int awq_chain_forward(const void* plan_dev, const void* plan_host, void* workspace, size_t workspace_bytes,
-                                 void* stream);
-AWQ_EXPORT int awq_chain_status(const void* workspace, void* stream, uint32_t* err_out);
 
 #ifdef __cplusplus
 }

@@ -484,6 +484,14 @@ def test_gemv_layout_golden(ops, oracle, name):
     assert_product_close(y, y32, f"{name} gemv layout", wsigma=wsig)
 
 
+GEMV_KERNEL_TILE16, GEMV_KERNEL_ROWS = 1, 2  # AWQ_GEMV_KERNEL_* of include/awq_hip.h
+
+
+def gemv_rows_takes(M, K, g):
+    """AUTO dispatch of awq_gemv_forward (capi.hip): the row-streaming kernel at batch 1, and at batch 2 while K <= 6144"""
+    return g % 128 == 0 and K % g == 0 and K >= 128 and (M == 1 or (M == 2 and K <= 6144))
+
+
 @pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (11008, 4096, 128), (4096, 11008, 128), (1024, 72, 64),
                                    (512, 40, 32), (2048, 200, 2048), (256, 16, 128)])
 @pytest.mark.parametrize("M", [1, 2, 5, 8, 16, 33])
@@ -494,9 +502,13 @@ def test_gemv_layout_vs_oracle(ops, oracle, K, N, g, M):
     assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
     y32, _ = oracle.matmul(x.numpy(), W)
     wsig = oracle.weight_rounding_sigma(x.numpy(), W)
-    for flags in (0, ops.gemm_flags(waves=4, unit=8), ops.gemm_flags(waves=16, unit=4)):
+    tile16 = ops.gemm_flags(kernel=GEMV_KERNEL_TILE16)
+    for flags in (0, tile16, tile16 | ops.gemm_flags(waves=4, unit=8), tile16 | ops.gemm_flags(waves=16, unit=4)):
         y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=flags)
-        assert ops.last_kernel() == "gemv_nk"
+        if flags == 0 and (M <= 2 or (M <= 16 and K <= 4096)):  # (wider K: the wrapper splits the batch to fit the tile kernel's LDS)
+            assert ops.last_kernel() == ("gemv_rows" if gemv_rows_takes(M, K, g) else "gemv_nk")
+        elif flags:
+            assert ops.last_kernel() == "gemv_nk"
         assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemv K{K} N{N} g{g} M{M} f{flags:x}", wsigma=wsig)
     # bitwise reproducible, one-hot rows select rows of the bit-exact W, zero in -> zero out
     y1 = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g)
@@ -506,6 +518,66 @@ def test_gemv_layout_vs_oracle(ops, oracle, K, N, g, M):
     e[torch.arange(M, device="cuda"), ks] = 1.0
     assert torch.equal(ops.gemv_forward(e, qw.cuda(), sc.cuda(), qz.cuda(), g), Wt.t()[ks])
     assert int(ops.gemv_forward(torch.zeros_like(e), qw.cuda(), sc.cuda(), qz.cuda(), g).abs().max()) == 0
+
+
+# the row-streaming kernel (csrc/gemv_rows.hip): 7B shapes incl. the fused qkv / gate|up widths bench.py --layout gemv
+# times, the 70B TP = 8 shard shapes of BASELINE configs[3] (8192 -> 1280, 1024 -> 8192, 8192 -> 7168, 3584 -> 8192), the
+# unsharded 70B shapes (8192 -> 10240; K = 28672: two waves side by side on a row), odd sizes (N not a multiple of the
+# rows per super-unit, one-line rows, a group wider than a slot, g = 256)
+ROWS_SHAPES = [(4096, 4096, 128), (4096, 12288, 128), (4096, 22016, 128), (11008, 4096, 128), (8192, 1280, 128),
+               (1024, 8192, 128), (8192, 7168, 128), (3584, 8192, 128), (8192, 10240, 128), (28672, 1024, 128),
+               (13824, 5120, 128), (2048, 200, 2048), (256, 16, 128), (1280, 10, 256), (384, 7, 128), (4096, 4099, 128)]
+
+
+@pytest.mark.parametrize("K,N,g", ROWS_SHAPES)
+def test_gemv_rows_kernel_vs_oracle(ops, oracle, K, N, g):
+    """every batch size the kernel takes (1..4), the default configuration and forced ones: slots per wave (whole rows
+    or several waves side by side), waves per block, super-units in flight, blocks per CU"""
+    small = K * N <= 4096 * 4096
+    qw, qz, sc, x4 = gemv_case(K, N, g, 4, seed=K + 5 * N)
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+    Wt = ops.dequantize_weights_gemv(qw.cuda(), sc.cuda(), qz.cuda(), g)
+    assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
+    qwc, qzc, scc = qw.cuda(), qz.cuda(), sc.cuda()
+    rows = ops.gemm_flags(kernel=GEMV_KERNEL_ROWS)
+    forced = [0] + [ops.gemm_flags(nlog=sl) for sl in (1, 2, 3, 4, 6, 8)] + [
+        ops.gemm_flags(waves=8, unit=1, splitk=1), ops.gemm_flags(waves=4, unit=2, splitk=2), ops.gemm_flags(waves=8, unit=2, splitk=3),
+        ops.gemm_flags(waves=2, unit=1, splitk=1)]
+    ran = 0
+    for M in (1, 2, 3, 4) if small else (1, 2):
+        x = x4[:M].contiguous()
+        y32, _ = oracle.matmul(x.numpy(), W)
+        wsig = oracle.weight_rounding_sigma(x.numpy(), W)
+        for f in forced if (small or M == 1) else forced[:1]:
+            try:
+                y = ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=rows | f)
+            except Exception as e:  # a forced slot count the register budget or the 8-wave limit rules out
+                assert "code -3" in str(e), e
+                assert f != 0, f"K{K} N{N} M{M}: the default configuration must run"
+                continue
+            assert ops.last_kernel() == "gemv_rows"
+            ran += 1
+            assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"rows K{K} N{N} g{g} M{M} f{f:x}", wsigma=wsig)
+            assert torch.equal(y, ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=rows | f)), "not bitwise reproducible"
+        e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+        ks = (torch.arange(M, device="cuda") * 1237 + K - 3) % K
+        e[torch.arange(M, device="cuda"), ks] = 1.0
+        assert torch.equal(ops.gemv_forward(e, qwc, scc, qzc, g, flags=rows), Wt.t()[ks]), "one-hot rows must select rows of W"
+        assert int(ops.gemv_forward(torch.zeros_like(e), qwc, scc, qzc, g, flags=rows).abs().max()) == 0
+        assert torch.equal(ops.gemv_forward(2 * x.cuda(), qwc, scc, qzc, g, flags=rows).float(),
+                           2 * ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=rows).float()), "f(2x) != 2 f(x)"
+    assert ran >= (8 if small else 2)
+
+
+def test_gemv_rows_refuses_what_it_cannot_take(ops):
+    """g = 64 / 32 (a lane quad would straddle groups), M > 4: AWQ_ERR_UNSUPPORTED when forced, the tile kernel on AUTO"""
+    rows = ops.gemm_flags(kernel=GEMV_KERNEL_ROWS)
+    for K, N, g, M in [(1024, 72, 64, 1), (512, 40, 32, 1), (4096, 64, 128, 5)]:
+        qw, qz, sc, x = gemv_case(K, N, g, M, seed=1)
+        with pytest.raises(Exception, match="code -3"):
+            ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=rows)
+        ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g)
+        assert ops.last_kernel() == "gemv_nk"
 
 
 def test_gemv_module_forward_semantics(ops, oracle):
