@@ -347,6 +347,9 @@ int launch_skinny(const SkinnyParams& p, dim3 grid, size_t lds, hipStream_t st) 
 
 bool awq_gemm_skinny_supports(int M, int K, int N, int g) {
     uint32_t magic;
+    // all reducer blocks of a launch must be co-resident (2 per tile up to 32 rows, 4 above; one 128 KB block per CU in the
+    // worst case): N <= 32768 / 16384.  Wider matrices (7B gate|up at M > 32) take the LDS-tiled kernel.
+    if ((int64_t)(M > 32 ? 4 : 2) * ((N + 255) / 256) > 256) return false;
     return M >= 9 && M <= 64 && K >= 128 && K % 64 == 0 && g % 64 == 0 && K % g == 0 && N % 8 == 0 && K < 65536 &&
            (int64_t)K * (N / 8) * 4 < ((int64_t)1 << 31) && (int64_t)(K / g) * N * 2 < ((int64_t)1 << 31) &&
            awq_magic_u32((uint32_t)g, (uint32_t)K + 64u, &magic);
@@ -370,9 +373,8 @@ int awq_launch_gemm_skinny(const AwqGemmArgs& a, int splitk) {
     if (S < 1) S = 1;
     int sps = (T + S - 1) / S;
     // 128 KB of LDS for the activation slice (one block per CU at M > 32): with 96 KB a 64-row batch had to take six
-    // slices instead of four: 4096 x 11008, M = 64: 25.2 -> 17.9 us (AWQ_SKINNY_LDS_KB overrides, for sweeps)
-    static const int lds_kb = [] { const char* e = getenv("AWQ_SKINNY_LDS_KB"); const int v = e ? atoi(e) : 128; return v < 32 ? 32 : (v > 144 ? 144 : v); }();
-    const int sps_max = (lds_kb * 1024) / (BM * 128);
+    // slices instead of four: 4096 x 11008, M = 64: 25.2 -> 17.9 us
+    const int sps_max = (128 * 1024) / (BM * 128);
     if (sps > sps_max) sps = sps_max;  // more slices than asked for: the slice has to fit
     S = (T + sps - 1) / sps;
     if (S > 1 && S < R) {  // the reducers are the last R slices: fewer slices than that -> exactly R, or no split at all
@@ -383,7 +385,7 @@ int awq_launch_gemm_skinny(const AwqGemmArgs& a, int splitk) {
         if (S < R) {
             S = 1;
             sps = T;
-            if (sps > sps_max) return AWQ_ERR_UNSUPPORTED;
+            if (sps > (128 * 1024) / (BM * 128)) return AWQ_ERR_UNSUPPORTED;
         }
     }
     if (S > 1) {
@@ -404,6 +406,11 @@ int awq_launch_gemm_skinny(const AwqGemmArgs& a, int splitk) {
     p.err = a.counters;
     const size_t a_bytes = (size_t)sps * BM * 128, fold_bytes = (size_t)4 * MI * 4 * 1024;
     const size_t lds = a_bytes > fold_bytes ? a_bytes : fold_bytes;
+    // Every reducer block (the last R slices of every tile) polls the other slices of its tile, so all R * tiles of them have
+    // to be RESIDENT at once, or the resident ones spin on blocks that cannot be scheduled.  Two 512-thread
+    // blocks fit a CU up to 80 KB of LDS each.  awq_gemm_skinny_supports() already keeps R * tiles <= 256; this is the net
+    // under it.
+    if (S > 1 && R * tiles > 256 * (lds <= 80 * 1024 ? 2 : 1)) return AWQ_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles, (unsigned)S, 1u);
     return MI == 2 ? launch_skinny<2>(p, grid, lds, a.stream) : launch_skinny<4>(p, grid, lds, a.stream);
 }

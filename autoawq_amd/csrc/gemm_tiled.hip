@@ -410,7 +410,7 @@ extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_tiled
 #endif
 
 // AWQ_TILED_FAT=0 falls back to the 8-wave 64 x 64-per-wave tiles everywhere (A/B measurements)
-static const bool g_fat = [] { const char* e = getenv("AWQ_TILED_FAT"); return !(e && e[0] == '0'); }();
+static const bool g_fat = true;  // 64 x 128 "fat" waves for the chip-filling tiles (the r01 A/B switch read an environment variable here)
 
 bool awq_gemm_tiled_supports(int M, int K, int N, int g) {
     if (M < 1) return false;

@@ -219,8 +219,9 @@ def test_auto_dispatch_table_host_only():
     for K, N in [(4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288), (4096, 22016)]:
         for M in (1, 2, 4, 8):
             assert q(M, K, N) == ops.KERNEL_MFMA_GEMV
-        for M in (17, 32, 64):
-            assert q(M, K, N) == ops.KERNEL_SKINNY
+        for M in (17, 32, 64):  # above 32 rows the batched kernel has four reducer blocks per tile, all of which must be
+            # resident at once (one 128 KB block per CU): 86 tiles x 4 > 256 -> the LDS-tiled kernel
+            assert q(M, K, N) == (ops.KERNEL_TILED if (M > 32 and N > 16384) else ops.KERNEL_SKINNY)
         for M in (65, 128):
             assert q(M, K, N) == ops.KERNEL_TILED
         assert q(16384, K, N) == ops.KERNEL_REGB

@@ -64,6 +64,132 @@ def test_fused_prefill_gemm_at_config3_shape_vs_oracle(ops, oracle, K, N, M, wha
     assert_product_close(ym[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module route {what}")
 
 
+# ------------------------------------------------------------------ config 3: the kernel that actually runs there
+
+@pytest.mark.parametrize("K,N", [(4096, 11008), (11008, 4096)])
+@pytest.mark.parametrize("bm", [1, 2])
+def test_regb_prefill_kernel_directly_at_config3_shape(ops, oracle, K, N, bm):
+    """csrc/gemm_regb.hip FORCED (128- and 256-row tiles) at M = 16384: every output element against the fp32 product of
+    the bit-exact dequantised weights, 128 sampled rows (first and last included) against the CPU oracle, and AUTO takes
+    this kernel at this size (VERDICT r02 item 1 ii)."""
+    M = 16384
+    qw, qz, s, _, bias = fullrange_case(K, N, 128, 1, seed=K + 7 * N + bm, realistic=True)
+    gen = torch.Generator().manual_seed(K + bm)
+    x = torch.randn((M, K), generator=gen).half()
+    dq, ds, dz, db, dx = qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), x.cuda()
+    y = ops.gemm_forward(dx, dq, ds, dz, db, flags=ops.gemm_flags(ops.KERNEL_REGB, nlog=bm))
+    assert ops.last_kernel() == "gemm_regb"
+    assert ops.auto_kernel(M, K, N, 128) == ops.KERNEL_REGB
+    rows = torch.randperm(M, generator=gen)[:128].sort().values
+    rows[0], rows[-1] = 0, M - 1
+    y32, _ = oracle.linear_gemm(x[rows].numpy(), qw.numpy(), qz.numpy(), s.numpy(), 128, bias.numpy())
+    assert_product_close(y[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"regb bm{bm} {K}x{N} M{M}")
+    W = ops.dequantize_weights(dq, ds, dz).float()
+    for m0 in range(0, M, 2048):
+        ref = dx[m0:m0 + 2048].float() @ W + db.float()
+        err = (y[m0:m0 + 2048].float() - ref).abs()
+        tol = 2e-3 * ref.abs() + 2e-3 * ref.abs().mean()
+        assert bool((err <= tol).all()), (K, N, bm, m0, float(err.max()))
+    assert torch.equal(y, ops.gemm_forward(dx, dq, ds, dz, db, flags=ops.gemm_flags(ops.KERNEL_REGB, nlog=bm))), "not reproducible"
+
+
+# ------------------------------------------------------------------ the batched-decode configurations bench.py times
+
+@pytest.mark.parametrize("K,N", [(4096, 11008), (4096, 22016), (4096, 28672)])
+@pytest.mark.parametrize("M", [17, 32, 33, 48, 64])
+def test_batched_decode_at_benched_shapes_vs_oracle(ops, oracle, K, N, M):
+    """csrc/gemm_skinny.hip at the widths `gemm_bs` times (4096 x 11008) and at the fused gate|up widths (22016, and 28672
+    of the 70B model): AUTO and forced K splits against the oracle, the one-hot row check.  Above 32 rows the kernel has four
+    reducer blocks per tile which must all be resident: N > 16384 is refused there (344 reducers on 256 CUs spun
+    until the give-up) and AUTO takes the LDS-tiled kernel, checked here as well."""
+    qw, qz, s, x, bias = fullrange_case(K, N, 128, M, seed=K + N + M, realistic=True)
+    y32, _ = oracle.linear_gemm(x.numpy(), qw.numpy(), qz.numpy(), s.numpy(), 128, bias.numpy())
+    dq, ds, dz, db, dx = qw.cuda(), s.cuda(), qz.cuda(), bias.cuda(), x.cuda()
+    takes = not (M > 32 and N > 16384)
+    y = ops.gemm_forward(dx, dq, ds, dz, db)
+    assert ops.last_kernel() == ("gemm_skinny" if takes else "gemm_tiled")
+    assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"auto {K}x{N} M{M}")
+    ran = 0
+    for sk in (0, 2, 4, 8):
+        fl = ops.gemm_flags(ops.KERNEL_SKINNY, splitk=sk)
+        try:
+            y = ops.gemm_forward(dx, dq, ds, dz, db, flags=fl)
+        except Exception as e:
+            assert "code -3" in str(e), e
+            assert not takes or sk in (2, 8), f"split {sk} refused at {K}x{N} M{M}"  # (2 < the four reducers above 32 rows; 8 x exchange)
+            continue
+        assert takes
+        ran += 1
+        assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"skinny {K}x{N} M{M} s{sk}")
+        assert torch.equal(y, ops.gemm_forward(dx, dq, ds, dz, db, flags=fl))
+    assert ran >= (2 if takes else 0)
+    ops.check_workspaces()
+    assert ops.workspace_is_clean(dx.device)
+    W = ops.dequantize_weights(dq, ds, dz)
+    e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    ks = (torch.arange(M, device="cuda") * 61 + 17) % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    assert torch.equal(ops.gemm_forward(e, dq, ds, dz), W[ks]), "one-hot rows must select rows of W"
+
+
+# ------------------------------------------------------------------ config 4: Llama-3-70B, TP = 8 shards and unsharded
+
+@pytest.mark.parametrize("K,N,what", [(8192, 1280, "qkv shard"), (1024, 8192, "o shard"), (8192, 7168, "gate|up shard"),
+                                      (3584, 8192, "down shard"), (8192, 10240, "qkv unsharded"), (28672, 8192, "down unsharded")])
+@pytest.mark.parametrize("M", [1, 8])
+def test_config4_shapes_vs_oracle(ops, oracle, K, N, M, what):
+    """BASELINE configs[3] (Llama-3-70B, TP = 8): the per-rank shard shapes tools/bench_tp_shards.py times and the unsharded
+    projections, GEMM layout AUTO + the GEMV layout's two kernels, against the oracle."""
+    from autoawq_amd.utils.convert import pack_linear
+
+    qw, qz, s, x, bias = fullrange_case(K, N, 128, M, seed=K + 3 * N + M, realistic=True)
+    y32, _ = oracle.linear_gemm(x.numpy(), qw.numpy(), qz.numpy(), s.numpy(), 128, None)
+    dq, ds, dz, dx = qw.cuda(), s.cuda(), qz.cuda(), x.cuda()
+    W = oracle.dequant_gemm(qw.numpy(), qz.numpy(), s.numpy(), 128)
+    wsig = oracle.weight_rounding_sigma(x.numpy(), W)
+    y = ops.gemm_forward(dx, dq, ds, dz)
+    assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemm layout {what} M{M} ({ops.last_kernel()})", wsigma=wsig)
+    # the same integers in the GEMV layout (repacked on the device, bit-exact: tests/test_checkpoint.py pins the converter)
+    from autoawq_amd import WQLinear_GEMM
+    from autoawq_amd.utils.convert import convert_linear
+
+    mg = WQLinear_GEMM(4, 128, K, N, False, "cuda")
+    mg.qweight, mg.qzeros, mg.scales = dq, dz, ds
+    mv = convert_linear(mg, "gemv")
+    Wt = ops.dequantize_weights_gemv(mv.qweight, mv.scales, mv.qzeros, 128)
+    assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
+    for flags, name in ((0, "auto"), (ops.gemm_flags(kernel=1), "tile16"), (ops.gemm_flags(kernel=2), "rows")):
+        try:
+            yv = ops.gemv_forward(dx, mv.qweight, mv.scales, mv.qzeros, 128, flags=flags)
+        except Exception as e:
+            assert name == "rows" and M > 4 and "code -3" in str(e), e
+            continue
+        assert_product_close(yv.cpu().numpy().astype(np.float64), y32, f"gemv layout {name} {what} M{M} ({ops.last_kernel()})", wsigma=wsig)
+
+
+# ------------------------------------------------------------------ the fused 7B widths on the GEMV / GEMVFast layouts
+
+@pytest.mark.parametrize("N", [12288, 22016])
+@pytest.mark.parametrize("M", [1, 8])
+def test_gemv_and_gemvfast_layouts_at_fused_widths(ops, oracle, N, M):
+    """4096 -> 12288 (q|k|v) and 4096 -> 22016 (gate|up): the widths bench.py --layout gemv / gemvfast times."""
+    from test_gpu_parity import gemv_case, gemvfast_case
+
+    K, g = 4096, 128
+    qw, qz, sc, x = gemv_case(K, N, g, M, seed=N + M)
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+    y32, _ = oracle.matmul(x.numpy(), W)
+    wsig = oracle.weight_rounding_sigma(x.numpy(), W)
+    for flags in (0, ops.gemm_flags(kernel=1)):
+        y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=flags)
+        assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemv {K}x{N} M{M} ({ops.last_kernel()})", wsigma=wsig)
+    qf, sf, zf, xf = gemvfast_case(K, N, g, M, seed=N + 2 * M)
+    Wf = oracle.dequant_gemvfast(qf.numpy(), sf.numpy(), zf.numpy(), g)
+    yf32, _ = oracle.matmul(xf.numpy(), Wf)
+    y = ops.gemv_fast_forward(xf.cuda(), qf.cuda(), sf.cuda(), zf.cuda(), g)
+    assert_product_close(y.cpu().numpy().astype(np.float64), yf32, f"gemvfast {K}x{N} M{M}", wsigma=oracle.weight_rounding_sigma(xf.numpy(), Wf))
+
+
 # ------------------------------------------------------------------ config 5: Mixtral-8x7B MoE block, bs = 4, top-2
 
 def _rand_gemm_module(K, N, g, gen):
