@@ -28,6 +28,11 @@ class AwqGemmEx(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol include/awq_hip.h declares
 # (tests/test_boundary.py cross-checks this table against the header and the .so).
 SIGNATURES = {
+    "awq_allreduce_staging_bytes": (c_size_t, [c_int64]),
+    "awq_allreduce_flag_bytes": (c_size_t, []),
+    "awq_allreduce_state_bytes": (c_size_t, []),
+    "awq_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "awq_allreduce_oneshot_group": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "awq_hip_abi_version": (c_int, []),
     "awq_hip_error_string": (ctypes.c_char_p, [c_int]),
     "awq_hip_last_kernel": (ctypes.c_char_p, []),

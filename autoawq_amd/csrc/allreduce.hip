@@ -1,0 +1,149 @@
+// allreduce.hip -- one-shot small-message all-reduce for tensor-parallel decode, gfx950 / xGMI.
+//
+// The reference has no distributed code; north_star asks for "RCCL all-reduce over xGMI only where the model
+// needs TP", SURVEY.md 8(e) plans this one-shot form for the [M, hidden] fp16 outputs of the row-parallel o / down
+// projections (8 KiB at batch 1 for a 7B model, 16 KiB for 70B): at that size a ring collective is pure latency
+// (2 (P - 1) hops), and -- what matters for bench.py --gpus N -- the whole decode step must stay inside ONE hipGraph.
+//
+// Protocol (one launch per rank, no host involvement, hipGraph-replayable):
+//   every rank owns a staging buffer and a flag block that all peers have mapped (P2P / IPC; the caller passes the P
+//   pointers of each -- in a single-GPU test they are simply P local allocations).  Epoch e = launches so far + 1, kept on
+//   the device; parity e & 1 selects one of two staging / flag halves.  Block b of rank r
+//     1. copies its slice of the input into its own staging half (write-through, system scope),
+//     2. fences, then stores e into flag [e & 1][b][r] of EVERY peer (one xGMI store each),
+//     3. spins (bounded) until its own flags [e & 1][b][0 .. P-1] all read e,
+//     4. reads the slice from every peer's staging half (system-scope loads over xGMI), adds the P vectors in rank order
+//        in fp32 -- every rank computes the bitwise identical sum -- rounds once and writes the output.
+//   No second barrier: a rank overwrites staging half e & 1 at epoch e + 2 only after passing the wait of epoch e + 1, and a
+//   peer raises its flag for e + 1 only after it has finished reading at epoch e.  Blocks are independent (per-block flags),
+//   so nothing needs all blocks of a launch to be resident.
+//
+// Cost model: one xGMI store + one dependent poll (~1-2 us) + P remote reads of n / blocks bytes; the P - 1 links of a GPU
+// are driven in parallel (xGMI is point to point), each carrying n bytes once.
+#include "awq_device.h"
+#include "awq_internal.h"
+
+namespace {
+
+struct ArParams {
+    const unsigned long long* peer_data[AWQ_AR_MAX_RANKS];  // staging of rank p: [2][n_max] fp16 as 8-byte words
+    uint32_t* peer_flags[AWQ_AR_MAX_RANKS];                 // flags of rank p: [2][AWQ_AR_BLOCKS][AWQ_AR_MAX_RANKS]
+    // blockIdx.y selects the rank this block acts for: one entry (the product: one process per GPU), or all `world` of them
+    // in ONE launch (awq_allreduce_oneshot_group: every rank of a single-process group, guaranteed co-resident)
+    const uint16_t* in[AWQ_AR_MAX_RANKS];
+    uint16_t* out[AWQ_AR_MAX_RANKS];
+    uint32_t* state[AWQ_AR_MAX_RANKS];  // per rank: [0] epoch, [1] sticky error, [2] blocks done
+    long long n;      // halfs (multiple of 4)
+    long long n_max;  // halfs per staging half
+    int rank0, world;
+    uint32_t max_spin;
+};
+
+AWQ_DEV void st_sys_u64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+AWQ_DEV unsigned long long ld_sys_u64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void awq_allreduce_oneshot_kernel(ArParams p) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int rank = p.rank0 + blockIdx.y;
+    uint32_t* const state = p.state[blockIdx.y];
+    const uint32_t e = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int par = (int)(e & 1u);
+    const long long words = p.n / 4, per = (words + gridDim.x - 1) / gridDim.x;
+    const long long w0 = (long long)b * per, w1 = w0 + per < words ? w0 + per : words;
+    const long long half_words = p.n_max / 4;
+
+    // 1. my slice -> my staging half
+    unsigned long long* mine = const_cast<unsigned long long*>(p.peer_data[rank]) + par * half_words;
+    const unsigned long long* in64 = reinterpret_cast<const unsigned long long*>(p.in[blockIdx.y]);
+    for (long long w = w0 + tid; w < w1; w += 256) st_sys_u64(mine + w, in64[w]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: my stores are visible before my flag
+    __syncthreads();
+    // 2. tell everybody
+    if (tid < p.world)
+        __hip_atomic_store(p.peer_flags[tid] + ((par * AWQ_AR_BLOCKS + b) * AWQ_AR_MAX_RANKS + rank), e, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    // 3. wait for everybody (bounded)
+    if (tid < p.world) {
+        const uint32_t* f = p.peer_flags[rank] + ((par * AWQ_AR_BLOCKS + b) * AWQ_AR_MAX_RANKS + tid);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > p.max_spin) {
+                __hip_atomic_store(state + 1, 1u + (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    // 4. gather + add in rank order (fp32), one rounding
+    for (long long w = w0 + tid; w < w1; w += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int r = 0; r < p.world; ++r) {
+            const unsigned long long v = ld_sys_u64(p.peer_data[r] + par * half_words + w);
+            const half2_t lo = u2h2((uint32_t)v), hi = u2h2((uint32_t)(v >> 32));
+            a0 += (float)lo[0]; a1 += (float)lo[1]; a2 += (float)hi[0]; a3 += (float)hi[1];
+        }
+        const half2_t lo = {(half_t)a0, (half_t)a1}, hi = {(half_t)a2, (half_t)a3};
+        reinterpret_cast<unsigned long long*>(p.out[blockIdx.y])[w] = (unsigned long long)h22u(lo) | ((unsigned long long)h22u(hi) << 32);
+    }
+    // the last block of the launch closes the epoch
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(state + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done + 1u == gridDim.x) {
+            __hip_atomic_store(state + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace
+
+size_t awq_allreduce_staging_bytes(int64_t max_halfs) { return max_halfs > 0 ? (size_t)2 * ((max_halfs + 3) / 4 * 4) * 2 : 0; }
+size_t awq_allreduce_flag_bytes(void) { return (size_t)2 * AWQ_AR_BLOCKS * AWQ_AR_MAX_RANKS * sizeof(uint32_t); }
+size_t awq_allreduce_state_bytes(void) { return 4 * sizeof(uint32_t); }
+
+namespace {
+int launch_allreduce(const void* const* peer_staging, void* const* peer_flags, int rank0, int nranks, int64_t world,
+                     const uint16_t* const* ins, uint16_t* const* outs, int64_t n_halfs, int64_t max_halfs, void* const* states,
+                     void* stream) {
+    if (world < 1 || world > AWQ_AR_MAX_RANKS || rank0 < 0 || rank0 + nranks > world || n_halfs < 0 || n_halfs > max_halfs || n_halfs % 4)
+        return AWQ_ERR_BAD_SHAPE;
+    if (n_halfs == 0) return AWQ_OK;
+    if (!peer_staging || !peer_flags || !ins || !outs || !states) return AWQ_ERR_NULL;
+    ArParams p;
+    for (int r = 0; r < AWQ_AR_MAX_RANKS; ++r) {
+        p.peer_data[r] = r < world ? static_cast<const unsigned long long*>(peer_staging[r]) : nullptr;
+        p.peer_flags[r] = r < world ? static_cast<uint32_t*>(peer_flags[r]) : nullptr;
+        if (r < world && (!p.peer_data[r] || !p.peer_flags[r])) return AWQ_ERR_NULL;
+        if (r < world && (reinterpret_cast<uintptr_t>(peer_staging[r]) & 7)) return AWQ_ERR_BAD_ALIGNMENT;
+        p.in[r] = r < nranks ? ins[r] : nullptr;
+        p.out[r] = r < nranks ? outs[r] : nullptr;
+        p.state[r] = r < nranks ? static_cast<uint32_t*>(states[r]) : nullptr;
+        if (r < nranks && (!p.in[r] || !p.out[r] || !p.state[r])) return AWQ_ERR_NULL;
+        if (r < nranks && ((reinterpret_cast<uintptr_t>(p.in[r]) & 7) || (reinterpret_cast<uintptr_t>(p.out[r]) & 7))) return AWQ_ERR_BAD_ALIGNMENT;
+    }
+    p.n = n_halfs; p.n_max = (max_halfs + 3) / 4 * 4;
+    p.rank0 = rank0; p.world = (int)world;
+    p.max_spin = 1u << 20;  // ~ a second: a peer that never arrives raises the sticky error instead of hanging the GPU
+    int blocks = (int)((n_halfs / 4 + 511) / 512);  // >= 512 8-byte words (4 KiB) per block
+    if (blocks < 1) blocks = 1;
+    if (blocks > AWQ_AR_BLOCKS) blocks = AWQ_AR_BLOCKS;
+    hipLaunchKernelGGL(awq_allreduce_oneshot_kernel, dim3((unsigned)blocks, (unsigned)nranks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+}  // namespace
+
+int awq_allreduce_oneshot(const void* const* peer_staging, void* const* peer_flags, int64_t rank, int64_t world, const uint16_t* in,
+                          uint16_t* out, int64_t n_halfs, int64_t max_halfs, void* state, void* stream) {
+    return launch_allreduce(peer_staging, peer_flags, (int)rank, 1, world, &in, &out, n_halfs, max_halfs, &state, stream);
+}
+
+int awq_allreduce_oneshot_group(const void* const* peer_staging, void* const* peer_flags, int64_t world, const uint16_t* const* ins,
+                                uint16_t* const* outs, int64_t n_halfs, int64_t max_halfs, void* const* states, void* stream) {
+    return launch_allreduce(peer_staging, peer_flags, 0, (int)world, world, ins, outs, n_halfs, max_halfs, states, stream);
+}

@@ -97,8 +97,9 @@ class ExpertParallelSparseMoeBlock(nn.Module):
     """Drop-in for FusedSparseMoeBlock(top_k, gate, ws, w2s) (awq/modules/fused/moe.py:12-42) on `world` ranks:
     keeps experts expert_bounds(E, rank, world) of the stacked modules and all-reduces the block output."""
 
-    def __init__(self, top_k, gate, ws, w2s, rank, world, group=None):
+    def __init__(self, top_k, gate, ws, w2s, rank, world, group=None, collective=None):
         super().__init__()
+        self.collective = collective  # e.g. autoawq_amd.comm.OneShotAllReduce for decode-sized outputs; None: RCCL
         self.top_k, self.gate = top_k, gate
         self.rank, self.world, self.group = rank, world, group
         self.num_experts = ws.qweight.shape[0]
@@ -115,8 +116,14 @@ class ExpertParallelSparseMoeBlock(nn.Module):
         if self.world > 1:
             import torch.distributed as dist
 
-            if dist.is_available() and dist.is_initialized():  # one process per GPU: RCCL over xGMI
+            small = self.collective is not None and out.numel() % 4 == 0 and out.numel() <= getattr(self.collective, "max_halfs", 0)
+            if small and out.dtype == torch.float16 and out.is_contiguous():
+                self.collective(out)  # one-shot xGMI all-reduce (csrc/allreduce.hip)
+            elif dist.is_available() and dist.is_initialized():  # one process per GPU: RCCL over xGMI
                 dist.all_reduce(out, group=self.group)
+            else:  # (single-process tests add the ranks' partial sums themselves: apply_moe_weights_local)
+                raise RuntimeError("ExpertParallelSparseMoeBlock: world > 1 but neither a collective nor an initialised process "
+                                   "group: returning this rank's partial sum would be silently wrong")
         return out.view(batch_size, sequence_length, hidden_dim)
 
 

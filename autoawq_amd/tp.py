@@ -111,8 +111,12 @@ class ColumnParallelWQLinear(nn.Module):
 class RowParallelWQLinear(nn.Module):
     """Holds this rank's input-row slice (whole groups; GEMM or GEMV layout); forward all-reduces the partial sums."""
 
-    def __init__(self, full, rank, world, bounds=None, group=None):
+    def __init__(self, full, rank, world, bounds=None, group=None, collective=None):
+        """collective: a callable summing a contiguous fp16 tensor over the ranks in place -- e.g. an
+        autoawq_amd.comm.OneShotAllReduce (one kernel launch, hipGraph-capturable; decode-sized outputs) -- or None for
+        torch.distributed.all_reduce (RCCL)."""
         super().__init__()
+        self.collective = collective
         g = full.group_size
         if bounds is None:
             s, c = split_even_units(full.in_features // g, world)[rank]
@@ -131,8 +135,14 @@ class RowParallelWQLinear(nn.Module):
         if self.world > 1:
             import torch.distributed as dist
 
-            if dist.is_available() and dist.is_initialized():  # one process per GPU: RCCL over xGMI
+            small = self.collective is not None and y.numel() % 4 == 0 and y.numel() <= getattr(self.collective, "max_halfs", 0)
+            if small and y.dtype == torch.float16 and y.is_contiguous():
+                self.collective(y)  # one-shot xGMI all-reduce (csrc/allreduce.hip)
+            elif dist.is_available() and dist.is_initialized():  # one process per GPU: RCCL over xGMI
                 dist.all_reduce(y, group=self.group)
+            else:
+                raise RuntimeError("RowParallelWQLinear: world > 1 but neither a collective nor an initialised process group: "
+                                   "returning this rank's partial sum would be silently wrong")
         return y
 
 

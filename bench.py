@@ -116,7 +116,8 @@ def build_model(dev, rank, world, layers, seed=1234, layout="gemm", model="7b"):
     return net, shapes
 
 
-def run_step(model, outs, ops, dist):
+def run_step(model, outs, ops, allreduce):
+    """allreduce: None (one GPU), or a callable summing a [1, hidden] fp16 tensor over the ranks in place"""
     i = 0
     for layer in model:
         for lin in layer:
@@ -127,7 +128,7 @@ def run_step(model, outs, ops, dist):
             else:
                 y = ops.gemv_fast_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"], GROUP)
             if lin["reduce"]:
-                dist.all_reduce(y)
+                allreduce(y)
             outs[i] = y
             i += 1
 
@@ -473,24 +474,46 @@ def main():
     if a.layout == "gemvfast":  # zeros are stored as fp16 -(s*z): 2 bytes instead of half a byte per (group, column)
         bytes_step += sum((l["K"] // GROUP) * l["N"] * 3 // 2 for layer in model for l in layer)
 
+    # the TP collective: the one-shot xGMI all-reduce of csrc/allreduce.hip (a plain kernel launch: the whole step stays one
+    # hipGraph); RCCL through torch.distributed if its setup (CUDA-IPC mapping of the peers' buffers) fails
+    allreduce, collective = None, "none"
+    if world > 1:
+        try:
+            from autoawq_amd.comm import OneShotAllReduce
+
+            allreduce = OneShotAllReduce.from_process_group(max_halfs=cfg["hidden"], device=dev)
+            probe = torch.full((1, cfg["hidden"]), float(rank + 1), dtype=torch.float16, device=dev)
+            allreduce(probe)
+            torch.cuda.synchronize()
+            ok = torch.tensor([int(bool((probe == world * (world + 1) / 2).all()) and allreduce.status()[1] == 0)], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) != 1:
+                raise RuntimeError("one-shot all-reduce self-check failed")
+            collective = "one-shot xGMI all-reduce (csrc/allreduce.hip), 8-16 KiB, hipGraph-captured"
+        except Exception as e:
+            allreduce = dist.all_reduce
+            collective = f"RCCL all_reduce via torch.distributed (one-shot setup failed: {type(e).__name__}: {str(e)[:120]})"
+            if rank == 0:
+                print(f"[bench] {collective}", file=sys.stderr)
+
     stream = torch.cuda.Stream(device=dev)
     graph, used_graph, capture_note = None, False, None
     with torch.cuda.stream(stream):
         for _ in range(max(a.warmup, 3) if a.no_graph else 3):
-            run_step(model, outs, ops, dist)
+            run_step(model, outs, ops, allreduce)
         stream.synchronize()
         if not a.no_graph:
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=stream):
-                    run_step(model, outs, ops, dist)
+                    run_step(model, outs, ops, allreduce)
                 used_graph = True
             except Exception as e:  # e.g. collective not capturable: fall back to eager launches, and SAY so
                 capture_note = f"hipGraph capture failed ({type(e).__name__}: {str(e)[:200]}): every launch and all-reduce is issued eagerly"
                 if rank == 0:
                     print(f"[bench] {capture_note}", file=sys.stderr)
                 graph = None
-        step = graph.replay if graph is not None else (lambda: run_step(model, outs, ops, dist))
+        step = graph.replay if graph is not None else (lambda: run_step(model, outs, ops, allreduce))
         for _ in range(a.warmup):
             step()
         stream.synchronize()
@@ -548,7 +571,7 @@ def main():
                        "layout_note": "packed tensors in the reference's WQLinear_" + {"gemm": "GEMM", "gemv": "GEMV", "gemvfast": "GEMVFast"}[a.layout] +
                                       " checkpoint format (awq/modules/linear/); utils/convert.py repacks between the three, bit-exactly",
                        "parallelism": f"tp{world}" if world > 1 else "single",
-                       "collectives_per_step": sum(1 for layer in model for l in layer if l["reduce"]),
+                       "collectives_per_step": sum(1 for layer in model for l in layer if l["reduce"]), "collective": collective,
                        "algorithmic_bytes_per_step_all_ranks": bytes_all, "kernel": ops.last_kernel()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

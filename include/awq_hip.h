@@ -286,6 +286,30 @@ AWQ_EXPORT int awq_decode_attention_rope(const uint16_t* qkv, uint16_t* k_cache,
                                          int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq,
                                          float scale, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- one-shot small-message all-reduce for tensor-parallel decode (no reference counterpart: SURVEY.md 2.3 / 8e) ------
+ * out[i] = sum over ranks of in_r[i], fp16 with fp32 accumulation in rank order (bitwise identical on every rank), for the
+ * [M, hidden] outputs of row-parallel projections (n_halfs % 4 == 0, n_halfs <= max_halfs; <= 64 KiB is what it is built for).
+ * One launch per rank, no host involvement, hipGraph-replayable; see csrc/allreduce.hip for the protocol.
+ * Setup (once): every rank allocates awq_allreduce_staging_bytes(max_halfs) of staging and awq_allreduce_flag_bytes() of
+ * flags -- both ZEROED, both mapped by every peer (hipIpc / P2P) -- and awq_allreduce_state_bytes() of private, zeroed state.
+ * peer_staging[r] / peer_flags[r] are THIS process's addresses of rank r's buffers (entry `rank` = its own); every rank must
+ * pass the same max_halfs and issue the same sequence of calls.  A peer that never arrives raises a sticky error word
+ * (state[1] != 0) after a bounded spin instead of hanging the GPU. */
+#define AWQ_AR_MAX_RANKS 8
+#define AWQ_AR_BLOCKS 16
+AWQ_EXPORT size_t awq_allreduce_staging_bytes(int64_t max_halfs);
+AWQ_EXPORT size_t awq_allreduce_flag_bytes(void);
+AWQ_EXPORT size_t awq_allreduce_state_bytes(void);
+AWQ_EXPORT int awq_allreduce_oneshot(const void* const* peer_staging, void* const* peer_flags, int64_t rank, int64_t world,
+                                     const uint16_t* in, uint16_t* out, int64_t n_halfs, int64_t max_halfs, void* state,
+                                     void* stream);
+/* All `world` ranks of a SINGLE-PROCESS group (every buffer on one device) in ONE launch: ins / outs / states are arrays of
+ * `world` pointers.  Same kernel, same protocol; the ranks are guaranteed co-resident (streams of one process may share a
+ * hardware queue and then serialise).  Used by the single-GPU tests of the protocol and by single-process multi-"rank" setups. */
+AWQ_EXPORT int awq_allreduce_oneshot_group(const void* const* peer_staging, void* const* peer_flags, int64_t world,
+                                           const uint16_t* const* ins, uint16_t* const* outs, int64_t n_halfs,
+                                           int64_t max_halfs, void* const* states, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
