@@ -76,6 +76,11 @@ int awq_launch_gemv_nk(const uint16_t* x, const int32_t* qweight, const uint16_t
 bool awq_gemv_rows_supports(int M, int K, int N, int g);
 int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                          uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st);
+// GEMV layout, 2 <= M <= 16 while the activations fit LDS as MFMA fragments (M K <= 32768; M <= 8 at K = 4096): weights stream
+// through LDS by DMA into v_mfma_f32_16x16x32_f16 (gemv_lds.hip).  ks: waves per tile (1|2|4), depth: pieces in flight; 0 = auto.
+bool awq_gemv_lds_supports(int M, int K, int N, int g);
+int awq_launch_gemv_lds(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
+                        int M, int K, int N, int g, int ZW, int ks, int depth, hipStream_t st);
 int awq_launch_dequant_nk(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out, int K,
                           int N, int g, int ZW, hipStream_t st);
 // Grouped (MoE) GEMM over stacked expert tensors (awq/modules/fused/moe.py:60-89), M = 16-row token blocks.

@@ -354,7 +354,7 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     // AUTO: the row-streaming kernel at batch 1, and at batch 2 while a wave still covers whole rows (K <= 6144); the
     // 16-row MFMA tile kernel otherwise (profiles/r03_gemv_rows_sweep.txt)
     const bool rows_auto = M == 1 || (M == 2 && K <= 6144);
-    if (kern != AWQ_GEMV_KERNEL_TILE16 && (kern == AWQ_GEMV_KERNEL_ROWS || rows_auto) &&
+    if ((kern == AWQ_GEMV_KERNEL_ROWS || (kern == AWQ_GEMV_KERNEL_AUTO && rows_auto)) &&
         awq_gemv_rows_supports((int)M, (int)K, (int)N, (int)group_size)) {
         g_last_kernel = "gemv_rows";
         return awq_launch_gemv_rows(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,
@@ -363,6 +363,16 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
                                     static_cast<hipStream_t>(stream));
     }
     if (kern == AWQ_GEMV_KERNEL_ROWS) return AWQ_ERR_UNSUPPORTED;
+    // AUTO: the LDS-streaming MFMA kernel from five batch rows on matrices of 8192 rows and more (4096 x 11008, M = 8: 11.6 us
+    // vs 19.0 for the tile kernel; 4096 x 22016: 16.7 vs 35.7); below that the tile kernel is level or ahead
+    const bool lds_auto = M >= 5 && N >= 8192;
+    if ((kern == AWQ_GEMV_KERNEL_LDS || (kern == AWQ_GEMV_KERNEL_AUTO && lds_auto)) &&
+        awq_gemv_lds_supports((int)M, (int)K, (int)N, (int)group_size)) {
+        g_last_kernel = "gemv_lds";
+        return awq_launch_gemv_lds(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,
+                                   (int)AWQ_GEMM_FLAG_SPLITK(flags), (int)AWQ_GEMM_FLAG_UNIT(flags), static_cast<hipStream_t>(stream));
+    }
+    if (kern == AWQ_GEMV_KERNEL_LDS) return AWQ_ERR_UNSUPPORTED;
     if (!awq_gemv_nk_supports((int)M, (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
     g_last_kernel = "gemv_nk";
     return awq_launch_gemv_nk(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,

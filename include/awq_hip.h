@@ -160,12 +160,15 @@ AWQ_EXPORT int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweigh
  * awq_gemv_lds_bytes(M, K, ZW) <= 160 KiB (the host wrapper chunks larger M); no bias (the
  * reference adds it afterwards, gemv.py:185).  AUTO: M = 1 (and M = 2 for K <= 6144) takes the row-streaming kernel
  * (gemv_rows.hip: a wave instruction reads 1 KiB of one row, activations in registers, no cross-CU exchange; needs
- * group_size % 128 == 0 and K <= 65536), everything else up to M = 16 the 16-row MFMA tile kernel (gemv_nk.hip).  flags: AWQ_GEMM_FLAG_KERNEL = AWQ_GEMV_KERNEL_*; tuning: _WAVES (waves per
+ * group_size % 128 == 0 and K <= 65536); 5 <= M with N >= 8192 and M K <= 32768 the LDS-streaming MFMA kernel (gemv_lds.hip:
+ * weights by LDS-DMA, 1 KiB of two rows per instruction, into v_mfma_f32_16x16x32_f16); everything else up to M = 16 the 16-row
+ * MFMA tile kernel (gemv_nk.hip).  flags: AWQ_GEMM_FLAG_KERNEL = AWQ_GEMV_KERNEL_*; tuning: _WAVES (waves per
  * block), _UNIT (TILE16: unroll; ROWS: super-units in flight per wave, 1 | 2), _SPLITK (ROWS: blocks per CU), _NLOG (ROWS:
  * 1-KiB slots of a row per wave, 1 | 2 | 3 | 4 | 6 | 8). */
 #define AWQ_GEMV_KERNEL_AUTO 0u
 #define AWQ_GEMV_KERNEL_TILE16 1u /* 16 rows per block through v_mfma_f32_16x16x32_f16, M <= 16 */
-#define AWQ_GEMV_KERNEL_ROWS 2u   /* row-streaming VALU (v_dot2_f32_f16) kernel, M <= 4 */
+#define AWQ_GEMV_KERNEL_ROWS 2u   /* row-streaming kernel (1 KiB of one row per wave instruction, activations in registers), M <= 4 */
+#define AWQ_GEMV_KERNEL_LDS 3u    /* weights through LDS by DMA into MFMA 16x16x32, 2 <= M <= 16 with M K <= 32768; _SPLITK: waves per tile */
 AWQ_EXPORT int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
                                 const int32_t* qzeros, uint16_t* y, int64_t M, int64_t K, int64_t N,
                                 int64_t group_size, int64_t zeros_width, uint32_t flags, void* stream);

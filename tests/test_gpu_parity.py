@@ -506,7 +506,8 @@ def test_gemv_layout_vs_oracle(ops, oracle, K, N, g, M):
     for flags in (0, tile16, tile16 | ops.gemm_flags(waves=4, unit=8), tile16 | ops.gemm_flags(waves=16, unit=4)):
         y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=flags)
         if flags == 0 and (M <= 2 or (M <= 16 and K <= 4096)):  # (wider K: the wrapper splits the batch to fit the tile kernel's LDS)
-            assert ops.last_kernel() == ("gemv_rows" if gemv_rows_takes(M, K, g) else "gemv_nk")
+            lds = g == 128 and 5 <= M <= 16 and N >= 8192 and M * K <= 32768
+            assert ops.last_kernel() == ("gemv_rows" if gemv_rows_takes(M, K, g) else ("gemv_lds" if lds else "gemv_nk"))
         elif flags:
             assert ops.last_kernel() == "gemv_nk"
         assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemv K{K} N{N} g{g} M{M} f{flags:x}", wsigma=wsig)
@@ -564,9 +565,53 @@ def test_gemv_rows_kernel_vs_oracle(ops, oracle, K, N, g):
         e[torch.arange(M, device="cuda"), ks] = 1.0
         assert torch.equal(ops.gemv_forward(e, qwc, scc, qzc, g, flags=rows), Wt.t()[ks]), "one-hot rows must select rows of W"
         assert int(ops.gemv_forward(torch.zeros_like(e), qwc, scc, qzc, g, flags=rows).abs().max()) == 0
-        assert torch.equal(ops.gemv_forward(2 * x.cuda(), qwc, scc, qzc, g, flags=rows).float(),
-                           2 * ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=rows).float()), "f(2x) != 2 f(x)"
+        y1, y2 = ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=rows).float(), ops.gemv_forward(2 * x.cuda(), qwc, scc, qzc, g, flags=rows).float()
+        normal = y1.abs() >= 2.0 ** -13  # (an fp16 SUBNORMAL output is rounded on a coarser grid than its double)
+        assert torch.equal(y2[normal], 2 * y1[normal]), "f(2x) != 2 f(x)"
     assert ran >= (8 if small else 2)
+
+
+@pytest.mark.parametrize("K,N", [(4096, 11008), (4096, 22016), (4096, 4096), (11008, 4096), (8192, 1280), (2048, 4099), (1024, 200), (3584, 8192)])
+@pytest.mark.parametrize("M", [2, 3, 5, 8, 9, 16])
+def test_gemv_lds_kernel_vs_oracle(ops, oracle, K, N, M):
+    """csrc/gemv_lds.hip (GEMV layout, weights through LDS by DMA into MFMA 16x16x32): every batch size and shape its LDS
+    budget admits (M K <= 32768 and the activations' fragment form + the ring fit 160 KB), waves per tile 1 / 2 / 4, the
+    4-wave two-pieces-in-flight variant, ragged N, ragged last piece (K = 11008, 3584), one-hot / zero / 2x properties."""
+    g = 128
+    qw, qz, sc, x = gemv_case(K, N, g, M, seed=K + 11 * N + M)
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+    Wt = ops.dequantize_weights_gemv(qw.cuda(), sc.cuda(), qz.cuda(), g)
+    y32, _ = oracle.matmul(x.numpy(), W)
+    wsig = oracle.weight_rounding_sigma(x.numpy(), W)
+    qwc, qzc, scc = qw.cuda(), qz.cuda(), sc.cuda()
+    lds = ops.gemm_flags(kernel=3)
+    ran = 0
+    for f in (0, ops.gemm_flags(splitk=1), ops.gemm_flags(splitk=2), ops.gemm_flags(splitk=4), ops.gemm_flags(unit=2), ops.gemm_flags(unit=3, splitk=2)):
+        try:
+            y = ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=lds | f)
+        except Exception as e:
+            assert "code -3" in str(e), e
+            continue
+        assert ops.last_kernel() == "gemv_lds"
+        ran += 1
+        assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"lds K{K} N{N} M{M} f{f:x}", wsigma=wsig)
+        assert torch.equal(y, ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=lds | f)), "not bitwise reproducible"
+    takes = M * K <= 32768 and (K + 1023) // 1024 * (32 * (M + 1) * 64 + 1024) + 8 * 9472 + 8192 <= 160 * 1024
+    assert (ran > 0) == takes, (ran, takes)
+    if ran:
+        e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+        ks = (torch.arange(M, device="cuda") * 977 + K - 5) % K
+        e[torch.arange(M, device="cuda"), ks] = 1.0
+        assert torch.equal(ops.gemv_forward(e, qwc, scc, qzc, g, flags=lds), Wt.t()[ks]), "one-hot rows must select rows of W"
+        assert int(ops.gemv_forward(torch.zeros_like(e), qwc, scc, qzc, g, flags=lds).abs().max()) == 0
+        y1, y2 = ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=lds).float(), ops.gemv_forward(2 * x.cuda(), qwc, scc, qzc, g, flags=lds).float()
+        normal = y1.abs() >= 2.0 ** -13  # (an fp16 SUBNORMAL output is rounded on a coarser grid than its double)
+        assert torch.equal(y2[normal], 2 * y1[normal]), "f(2x) != 2 f(x)"
+    # AUTO: this kernel from five rows on wide matrices, else the row-streaming / tile kernels
+    ops.gemv_forward(x.cuda(), qwc, scc, qzc, g)
+    want = "gemv_rows" if gemv_rows_takes(M, K, g) else ("gemv_lds" if (takes and M >= 5 and N >= 8192) else "gemv_nk")
+    if M <= 2 or K <= 4096:
+        assert ops.last_kernel() == want, (ops.last_kernel(), want)
 
 
 def test_gemv_rows_refuses_what_it_cannot_take(ops):

@@ -132,7 +132,7 @@ def audit_inflight_regs(src):
                     if kind2 == "drain":
                         break
                     if kind2 == "wait" and regs2 & dst:
-                        if regs2 != dst:
+                        if not dst <= regs2:  # (a wait may release several request blocks at once: a superset is fine)
                             bad.append((k + 1, f"wait names {sorted(regs2)} but the request at line {start + 1} wrote {sorted(dst)}"))
                         break
                     if kind2 == "request" and regs2 & dst:
