@@ -18,15 +18,14 @@ from torch.autograd import Function
 from ... import ops
 from ...utils.packing import pack_rows_int4, quantize_int_weights_kn
 
-# Dispatch by token count M (measured on MI355X, profiles/r02_regb_by_m.txt, r01_gemm_tiled_vs_two_pass.txt, r01_small_m.txt):
-# M <= 8 decode kernel (csrc/gemv_mfma.hip);  9..64 the batched register-decoded kernel (csrc/gemm_skinny.hip: 14-25 us at
-# 4096x11008);  65..128 fused dequant + MFMA GEMM with split-K (csrc/gemm_tiled.hip: 37 us vs 42-53 us for the two-pass route);  prefill sizes whose 128 x 256 tiles fill the chip: the fused
-# register-decoded kernel (csrc/gemm_regb.hip; 4096x11008: 975 / 1071 / 1140 TF at M = 2048 / 4096 / 8192 vs 600 / 976 / 1043
-# for the two-pass route, 11008x4096: 924 / 1123 / 1162 vs 932 / 1198 / 1267 -- one launch, no 90 MB fp16 copy of W);
-# in between, dequant (bit-exact HIP kernel) + vendor fp16 GEMM, the reference's own large-batch route
-# (awq/modules/linear/gemm.py:48-54, there from 1024 tokens).  PREFILL_IMPL forces a route.
-TWO_PASS_MIN_TOKENS = 129
-PREFILL_IMPL = "auto"  # "auto" | "fused" | "two_pass"
+# Dispatch by token count M (awq_gemm_forward AUTO; measured on MI355X, profiles/r02_regb_by_m.txt, r01_small_m.txt):
+# M <= 8 decode kernel (csrc/gemv_mfma.hip);  9..64 the batched register-decoded kernel (csrc/gemm_skinny.hip);  above that the
+# fused dequant + MFMA GEMM through LDS with split-K (csrc/gemm_tiled.hip) until 128 x 256 tiles give every CU a block, from
+# there the register-decoded prefill kernel (csrc/gemm_regb.hip).  Every forward is a hand-written kernel: the reference's own
+# large-batch route -- dequantise, then a vendor fp16 GEMM (awq/modules/linear/gemm.py:48-54) -- is 5-20 % ahead of the fused
+# kernels between ~256 and ~1024 tokens on some shapes (r02_regb_by_m.txt) and stays available as PREFILL_IMPL = "two_pass"
+# (A/B, and backward uses it), but nothing selects it by default.
+PREFILL_IMPL = "fused"  # "fused" | "two_pass"
 
 
 class WQLinearMMFunction(Function):
@@ -60,13 +59,8 @@ class WQLinearMMFunction(Function):
 
 
 def _linear_forward(x, x2d, qweight, scales, qzeros, bias):
-    M = x2d.shape[0]
-    two_pass = PREFILL_IMPL == "two_pass" or (
-        PREFILL_IMPL == "auto" and M >= TWO_PASS_MIN_TOKENS
-        and ops.auto_kernel(M, x2d.shape[1], qweight.shape[1] * 8, x2d.shape[1] // scales.shape[0]) != ops.KERNEL_REGB)
-    if two_pass and M > 16:
-        W = ops.dequantize_weights(qweight, scales, qzeros)
-        out = torch.matmul(x2d, W)
+    if PREFILL_IMPL == "two_pass" and x2d.shape[0] > 16:  # opt-in A/B route: bit-exact HIP dequant + vendor fp16 GEMM
+        out = torch.mm(x2d, ops.dequantize_weights(qweight, scales, qzeros))
         return out + bias if bias is not None else out
     return ops.gemm_forward(x2d, qweight, scales, qzeros, bias)
 

@@ -19,9 +19,25 @@ from ... import _lib, ops
 from ...utils.packing import (GEMV_ORDER, calculate_zeros_width, pack_rows_int4, pack_zeros_nk,
                               quantize_int_weights_nk)
 
-# above this many rows the matmul goes dequant (HIP, bit exact) + vendor fp16 GEMM instead of
-# ceil(M/16) passes of the decode kernel (the reference switches kernels at 8 rows, gemv.py:168)
-DEQUANT_MATMUL_MIN_ROWS = 65
+# from this many rows a call is prefill-shaped: the fused MFMA GEMM kernels on a cached GEMM-layout repack of the same integers
+# instead of ceil(M/16) passes of the decode kernel (the reference switches kernels at 8 rows, gemv.py:168)
+PREFILL_MIN_ROWS = 65
+
+
+def _gemm_layout_copy(m):
+    """The same integers repacked (bit-exactly, utils/convert.py) into the GEMM layout, built on first use and kept: batches the
+    decode kernels of this layout do not take (prefill) run on the fused MFMA kernels of awq_gemm_forward instead of
+    dequantise + vendor GEMM.  Costs one more int4 copy of the weights (HBM is 288 GB); rebuilt if the buffers are re-assigned."""
+    key = (m.qweight.data_ptr(), m.scales.data_ptr(), m.qzeros.data_ptr())
+    c = m.__dict__.get("_gemm_copy")
+    if c is None or c[0] != key:
+        from ...utils.convert import pack_linear, unpack_linear
+
+        w, z, s, _ = unpack_linear(m)
+        g = pack_linear("gemm", w, z, s, None, m.in_features, m.out_features, m.group_size)
+        c = (key, g.qweight, g.scales, g.qzeros)
+        m.__dict__["_gemm_copy"] = c
+    return c[1], c[2], c[3]
 
 
 class WQLinear_GEMV(nn.Module):
@@ -72,16 +88,15 @@ class WQLinear_GEMV(nn.Module):
         input_dtype = inputs.dtype
         if input_dtype != torch.float16:
             inputs = inputs.half()
-        if inputs.shape[0] >= DEQUANT_MATMUL_MIN_ROWS:
-            Wt = ops.dequantize_weights_gemv(self.qweight, self.scales, self.qzeros, self.group_size)  # [N, K]
-            out = torch.matmul(inputs, Wt.t())
+        if inputs.shape[0] >= PREFILL_MIN_ROWS:
+            out = ops.gemm_forward(inputs, *_gemm_layout_copy(self))
         else:
             try:
                 out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
-            except _lib.AwqHipError as e:  # a shape the decode kernel does not take (K % 128, unusual group sizes): the
-                if e.code != _lib.ERR_UNSUPPORTED:  # dequant kernel + vendor GEMM handle every valid tensor
+            except _lib.AwqHipError as e:  # a shape the decode kernels do not take (K % 128, unusual group sizes): the
+                if e.code != _lib.ERR_UNSUPPORTED:  # GEMM-layout kernels handle every valid tensor
                     raise
-                out = torch.matmul(inputs, ops.dequantize_weights_gemv(self.qweight, self.scales, self.qzeros, self.group_size).t())
+                out = ops.gemm_forward(inputs, *_gemm_layout_copy(self))
         if input_dtype != torch.float16:
             out = out.to(dtype=input_dtype)
         out = out + self.bias if self.bias is not None else out

@@ -9,14 +9,15 @@ Drop-in contract kept (reference gemv_fast.py:68-208):
   * forward needs a 3-D input [batch, tokens, K] (gemv_fast.py:190), bias added afterwards.
 The reference picks its decode kernel for batch < 8 and one token, its prefill GEMM otherwise; here
 the decode kernel (csrc/gemv_fast.hip) serves up to 64 rows in 16-row passes and larger inputs take
-bit-exact dequant + vendor fp16 GEMM.
+the fused MFMA GEMM kernels on a cached, bit-exact GEMM-layout repack of the same integers.
 """
 import torch
 
 from ... import _lib, ops
 from ...utils.packing import calculate_zeros_width, pack_intweight_fast, quantize_int_weights_nk
+from .gemv import _gemm_layout_copy
 
-DEQUANT_MATMUL_MIN_ROWS = 65
+PREFILL_MIN_ROWS = 65
 
 
 class WQLinear_GEMVFast(torch.nn.Module):
@@ -73,16 +74,15 @@ class WQLinear_GEMVFast(torch.nn.Module):
         in_dtype = inputs.dtype
         if in_dtype != torch.float16:
             inputs = inputs.half()
-        if inputs.shape[0] >= DEQUANT_MATMUL_MIN_ROWS or self.out_features % 16:
-            Wt = ops.dequantize_weights_gemv_fast(self.qweight, self.scales, self.qzeros, self.group_size)
-            out = torch.matmul(inputs, Wt.t())
+        if inputs.shape[0] >= PREFILL_MIN_ROWS or self.out_features % 16:
+            out = ops.gemm_forward(inputs, *_gemm_layout_copy(self))
         else:
             try:
                 out = ops.gemv_fast_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
             except _lib.AwqHipError as e:  # a shape the decode kernel does not take (K % 128, unusual group sizes): the
-                if e.code != _lib.ERR_UNSUPPORTED:  # dequant kernel + vendor GEMM handle every valid tensor
+                if e.code != _lib.ERR_UNSUPPORTED:  # GEMM-layout kernels handle every valid tensor
                     raise
-                out = torch.matmul(inputs, ops.dequantize_weights_gemv_fast(self.qweight, self.scales, self.qzeros, self.group_size).t())
+                out = ops.gemm_forward(inputs, *_gemm_layout_copy(self))
         if in_dtype != torch.float16:
             out = out.to(in_dtype)
         out = out.reshape(batch_size, n_tokens, self.out_features)

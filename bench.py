@@ -263,7 +263,8 @@ def leg_gemm_prefill(dev, ops):
             "fused_mfma": {"us": us_f, "kernel": kernel, "roofline": roof(us_f)},
             "fused_lds_tiled_r01": {"us": us_t, "roofline": roof(us_t)}, "two_pass": {"us": us_2, "roofline": roof(us_2)},
             "module": {"us": us_m, "roofline": roof(us_m),
-                       "route": "fused (gemm_regb)" if ops.auto_kernel(M, K, N, GROUP) == ops.KERNEL_REGB else "two_pass (HIP dequant + vendor fp16 GEMM)"},
+                       "route": "fused (awq_gemm_forward AUTO -> " + {ops.KERNEL_REGB: "gemm_regb", ops.KERNEL_TILED: "gemm_tiled"}.get(ops.auto_kernel(M, K, N, GROUP), "other") +
+                                "); the dequant + vendor-GEMM route is opt-in only since round 3 (modules/linear/gemm.py PREFILL_IMPL)"},
             "other_token_counts": by_m,
             "fused_vs_two_pass_max_rel": rel}
 

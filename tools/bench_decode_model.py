@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 H, I, V, HEADS, G = 4096, 11008, 32000, 32, 128
 
 
-def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbose=True, check=True):
+def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbose=True, check=True, layout="gemm"):
     """Returns {context: ms_per_token}.  check: before timing, the logits of the five-launch stream path (norms folded
     into the projections, fused RoPE + append + attention) must agree with the plain module path (separate norm, RoPE /
     append, attention, o_proj, MLP launches) on the same weights and cache."""
@@ -29,6 +29,16 @@ def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbos
     lim = 0x7FFFFFFF
 
     def rand_linear(K, N):
+        if layout == "gemv":  # the reference's WQLinear_GEMV checkpoint format: the decode layout since round 3
+            from autoawq_amd.modules.linear import WQLinear_GEMV
+            from autoawq_amd.utils.packing import calculate_zeros_width
+
+            zw = calculate_zeros_width(K, G)
+            m = WQLinear_GEMV(4, G, K, N, False, dev)
+            m.qweight = torch.randint(-lim - 1, lim, (N, K // 8), dtype=torch.int32, device=dev, generator=gen)
+            m.qzeros = torch.randint(-lim - 1, lim, (N, zw), dtype=torch.int32, device=dev, generator=gen)
+            m.scales = (torch.rand((N, zw * 8), device=dev, generator=gen) * 0.004 + 0.001).half()
+            return m
         m = WQLinear_GEMM(4, G, K, N, False, dev)
         m.qweight = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, device=dev, generator=gen)
         m.qzeros = torch.randint(-lim - 1, lim, (K // G, N // 8), dtype=torch.int32, device=dev, generator=gen)
@@ -117,5 +127,6 @@ if __name__ == "__main__":
     ap.add_argument("--contexts", default="64,512,2048")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--layout", choices=["gemm", "gemv"], default="gemm")
     a = ap.parse_args()
-    run(a.layers, tuple(int(c) for c in a.contexts.split(",")), a.batch, a.steps)
+    run(a.layers, tuple(int(c) for c in a.contexts.split(",")), a.batch, a.steps, layout=a.layout)

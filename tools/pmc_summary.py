@@ -18,6 +18,7 @@ def rows(d):
                 yield r
 
 
+KERNEL = os.environ.get("KERNEL", "awq_gemv_rows_kernel")  # the headline's decode kernel (round 2: awq_gemv_mfma_kernel)
 factor = 2.0
 if len(sys.argv) > 2:
     vals = collections.defaultdict(list)
@@ -31,10 +32,10 @@ shapes = {"qkv 4096->12288": (HIDDEN, 3 * HIDDEN), "o 4096->4096": (HIDDEN, HIDD
           "down 11008->4096": (INTER, HIDDEN)}
 by_grid = collections.defaultdict(list)
 for r in rows(sys.argv[1]):
-    if "awq_gemv_mfma_kernel" in r["Kernel_Name"]:
+    if KERNEL in r["Kernel_Name"]:
         targs = r["Kernel_Name"].split("<")[1].split(">")[0] if "<" in r["Kernel_Name"] else ""
         by_grid[(int(r["Grid_Size"]), int(r["Workgroup_Size"]), targs)].append(float(r["Counter_Value"]))
-print(f"\nbench.py decode kernels (awq_gemv_mfma_kernel), traffic = FETCH_SIZE x {factor:.0f} x 1024 B; by grid size (threads):")
+print(f"\nbench.py decode kernels ({KERNEL}), traffic = FETCH_SIZE x {factor:.0f} x 1024 B; by grid size (threads):")
 tot_t = tot_a = n = 0
 for g, v in sorted(by_grid.items()):
     med = sorted(v)[len(v) // 2] * factor * 1024
