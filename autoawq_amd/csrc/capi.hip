@@ -312,6 +312,18 @@ int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweight, const ui
                              const int32_t* num_tokens_post_padded, const float* pair_weights, int64_t num_pairs,
                              int64_t x_div, int64_t block_rows, int64_t max_blocks, int64_t num_experts, int64_t K,
                              int64_t N, int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
+    return awq_grouped_gemm_forward_ex(x, qweight, scales, qzeros, y, sorted_token_ids, expert_ids, num_tokens_post_padded,
+                                       pair_weights, num_pairs, x_div, block_rows, max_blocks, num_experts, K, N, group_size,
+                                       workspace, workspace_bytes, 0u, stream);
+}
+
+int awq_grouped_gemm_forward_ex(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                                uint16_t* y, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                                const int32_t* num_tokens_post_padded, const float* pair_weights, int64_t num_pairs,
+                                int64_t x_div, int64_t block_rows, int64_t max_blocks, int64_t num_experts, int64_t K,
+                                int64_t N, int64_t group_size, void* workspace, size_t workspace_bytes, uint32_t flags,
+                                void* stream) {
+    if (flags & ~AWQ_GEMM_FLAG_X_GATED_SILU) return AWQ_ERR_UNSUPPORTED;
     int rc = check_gemm_layout(K, N, group_size);
     if (rc) return rc;
     if (!(block_rows == 8 || block_rows == 16)) return AWQ_ERR_BAD_SHAPE;
@@ -326,6 +338,7 @@ int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweight, const ui
     AwqGemmArgs a;
     a.x = x; a.qweight = qweight; a.scales = scales; a.qzeros = qzeros; a.bias = nullptr; a.y = y;
     a.M = (int)block_rows; a.K = (int)K; a.N = (int)N; a.g = (int)group_size;
+    a.x_gated = (flags & AWQ_GEMM_FLAG_X_GATED_SILU) ? 1 : 0;
     a.stream = static_cast<hipStream_t>(stream);
     a.counters = nullptr; a.partial = nullptr; a.partial_floats = 0; a.exchange = nullptr; a.exchange_bytes = 0;
     if (workspace && workspace_bytes > AWQ_WS_COUNTER_BYTES) {  // [control][exchange]: no scratch half here

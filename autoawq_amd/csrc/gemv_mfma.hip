@@ -848,32 +848,45 @@ bool gemv_config(const AwqGemmArgs& a, bool two_pass, GemvCfg& c) {
 }  // namespace
 
 namespace {
-template <int UNIT, bool SEL>
-void launch_moe(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
+template <int UNIT, bool SEL, int XMODE>
+void launch_moe_x(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
     static const bool lds_opt_in = [] {
         (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true>),
+            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true, XMODE>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)lds_opt_in;
-    hipLaunchKernelGGL((awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true, XMODE>), grid, dim3(256), lds, st, p);
+}
+// x_gated: the pair rows are [gate | up] of 2K halves (the w1|w3 output) and silu(gate) * up is applied while the block stages
+// its activations -- the w2 grouped GEMM of a MoE block then needs no separate silu_and_mul launch (moe.py:73-76)
+template <int UNIT, bool SEL>
+void launch_moe(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    if (p.x_gated) launch_moe_x<UNIT, SEL, 1>(p, grid, lds, st);
+    else launch_moe_x<UNIT, SEL, 0>(p, grid, lds, st);
 }
 }  // namespace
 
 // Grouped (MoE) GEMM: `max_blocks` token blocks of a.M (8 or 16) rows, block b multiplies the gathered
 // rows sorted_ids[M*b .. M*b+M-1] with expert expert_ids[b]'s weights; blocks past *num_post_pad exit.
 // 8-row blocks use the selector-row kernel (one MFMA per fragment): the decode case.
+// The block path is the decode-sized one: past 1 GiB of split-K exchange (thousands of token blocks) the launcher refuses
+// and the caller runs its per-expert GEMM path (moe.py PREFILL_MIN_PAIRS sits far below this).
+static const size_t AWQ_GROUPED_MAX_EXCHANGE = (size_t)1 << 30;
+
 size_t awq_grouped_workspace_bytes_impl(int max_blocks, int K, int N) {
     (void)K;
     const size_t tiles = (size_t)(N + 255) / 256;
-    return (size_t)AWQ_WS_COUNTER_BYTES + (size_t)max_blocks * 8 * tiles * 16 * 256 * 4;  // S <= 8
+    size_t need = (size_t)max_blocks * 8 * tiles * 16 * 256 * 4;  // S <= 8
+    if (need > AWQ_GROUPED_MAX_EXCHANGE) need = AWQ_GROUPED_MAX_EXCHANGE;
+    return (size_t)AWQ_WS_COUNTER_BYTES + need;
 }
 
 int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const int* expert_ids, const int* num_post_pad,
                             const float* pair_weights, int num_pairs, int x_div, int max_blocks, int64_t expert_qw_words,
                             int64_t expert_z_words, int64_t expert_s_halfs) {
-    if (!(a.M == 16 || a.M == 8) || max_blocks < 1) return AWQ_ERR_BAD_SHAPE;
+    if (!(a.M == 16 || a.M == 8) || max_blocks < 1 || a.x_gated > 1) return AWQ_ERR_BAD_SHAPE;
     if (!awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2) || a.g % 32) return AWQ_ERR_UNSUPPORTED;
     GemvCfg c{2, 4, 0, 0, 0, 0, 0};
     AwqGemmArgs probe = a;
@@ -904,6 +917,7 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
     }
     if (c.S > 1) {
         const size_t need = (size_t)max_blocks * c.S * tiles * a.M * CW * sizeof(float);
+        if (need > AWQ_GROUPED_MAX_EXCHANGE) return AWQ_ERR_UNSUPPORTED;
         if (!a.exchange || !a.counters || a.exchange_bytes < need) return AWQ_ERR_WORKSPACE;
     }
     GemvMfmaParams p;

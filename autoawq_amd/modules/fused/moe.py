@@ -18,6 +18,7 @@ from ... import ops
 BLOCK_ROWS = 16        # token rows per grouped-GEMM block (moe.py:55: moe_align_block_size(topk_ids, 16, E))
 DECODE_BLOCK_ROWS = 8  # decode-sized batches: 8-row blocks run the selector-row kernel (one MFMA per fragment)
 DECODE_MAX_PAIRS = 64
+FUSE_ACTIVATION_INTO_W2 = True
 
 
 class FusedSparseMoeBlock(torch.nn.Module):
@@ -36,9 +37,48 @@ class FusedSparseMoeBlock(torch.nn.Module):
         return out.view(batch_size, sequence_length, hidden_dim)
 
 
+# From this many (token, expert) pairs an expert sees GEMM-sized batches: one fused GEMM per expert.  Mixtral shape, top-2
+# (tools/dbg_moe_sizes.py): 256 pairs 755 us (blocks) vs 812 us (per expert), 512 pairs 1265 vs 1003 us.
+PREFILL_MIN_PAIRS = 384
+
+
+def _apply_moe_prefill(w1, w2, x, gating_output, topk, renormalize):
+    """Prefill-sized token counts: the pairs are sorted by expert, every expert that was hit runs ITS rows through the fused
+    MFMA GEMM kernels (awq_gemm_forward AUTO: gemm_skinny / gemm_tiled / gemm_regb by row count) for w1|w3 and w2 instead of
+    ceil(rows / 16) passes of the decode kernel, then the routing weight is applied per pair and the top-k slots are summed
+    exactly like the decode path (`[T, topk, H]` fp16, sum over dim 1).  Reads the per-expert row counts back to the host
+    (one synchronisation; prefill is not graph-captured)."""
+    T, H = x.shape
+    E = w1.qweight.shape[0]
+    topk_weights, topk_ids = fused_topk(gating_output, topk, renormalize)
+    flat_e = topk_ids.reshape(-1).long()
+    order = torch.argsort(flat_e, stable=True)
+    counts = torch.bincount(flat_e, minlength=E).cpu().tolist()
+    xs = x.index_select(0, order // topk)                      # [T * topk, H] rows grouped by expert
+    ys = torch.empty_like(xs)
+    off = 0
+    for e, n in enumerate(counts):
+        if n == 0:
+            continue
+        gate_up = ops.gemm_forward(xs[off:off + n], w1.qweight[e], w1.scales[e], w1.qzeros[e])
+        if n <= 16:
+            ys[off:off + n] = ops.gemm_forward(gate_up, w2.qweight[e], w2.scales[e], w2.qzeros[e], flags=ops.X_GATED_SILU)
+        else:
+            ys[off:off + n] = ops.gemm_forward(ops.silu_and_mul(gate_up), w2.qweight[e], w2.scales[e], w2.qzeros[e])
+        off += n
+    w_sorted = topk_weights.reshape(-1).index_select(0, order).to(torch.float32)
+    out = torch.empty((T * topk, H), dtype=torch.float16, device=x.device)
+    out.index_copy_(0, order, (ys.float() * w_sorted[:, None]).half())
+    return out.view(T, topk, H).sum(dim=1)
+
+
 def apply_moe_weights(w1: Dict[str, torch.Tensor], w2: Dict[str, torch.Tensor], x: torch.Tensor,
                       gating_output: torch.Tensor, topk: int, renormalize: bool) -> torch.Tensor:
     num_experts = w1.qweight.shape[0]
+    if x.shape[0] * topk >= PREFILL_MIN_PAIRS and not torch.cuda.is_current_stream_capturing():
+        in_dtype = x.dtype
+        out = _apply_moe_prefill(w1, w2, x.half() if in_dtype != torch.float16 else x, gating_output, topk, renormalize)
+        return out.to(in_dtype) if in_dtype != torch.float16 else out
     rows = DECODE_BLOCK_ROWS if x.shape[0] * topk <= DECODE_MAX_PAIRS else BLOCK_ROWS
     if num_experts <= 64 and topk <= 8 and x.shape[0] <= 1024:  # one-launch routing
         topk_weights, topk_ids, sorted_token_ids, expert_ids, num_tokens_post_padded = ops.moe_route(
@@ -51,10 +91,16 @@ def apply_moe_weights(w1: Dict[str, torch.Tensor], w2: Dict[str, torch.Tensor], 
     xh = xh.view(xh.shape[0], 1, *xh.shape[1:])
     gate_up = ops.grouped_gemm_forward(xh, w1.qweight, w1.scales, w1.qzeros, topk_weights, sorted_token_ids, expert_ids,
                                        num_tokens_post_padded, False, 8, block_rows=rows)
-    out = torch.empty((gate_up.shape[:-1] + (gate_up.shape[-1] // 2,)), dtype=torch.float16, device=x.device)
-    ops.silu_and_mul(gate_up, out)
-    out = ops.grouped_gemm_forward(out, w2.qweight, w2.scales, w2.qzeros, topk_weights, sorted_token_ids, expert_ids,
-                                   num_tokens_post_padded, True, 8, block_rows=rows)
+    if FUSE_ACTIVATION_INTO_W2:
+        # silu(gate) * up is applied by the w2 grouped GEMM while it stages its activations (bit-identical to the separate
+        # awq_silu_and_mul launch of moe.py:73-76): one launch and one [pairs, I] round trip less
+        out = ops.grouped_gemm_forward(gate_up, w2.qweight, w2.scales, w2.qzeros, topk_weights, sorted_token_ids, expert_ids,
+                                       num_tokens_post_padded, True, 8, block_rows=rows, x_gated=True)
+    else:
+        out = torch.empty((gate_up.shape[:-1] + (gate_up.shape[-1] // 2,)), dtype=torch.float16, device=x.device)
+        ops.silu_and_mul(gate_up, out)
+        out = ops.grouped_gemm_forward(out, w2.qweight, w2.scales, w2.qzeros, topk_weights, sorted_token_ids, expert_ids,
+                                       num_tokens_post_padded, True, 8, block_rows=rows)
     out = torch.sum(out, dim=1)
     return out.to(in_dtype) if in_dtype != torch.float16 else out
 

@@ -268,7 +268,7 @@ _moe_workspaces = {}
 
 
 def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_ids, expert_ids,
-                         num_tokens_post_padded, mul_weights, split_k_iters=8, block_rows=16, zero_init=False):
+                         num_tokens_post_padded, mul_weights, split_k_iters=8, block_rows=16, zero_init=False, x_gated=False):
     """awq_ext.grouped_gemm_forward semantics (awq/modules/fused/moe.py:60-89): x [T, 1 | topk, K] fp16,
     stacked GEMM-layout expert tensors [E, ...]; returns [T, topk, N] fp16.  Nothing is read back
     to the host: the routing tensors are consumed on the device.  block_rows = the block size the
@@ -280,13 +280,16 @@ def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_
     G = qzeros.shape[1]
     x = x.contiguous()
     x_div = topk if x.shape[1] == 1 else 1
-    if x.shape[0] * x.shape[1] * x_div != T * topk or x.shape[-1] != K:
+    # x_gated: x holds [gate | up] rows of 2 K halves; silu(gate) * up is applied while the kernel stages its activations
+    if x.shape[0] * x.shape[1] * x_div != T * topk or x.shape[-1] != (2 * K if x_gated else K):
         raise _lib.AwqHipError(f"grouped_gemm_forward: x{tuple(x.shape)} does not match {T} tokens x top-{topk}")
     qweight, scales, qzeros = qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
     sorted_token_ids = sorted_token_ids.contiguous()
     # zero_init: rows of pairs that no block covers (expert-parallel routing places only the local experts' pairs) read as 0
     y = (torch.zeros if zero_init else torch.empty)((T, topk, N), dtype=torch.float16, device=x.device)
-    max_blocks = expert_ids.numel()
+    # expert_ids has the reference's capacity (one entry per pair + E, moe.py:121-123); the blocks that can exist are bounded by
+    # the padded row capacity of sorted_token_ids: that bound sizes the grid and the split-K exchange
+    max_blocks = max(1, min(expert_ids.numel(), sorted_token_ids.numel() // block_rows))
     L = _lib.lib()
     with torch.cuda.device(x.device):
         need = L.awq_grouped_gemm_workspace_bytes(max_blocks, K, N)
@@ -299,11 +302,10 @@ def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_
             _lib.check(L.awq_gemm_workspace_init(_ptr(ws), ws.numel(), _stream()), "awq_gemm_workspace_init")
             _moe_workspaces[key] = ws
         w = topk_weights.contiguous().float() if mul_weights else None
-        rc = L.awq_grouped_gemm_forward(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y),
-                                        _ptr(sorted_token_ids), _ptr(expert_ids), _ptr(num_tokens_post_padded),
-                                        _ptr(w), T * topk, x_div, block_rows, max_blocks, E, K, N, K // G, _ptr(ws),
-                                        ws.numel(),
-                                        _stream())
+        rc = L.awq_grouped_gemm_forward_ex(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y),
+                                           _ptr(sorted_token_ids), _ptr(expert_ids), _ptr(num_tokens_post_padded),
+                                           _ptr(w), T * topk, x_div, block_rows, max_blocks, E, K, N, K // G, _ptr(ws),
+                                           ws.numel(), X_GATED_SILU if x_gated else 0, _stream())
     _lib.check(rc, "awq_grouped_gemm_forward")
     return y
 

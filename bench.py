@@ -269,6 +269,15 @@ def leg_gemm_prefill(dev, ops):
             "fused_vs_two_pass_max_rel": rel}
 
 
+def leg_moe_prefill(dev):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_moe
+
+    r = bench_moe.run_prefill(dev=dev, verbose=False)
+    r["what"] = "Mixtral-8x7B-shape fused MoE MLP at 512 tokens (1024 pairs): one fused MFMA GEMM per expert and projection (modules/fused/moe.py)"
+    return r
+
+
 def leg_moe(dev):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_moe
@@ -601,7 +610,7 @@ def main():
                     ("decode_dependent", lambda: leg_decode_dependent(dev, ops, model, bytes_step)),
                     ("by_layout", lambda: (model.clear(), torch.cuda.empty_cache(), leg_by_layout(dev, ops, layers, a.layout))[2]),
                     ("gemm_bs", lambda: leg_gemm_bs(dev, ops)), ("gemm_prefill", lambda: leg_gemm_prefill(dev, ops)),
-                    ("moe_bs4", lambda: leg_moe(dev))]
+                    ("moe_bs4", lambda: leg_moe(dev)), ("moe_prefill", lambda: leg_moe_prefill(dev))]
             if not a.no_whole_model:
                 legs.append(("whole_model", lambda: (model.clear(), torch.cuda.empty_cache(), leg_whole_model(dev))[2]))
             for name, fn in legs:

@@ -150,6 +150,15 @@ AWQ_EXPORT int awq_grouped_gemm_forward(const uint16_t* x, const int32_t* qweigh
                                         const float* pair_weights, int64_t num_pairs, int64_t x_div,
                                         int64_t block_rows, int64_t max_blocks, int64_t num_experts, int64_t K, int64_t N,
                                         int64_t group_size, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with flags: AWQ_GEMM_FLAG_X_GATED_SILU -- the rows of x are [gate | up] of 2 K halves (the output of the w1|w3
+ * grouped GEMM) and silu(gate) * up is applied while a block stages its activations, bit-identical to awq_silu_and_mul: the
+ * w2 grouped GEMM of apply_moe_weights (awq/modules/fused/moe.py:73-89) then needs no separate activation launch. */
+AWQ_EXPORT int awq_grouped_gemm_forward_ex(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
+                                        const int32_t* qzeros, uint16_t* y, const int32_t* sorted_token_ids,
+                                        const int32_t* expert_ids, const int32_t* num_tokens_post_padded,
+                                        const float* pair_weights, int64_t num_pairs, int64_t x_div,
+                                        int64_t block_rows, int64_t max_blocks, int64_t num_experts, int64_t K, int64_t N,
+                                        int64_t group_size, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* ---- GEMV layout: qweight [N, K/8] i32 (ordinal nibbles), qzeros [N, ZW] i32, scales [N, 8*ZW] f16
  *      (awq/modules/linear/gemv.py:45-69; ZW = calculate_zeros_width, gemv.py:12-24) -------------- */

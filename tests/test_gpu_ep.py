@@ -28,7 +28,14 @@ def test_expert_parallel_ranks_sum_to_the_unsharded_block(E, T, topk, world):
     w1, w2 = _stack(E, H, 2 * I, gen, dev), _stack(E, I, H, gen, dev)
     x = torch.randn((T, H), device=dev, generator=gen).half()
     logits = torch.randn((T, E), device=dev, generator=gen)
-    full = apply_moe_weights(w1, w2, x, logits, topk, True).float()
+    from autoawq_amd.modules.fused import moe as _moe
+
+    saved = _moe.PREFILL_MIN_PAIRS  # like for like: the ranks run the grouped block kernel, so does the unsharded reference
+    _moe.PREFILL_MIN_PAIRS = 1 << 30
+    try:
+        full = apply_moe_weights(w1, w2, x, logits, topk, True).float()
+    finally:
+        _moe.PREFILL_MIN_PAIRS = saved
     total = torch.zeros_like(full)
     covered = 0
     for r in range(world):

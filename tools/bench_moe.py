@@ -85,6 +85,55 @@ def run(dev=None, verbose=True, layers=2, reps=20):
             "checked_against": f"per-(token, expert) awq_gemm_forward calls, max rel diff {rel:.1e}"}
 
 
+def run_prefill(T=512, dev=None, verbose=True, reps=5):
+    """The same block at a prefill-sized token count (T x top-2 = 1024 pairs, ~128 rows per expert): the per-expert fused-GEMM
+    path of apply_moe_weights vs the 16-row-block grouped kernel it replaces there; MFMA TFLOP/s (2 * pairs * (K N) flops of
+    both projections)."""
+    from autoawq_amd.modules.fused import moe
+
+    dev = dev or torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(1)
+    lim = 0x7FFFFFFF
+
+    def experts(K, N):
+        s = Stack()
+        s.qweight = torch.randint(-lim - 1, lim, (E, K, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        s.qzeros = torch.randint(-lim - 1, lim, (E, K // g, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        s.scales = (torch.rand((E, K // g, N), device=dev, generator=gen) * 0.004 + 0.001).half()
+        return s
+
+    w1, w2 = experts(H, 2 * I), experts(I, H)
+    x = torch.randn((T, H), device=dev, generator=gen).half()
+    logits = torch.randn((T, E), device=dev, generator=gen)
+    fl = 2.0 * T * topk * (H * 2 * I + I * H)
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            y = fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps, y
+
+    us_p, yp = timeit(lambda: moe.apply_moe_weights(w1, w2, x, logits, topk, True))
+    saved = moe.PREFILL_MIN_PAIRS
+    try:
+        moe.PREFILL_MIN_PAIRS = 1 << 30
+        us_b, yb = timeit(lambda: moe.apply_moe_weights(w1, w2, x, logits, topk, True))
+    finally:
+        moe.PREFILL_MIN_PAIRS = saved
+    rel = float((yp.float() - yb.float()).abs().max() / yb.float().abs().max())
+    if verbose:
+        print(f"Mixtral-8x7B-shape MoE MLP, T={T}, top-{topk}: per-expert fused GEMMs {us_p:.0f} us ({fl / us_p / 1e6:.0f} TF), "
+              f"16-row-block grouped kernel {us_b:.0f} us ({fl / us_b / 1e6:.0f} TF); max rel diff {rel:.1e}")
+    return {"tokens": T, "per_expert_fused_gemm_us": us_p, "block16_grouped_us": us_b, "flops": fl,
+            "roofline": {"bound": "mfma", "achieved": fl / us_p / 1e6, "peak": 2500.0, "unit": "TFLOP/s", "frac": fl / us_p / 1e6 / 2500.0},
+            "paths_max_rel_diff": rel, "note": "eager timing (the per-expert path reads the row counts back: one host sync per block)"}
+
+
 def run_ep(world, dev=None, layers=2, reps=20, verbose=True):
     """Expert-parallel split of the same block (autoawq_amd/ep.py) with the ranks run one after the other on THIS GPU:
     per-rank time of the local part (routing + the two grouped GEMMs over the owned experts that were hit, without the
@@ -153,6 +202,9 @@ def run_ep(world, dev=None, layers=2, reps=20, verbose=True):
     return {"world": world, "per_rank": per_rank, "busiest_rank_us": worst, "sum_vs_unsharded_max_rel": rel}
 
 
+if __name__ == "__main__" and "--prefill" in sys.argv:
+    run_prefill()
+    sys.exit(0)
 if __name__ == "__main__":
     import argparse
 
