@@ -25,6 +25,14 @@ class AwqGemmEx(ctypes.Structure):
                 ("ssq_in", c_void_p), ("ssq_in_tiles", c_int64), ("add_residual", c_void_p), ("ssq_out", c_void_p)]
 
 
+class AwqGemvEx(ctypes.Structure):
+    """struct AwqGemvEx of include/awq_hip.h (same field order)."""
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("x", c_void_p), ("qweight", c_void_p), ("scales", c_void_p), ("qzeros", c_void_p), ("y", c_void_p),
+                ("M", c_int64), ("K", c_int64), ("N", c_int64), ("group_size", c_int64), ("zeros_width", c_int64),
+                ("stream", c_void_p), ("norm_weight", c_void_p), ("norm_eps", c_float), ("add_residual", c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/awq_hip.h declares
 # (tests/test_boundary.py cross-checks this table against the header and the .so).
 SIGNATURES = {
@@ -59,6 +67,7 @@ SIGNATURES = {
     "awq_grouped_gemm_forward_ex": (c_int, [c_void_p] * 9 + [c_int64] * 8 + [c_void_p, c_size_t, c_uint32, c_void_p]),
     "awq_gemv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                  c_int64, c_uint32, c_void_p]),
+    "awq_gemv_forward_ex": (c_int, [ctypes.POINTER(AwqGemvEx)]),
     "awq_gemv_lds_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "awq_dequantize_weights_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                             c_int64, c_void_p]),

@@ -44,6 +44,23 @@ AWQ_DEV uint32_t and_or(uint32_t a, uint32_t mask, uint32_t magic) {
     return (a & opaque_sgpr(mask)) | opaque_vgpr(magic);
 }
 
+// silu(g) * u in fp32, the arithmetic of awq_silu_and_mul (elementwise.hip): ONE definition for the separate launch and for
+// every kernel that folds the activation into its staging or epilogue.  Contraction is off and every intermediate is pinned
+// in a register (empty asm), so instruction selection cannot fuse across the steps differently from one kernel to the next
+// (observed: 1 output in 10^4 -- the fp32 -> fp16 ties -- off by an fp16 ulp between two kernels with the same source expression).
+AWQ_DEV float awq_silu_mul_f32(float g, float u) {
+#pragma clang fp contract(off)
+    float e = expf(-g);
+    asm("" : "+v"(e));
+    float d = 1.0f + e;
+    asm("" : "+v"(d));
+    float q = g / d;
+    asm("" : "+v"(q));
+    float r = q * u;  // rounded to fp32 HERE: left to the caller's fp16 conversion, the product can become one v_fma_mixlo_f16
+    asm("" : "+v"(r));  // (a single rounding of the exact product), which differs from fp32-then-fp16 on exact ties
+    return r;
+}
+
 // half2(1024 + column 2J, 1024 + column 2J+1) of one packed word
 template <int J>
 AWQ_DEV uint32_t awq_pair_magic(uint32_t q) {

@@ -74,8 +74,15 @@ int awq_launch_gemv_nk(const uint16_t* x, const int32_t* qweight, const uint16_t
 // GEMV layout, row-streaming VALU kernel (gemv_rows.hip), M <= 4: waves per block (<= 8), super-units in flight per wave
 // (1|2), blocks per CU, 1-KiB slots of a row per wave (1|2|3|4|6|8); 0 = auto each.
 bool awq_gemv_rows_supports(int M, int K, int N, int g);
+struct AwqRowsFx {  // decoder-block prologue / epilogue of the row-streaming kernel (batch 1): see awq_gemv_forward_ex
+    const uint16_t* norm_w = nullptr;
+    float norm_eps = 0.f;
+    const uint16_t* res = nullptr;
+    bool pairs = false;
+};
 int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
-                         uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st);
+                         uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st,
+                         const AwqRowsFx* fx = nullptr);
 // GEMV layout, 2 <= M <= 16 while the activations fit LDS as MFMA fragments (M K <= 32768; M <= 8 at K = 4096): weights stream
 // through LDS by DMA into v_mfma_f32_16x16x32_f16 (gemv_lds.hip).  ks: waves per tile (1|2|4), depth: pieces in flight; 0 = auto.
 bool awq_gemv_lds_supports(int M, int K, int N, int g);

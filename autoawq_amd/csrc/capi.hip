@@ -393,6 +393,24 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
                               static_cast<hipStream_t>(stream));
 }
 
+int awq_gemv_forward_ex(const AwqGemvEx* e) {
+    if (!e || e->struct_bytes != sizeof(AwqGemvEx)) return AWQ_ERR_BAD_SHAPE;
+    const int64_t M = e->M, K = e->K, N = e->N, g = e->group_size, ZW = e->zeros_width;
+    if (K <= 0 || N < 0 || g <= 0 || K % g || K % 8 || ZW <= 0 || ZW * 8 < K / g) return AWQ_ERR_BAD_SHAPE;
+    if (M < 0 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX || (e->flags & ~AWQ_GEMV_EX_SILU_PAIRS)) return AWQ_ERR_BAD_SHAPE;
+    const bool pairs = e->flags & AWQ_GEMV_EX_SILU_PAIRS;
+    if (pairs && (e->add_residual || N % 2)) return AWQ_ERR_BAD_SHAPE;
+    if (M == 0 || N == 0) return AWQ_OK;
+    if (!e->x || !e->qweight || !e->scales || !e->qzeros || !e->y) return AWQ_ERR_NULL;
+    if (!aligned16(e->x) || !aligned16(e->qweight) || !aligned16(e->scales) || (e->norm_weight && !aligned16(e->norm_weight)))
+        return AWQ_ERR_BAD_ALIGNMENT;
+    if (M != 1) return AWQ_ERR_UNSUPPORTED;
+    const AwqRowsFx fx{e->norm_weight, e->norm_eps, e->add_residual, pairs};
+    g_last_kernel = "gemv_rows";
+    return awq_launch_gemv_rows(e->x, e->qweight, e->scales, e->qzeros, e->y, (int)M, (int)K, (int)N, (int)g, (int)ZW, 0, 0, 0, 0,
+                                static_cast<hipStream_t>(e->stream), &fx);
+}
+
 size_t awq_gemv_lds_bytes(int64_t M, int64_t K, int64_t zeros_width) {
     return awq_gemv_nk_lds_bytes((int)M, (int)K, (int)zeros_width, 8);
 }

@@ -19,8 +19,7 @@ __global__ __launch_bounds__(256) void awq_silu_and_mul_kernel(const half_t* __r
         half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float x = (float)g[e];
-            o[e] = (half_t)((x / (1.0f + expf(-x))) * (float)u[e]);
+            o[e] = (half_t)awq_silu_mul_f32((float)g[e], (float)u[e]);
         }
         *reinterpret_cast<half8_t*>(out + r * D + 8 * c) = o;
     }

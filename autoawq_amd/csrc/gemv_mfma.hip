@@ -187,8 +187,7 @@ __global__ __launch_bounds__(NWAVES * 64) void awq_gemv_mfma_kernel(GemvMfmaPara
         half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float xv = (float)gt[e];
-            o[e] = (half_t)((xv / (1.0f + expf(-xv))) * (float)uu[e]);
+            o[e] = (half_t)awq_silu_mul_f32((float)gt[e], (float)uu[e]);
         }
         return __builtin_bit_cast(u32x4, o);
     };

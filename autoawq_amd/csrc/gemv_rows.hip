@@ -61,13 +61,21 @@ struct RowsParams {
     int wk, rg;                 // waves side by side on a row, row groups per block (blockDim = (64 * wk, rg))
     int lines_base, lines_rem;  // 128-byte lines per (wave, slot): base (+1 for the first rem of the wk * SL slots)
     int su_total;               // super-units of the matrix: ceil(N / RPU)
-    int su_base, su_rem;        // super-units per row group: base (+1 for the first rem groups)
+    int su_base, su_rem;        // super-units per row group, in units of su_gran: base (+1 for the first rem groups)
     int su_max;                 // most SUs any row group gets
     int x_bytes;                // LDS: activations [MM][4][Cp] x 16 bytes
     int sc_pitch, z_pitch;      // LDS per wave: its rows' scales (whole KiB) and zero words (whole 256 bytes)
     uint32_t g_magic;           // (k * g_magic) >> 32 == k / g
     unsigned long long* trace;  // debug builds only
+    // decoder-block prologue / epilogue (FX template bits; batch 1, whole rows per wave):
+    const half_t* norm_w;       // FX_NORM: x := fp16(x * rsqrt(mean(x^2) + eps) * norm_w), == awq_rmsnorm_kernel's arithmetic
+    float norm_eps;
+    const half_t* res;          // FX_RES: y := fp16(fp16(W x) + res), the two roundings of the unfused add
+    int su_gran;                // super-units are dealt in multiples of this (2: row PAIRS never straddle two waves)
 };
+
+// FX bits of the kernel template
+constexpr int FX_NORM = 1, FX_RES = 2, FX_PAIRS = 4;  // FX_PAIRS: rows (2 i, 2 i + 1) = (gate_i, up_i), y[i] = silu(gate) * up
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -131,8 +139,9 @@ struct QuadSel {
 };
 
 // SL: 1-KiB slots of a row per wave (1, 2, 3, 4, 6, 8); D: super-units in flight per wave (1 | 2); MM: batch rows
-template <int SL, int D, int MM>
+template <int SL, int D, int MM, int FX = 0>
 __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
+    static_assert(FX == 0 || MM == 1, "the block prologue / epilogue is built for batch 1");
     constexpr int RPU = rows_per_su(SL);  // rows per super-unit
     constexpr int R = SL * RPU / 4;       // rounds per super-unit; unit u of an SU = (row u / SL, slot u % SL)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -145,8 +154,8 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #endif
     ROWS_STAMP(0);
     const int gi = blockIdx.x * p.rg + rgi;
-    const int t0 = gi * p.su_base + min(gi, p.su_rem);  // first SU of this wave's row group
-    const int nt = p.su_base + (gi < p.su_rem ? 1 : 0);
+    const int t0 = (gi * p.su_base + min(gi, p.su_rem)) * p.su_gran;  // first SU of this wave's row group
+    const int nt = (p.su_base + (gi < p.su_rem ? 1 : 0)) * p.su_gran;
     const int last_row = p.N - 1;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic segment
     const int sc_off = p.x_bytes + (rgi * p.wk + wki) * (p.sc_pitch + p.z_pitch), z_off = sc_off + p.sc_pitch;
@@ -166,6 +175,15 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
             }
         }
     }
+    if constexpr (FX & FX_NORM) {  // the norm weights travel like one more batch row (plane MM of xs)
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int cb = s * p.wk + wki;
+            const int c = min(cb * 64 + lane, p.C - 1);
+            for (int j = rgi; j < 4; j += p.rg)
+                AWQ_ROWS_DMA16((uint32_t)((32 * c + 8 * j) * 2), p.norm_w, lds0 + (uint32_t)(((MM * 4 + j) * p.Cp + cb * 64) * 16));
+        }
+    }
     // ---- 2. scales and zero words of every row this wave will touch: contiguous in this layout, copied as they are
     if constexpr (!(AWQ_ROWS_DBG & 16)) {
         const int rows_w = max(min((t0 + nt) * RPU, p.N) - t0 * RPU, 0);
@@ -176,6 +194,14 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
         for (int o = 0; o < zd; o += 64) AWQ_ROWS_DMA4(z_src + 4u * (uint32_t)min(o + lane, zd - 1), p.qzeros, lds0 + (uint32_t)(z_off + 4 * o));
     }
 
+    // FX_RES: lane e adds the residual of row e of this wave (at most 64 rows, the launcher checks); requested here, ahead of
+    // the ring, so that it has landed long before the fold (a load issued at the fold would expose its whole round trip)
+    uint32_t resv = 0;
+    if constexpr (FX & FX_RES) {
+        const int nrows = max(min((t0 + nt) * RPU, p.N) - t0 * RPU, 0);
+        const int row = min(t0 * RPU + min(lane, max(nrows - 1, 0)), last_row);
+        asm volatile("global_load_ushort %0, %1, %2" : "=&v"(resv) : "v"((uint32_t)(row * 2)), "s"(p.res) : "memory");
+    }
     // ---- 3. this lane's chunk of a row per slot, then the ring: D super-units of R rounds each
     uint32_t woff[SL];
     int cidx[SL];
@@ -228,7 +254,8 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     const int sc_step = RPU * p.SW * 2, z_step = RPU * p.ZW * 4;
 
     // ---- 5. the DMA pieces have landed (they are older than the ring); the activations are shared by the block
-    if constexpr (!(AWQ_ROWS_DBG & 2) || !(AWQ_ROWS_DBG & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AWQ_ROWS_LPR * R * D) : "memory");
+    if constexpr (FX & FX_RES) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(resv) : "n"(AWQ_ROWS_LPR * R * D) : "memory");
+    else if constexpr (!(AWQ_ROWS_DBG & 2) || !(AWQ_ROWS_DBG & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AWQ_ROWS_LPR * R * D) : "memory");
     if constexpr (!(AWQ_ROWS_DBG & 2)) __builtin_amdgcn_s_barrier();
     ROWS_STAMP(2);
 
@@ -238,6 +265,23 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     float* red = reinterpret_cast<float*>(smem + (size_t)p.x_bytes + (size_t)p.rg * p.wk * (p.sc_pitch + p.z_pitch));
     uint32_t xp[MM][SL][16];
     float c0g[MM][R], sxg[MM][R];
+    float inv = 1.f;
+    if constexpr (FX & FX_NORM) {  // the row statistic: a wave covers the whole row (wk == 1), inactive lanes add nothing
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < SL; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 d = *reinterpret_cast<const u32x4*>(smem + (size_t)((j * p.Cp + cidx[s]) * 16));
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q = dot2(d[i], d[i], q);
+                ss += act[s] ? q : 0.f;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv = rsqrtf(ss / (float)p.K + p.norm_eps);
+    }
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
         float c0s[SL], sxs[SL];
@@ -253,6 +297,17 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x4 d = dj[j];
+                if constexpr (FX & FX_NORM) {
+                    const u32x4 wv = *reinterpret_cast<const u32x4*>(smem + (size_t)(((MM * 4 + j) * p.Cp + cidx[s]) * 16));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const half2_t a = u2h2(d[i]), gw = u2h2(wv[i]);
+                        half2_t o;
+                        o[0] = (half_t)((float)a[0] * inv * (float)gw[0]);  // == awq_rmsnorm_kernel
+                        o[1] = (half_t)((float)a[1] * inv * (float)gw[1]);
+                        d[i] = h22u(o);
+                    }
+                }
                 if (!act[s]) d = u32x4{0u, 0u, 0u, 0u};
                 xp[m][s][4 * j + 0] = __builtin_amdgcn_perm(d[2], d[0], 0x05040100u);  // (x0, x4)  bias 1024
                 xp[m][s][4 * j + 1] = __builtin_amdgcn_perm(d[2], d[0], 0x07060302u);  // (x1, x5)  bias 64
@@ -385,8 +440,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
         if (p.wk == 1) {
             ROWS_STAMP(6);
             const int nrows = min((t0 + nt) * RPU, p.N) - t0 * RPU;
-            for (int e = lane; e < nrows * MM; e += 64) {
-                const int m = MM == 1 ? 0 : e / nrows, j = MM == 1 ? e : e - m * nrows;
+            auto row_sum = [&](int m, int j) {
                 const float4_t* rp = reinterpret_cast<const float4_t*>(red + ((size_t)(m * rows_blk + rgi * p.su_max * RPU + j) * NC) * 4);
                 float sum = 0.f;
 #pragma unroll
@@ -394,7 +448,23 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                     const float4_t v = rp[w];
                     sum += (v[0] + v[1]) + (v[2] + v[3]);
                 }
-                p.y[(int64_t)m * p.N + t0 * RPU + j] = (half_t)sum;
+                return sum;
+            };
+            if constexpr (FX & FX_PAIRS) {  // rows (2 e, 2 e + 1) = (gate, up) of output e: the unfused path's two roundings
+                for (int e = lane; e < (nrows >> 1); e += 64) {
+                    const float gt = (float)(half_t)row_sum(0, 2 * e), up = (float)(half_t)row_sum(0, 2 * e + 1);
+                    p.y[((t0 * RPU) >> 1) + e] = (half_t)awq_silu_mul_f32(gt, up);  // == awq_silu_and_mul_kernel
+                }
+            } else if constexpr (FX & FX_RES) {
+                if (lane < nrows) {
+                    const half_t r = __builtin_bit_cast(half_t, (unsigned short)resv);
+                    p.y[t0 * RPU + lane] = (half_t)((float)(half_t)row_sum(0, lane) + (float)r);
+                }
+            } else {
+                for (int e = lane; e < nrows * MM; e += 64) {
+                    const int m = MM == 1 ? 0 : e / nrows, j = MM == 1 ? e : e - m * nrows;
+                    p.y[(int64_t)m * p.N + t0 * RPU + j] = (half_t)row_sum(m, j);
+                }
             }
         } else {
             __syncthreads();
@@ -402,7 +472,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
             const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
             for (int rgj = 0; rgj < p.rg; ++rgj) {
                 const int gj = blockIdx.x * p.rg + rgj;
-                const int tj0 = gj * p.su_base + min(gj, p.su_rem), ntj = p.su_base + (gj < p.su_rem ? 1 : 0);
+                const int tj0 = (gj * p.su_base + min(gj, p.su_rem)) * p.su_gran, ntj = (p.su_base + (gj < p.su_rem ? 1 : 0)) * p.su_gran;
                 const int nr = min((tj0 + ntj) * RPU, p.N) - tj0 * RPU;
                 for (int e = tid; e < nr * MM; e += nthr) {
                     const int m = MM == 1 ? 0 : e / nr, j = MM == 1 ? e : e - m * nr;
@@ -427,13 +497,26 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #endif
 }
 
-template <int SL, int D, int MM>
+template <int SL, int D, int MM, int FX = 0>
 int launch_rows(const RowsParams& p, int blocks, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemv_rows_kernel<SL, D, MM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemv_rows_kernel<SL, D, MM, FX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((awq_gemv_rows_kernel<SL, D, MM>), dim3((unsigned)blocks), dim3(64 * p.wk, p.rg), lds, st, p);
+    hipLaunchKernelGGL((awq_gemv_rows_kernel<SL, D, MM, FX>), dim3((unsigned)blocks), dim3(64 * p.wk, p.rg), lds, st, p);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+// the decoder-block variants (batch 1): every (SL, D) of the plain kernel x {norm, residual, norm + residual, silu pairs, norm + silu pairs}
+template <int SL, int D>
+int launch_rows_fx(int fx, const RowsParams& p, int blocks, size_t lds, hipStream_t st) {
+    switch (fx) {
+        case FX_NORM: return launch_rows<SL, D, 1, FX_NORM>(p, blocks, lds, st);
+        case FX_RES: return launch_rows<SL, D, 1, FX_RES>(p, blocks, lds, st);
+        case FX_NORM | FX_RES: return launch_rows<SL, D, 1, FX_NORM | FX_RES>(p, blocks, lds, st);
+        case FX_PAIRS: return launch_rows<SL, D, 1, FX_PAIRS>(p, blocks, lds, st);
+        case FX_NORM | FX_PAIRS: return launch_rows<SL, D, 1, FX_NORM | FX_PAIRS>(p, blocks, lds, st);
+        default: return AWQ_ERR_UNSUPPORTED;
+    }
 }
 
 // Slots per wave for a row of `slots` 1-KiB units at batch M: the smallest legal SL (1, 2, 3, 4, 6, 8) that covers the whole
@@ -475,9 +558,15 @@ extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_rows(
 
 // waves: waves per block wanted (0 = auto, <= 8); depth: super-units in flight per wave (1 | 2, 0 = auto);
 // bpc: blocks per CU (0 = auto); sl: slots per wave (0 = auto).
+// fx (decoder-block prologue / epilogue, batch 1 with whole rows per wave, else AWQ_ERR_UNSUPPORTED and the caller runs the
+// separate launches): norm_w != null -> x is RMS-normalised while it is brought into registers; res != null -> y = fp16(fp16(W x)
+// + res); pairs -> rows (2 i, 2 i + 1) are (gate_i, up_i) and y [N / 2] = silu(gate) * up.
 int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
-                         uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st) {
+                         uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st,
+                         const AwqRowsFx* fxa) {
     if (!awq_gemv_rows_supports(M, K, N, g)) return AWQ_ERR_UNSUPPORTED;
+    const int fx = fxa ? (fxa->norm_w ? FX_NORM : 0) | (fxa->res ? FX_RES : 0) | (fxa->pairs ? FX_PAIRS : 0) : 0;
+    if (fx && (M != 1 || ((fx & FX_PAIRS) && ((fx & FX_RES) || N % 2)))) return AWQ_ERR_UNSUPPORTED;
     if ((int64_t)N * K / 2 >= ((int64_t)1 << 32) || (int64_t)N * ZW * 16 >= ((int64_t)1 << 32) || (int64_t)M * K * 2 >= ((int64_t)1 << 31))
         return AWQ_ERR_UNSUPPORTED;  // 32-bit byte offsets
     RowsParams p;
@@ -493,7 +582,7 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     const int SL = pick_sl(slots, M, sl);
     if (SL == 0 || 16 * SL * M > 128) return AWQ_ERR_UNSUPPORTED;
     p.wk = (slots + SL - 1) / SL;
-    if (p.wk > 8) return AWQ_ERR_UNSUPPORTED;
+    if (p.wk > 8 || (fx && p.wk != 1)) return AWQ_ERR_UNSUPPORTED;
     p.Cp = p.wk * SL * 64;
     // Defaults from the sweeps (profiles/r03_gemv_rows_sweep.txt): four waves per block and one block per CU start fastest
     // (1024 waves: the dispatch ramp and the per-block copy of x are what a short launch pays for); long streams take two.
@@ -506,14 +595,20 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     if (!awq_magic_u32((uint32_t)g, (uint32_t)K + 32u, &p.g_magic)) return AWQ_ERR_UNSUPPORTED;
     const int RPU = rows_per_su(SL);
     p.su_total = (N + RPU - 1) / RPU;
+    p.su_gran = (fx & FX_PAIRS) && RPU == 1 ? 2 : 1;  // a (gate, up) row pair stays with one wave
+    const int su_units = p.su_total / p.su_gran;      // N is even with pairs
     if (bpc <= 0) bpc = p.su_total > 8 * 256 * p.rg ? 2 : 1;
     int blocks = 256 * bpc;
-    const int max_blocks = (p.su_total + p.rg - 1) / p.rg;  // at least one SU per row group
+    const int max_blocks = (su_units + p.rg - 1) / p.rg;  // at least one SU per row group
     if (blocks > max_blocks) blocks = max_blocks;
     const int groups = blocks * p.rg;
-    p.su_base = p.su_total / groups;
-    p.su_rem = p.su_total % groups;
-    p.su_max = p.su_base + (p.su_rem ? 1 : 0);
+    p.su_base = su_units / groups;
+    p.su_rem = su_units % groups;
+    p.su_max = (p.su_base + (p.su_rem ? 1 : 0)) * p.su_gran;
+    if ((fx & FX_RES) && p.su_max * RPU > 64) return AWQ_ERR_UNSUPPORTED;  // one residual element per lane
+    p.norm_w = fxa ? reinterpret_cast<const half_t*>(fxa->norm_w) : nullptr;
+    p.norm_eps = fxa ? fxa->norm_eps : 0.f;
+    p.res = fxa ? reinterpret_cast<const half_t*>(fxa->res) : nullptr;
     const bool one_round = SL * RPU == 4;
     if (depth < 1 || depth > 2) depth = p.su_max >= 2 && p.su_max <= 8 && bpc == 1 && one_round ? 2 : 1;
     if (!one_round || (SL == 4 && M > 1) || (SL == 2 && M > 3)) depth = 1;  // instantiated combinations (register budget)
@@ -521,14 +616,19 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_rows_trace;
 #endif
-    p.x_bytes = M * 4 * p.Cp * 16;
+    p.x_bytes = (M + ((fx & FX_NORM) ? 1 : 0)) * 4 * p.Cp * 16;
     p.sc_pitch = (p.su_max * RPU * p.SW * 2 + 1023) / 1024 * 1024;
     p.z_pitch = (p.su_max * RPU * p.ZW * 4 + 255) / 256 * 256;
     const size_t lds = (size_t)p.x_bytes + (size_t)p.rg * p.wk * (p.sc_pitch + p.z_pitch) +
                        (size_t)M * p.su_max * p.rg * RPU * p.wk * SL * 4 * sizeof(float);
     if (lds > 160 * 1024) return AWQ_ERR_UNSUPPORTED;
-#define AWQ_ROWS_CASE(SLV, DV, MV) \
-    if (SL == SLV && depth == DV && M == MV) return launch_rows<SLV, DV, MV>(p, blocks, lds, st);
+#define AWQ_ROWS_CASE(SLV, DV, MV)                                                        \
+    if (SL == SLV && depth == DV && M == MV) {                                            \
+        if constexpr (MV == 1) {                                                          \
+            if (fx) return launch_rows_fx<SLV, DV>(fx, p, blocks, lds, st);               \
+        }                                                                                 \
+        return launch_rows<SLV, DV, MV>(p, blocks, lds, st);                              \
+    }
     AWQ_ROWS_CASE(1, 1, 1) AWQ_ROWS_CASE(1, 1, 2) AWQ_ROWS_CASE(1, 1, 3) AWQ_ROWS_CASE(1, 1, 4)
     AWQ_ROWS_CASE(1, 2, 1) AWQ_ROWS_CASE(1, 2, 2) AWQ_ROWS_CASE(1, 2, 3) AWQ_ROWS_CASE(1, 2, 4)
     AWQ_ROWS_CASE(2, 1, 1) AWQ_ROWS_CASE(2, 1, 2) AWQ_ROWS_CASE(2, 1, 3) AWQ_ROWS_CASE(2, 1, 4)

@@ -27,8 +27,19 @@ class FusedCausalLM(nn.Module):
         return self.lm_head(self.model(input_ids).last_hidden_state)
 
 
-def fuse_llama(hf_model, max_seq_len=2048):
+def fuse_llama(hf_model, max_seq_len=2048, decode_layout=None):
+    """decode_layout="gemv": the quantized Linears are repacked (same integers, bit-exact) into the WQLinear_GEMV layout
+    before fusing -- the layout the reference itself recommends for batch 1 (README.md:96-97) and the one the row-streaming
+    decode kernel reads; prefill-sized calls run the fused MFMA GEMM kernels on a cached GEMM-layout copy.  A declared
+    option like the reference's ExLlama repack at load time (awq/modules/linear/exllama.py:66-79); None keeps the
+    checkpoint's layout."""
     cfg = hf_model.config
+    if decode_layout is not None:
+        from .utils.convert import convert_model
+
+        if decode_layout.lower() != "gemv":
+            raise ValueError("fuse_llama: decode_layout must be None or 'gemv'")
+        convert_model(hf_model.model, "gemv")
     blocks = []
     for layer in hf_model.model.layers:
         dev = next(iter(layer.state_dict().values())).device

@@ -49,6 +49,36 @@ class LlamaLikeBlock(nn.Module):
                 and isinstance(self.attn.qkv_proj, WQLinear_GEMM) and isinstance(self.mlp, QuantFusedMLP)
                 and not self.mlp.gemv_layout and self.attn.qkv_proj.in_features % 32 == 0)
 
+    def _can_fold_gemv(self, h):
+        """GEMV-layout decode (one row): the four projections run the row-streaming kernel with the block's norm, residual add
+        and silu * mul in their prologue / epilogue (ops.gemv_forward_ex)."""
+        from ..linear.gemv import WQLinear_GEMV
+        from .mlp import QuantFusedMLP
+
+        if getattr(self, "_gemv_fold_refused", False) or not self.FOLD_NORMS_INTO_PROJECTIONS:
+            return False
+        a, m = self.attn, self.mlp
+        if not (h.numel() == h.shape[-1] and h.dtype == torch.float16 and isinstance(m, QuantFusedMLP) and m.gemv_layout
+                and m.activation is torch.nn.functional.silu
+                and all(isinstance(l, WQLinear_GEMV) and l.bias is None for l in (a.qkv_proj, a.o_proj, m.down_proj))):
+            return False
+        # what awq_gemv_forward_ex takes (include/awq_hip.h): a wave covers whole rows (K <= 16384), groups of 128 k, and with a
+        # residual at most 64 rows per wave; every projection of the block must qualify, or the block runs the separate launches
+        return all(l.in_features <= 16384 and l.group_size % 128 == 0 and l.out_features <= 65536 and l.in_features >= 128
+                   for l in (a.qkv_proj, a.o_proj, m.down_proj)) and 2 * m.intermediate_size <= 131072
+
+    def _forward_stream_gemv(self, h):
+        B, S, H = h.shape
+        q, o, d, n1, n2 = self.attn.qkv_proj, self.attn.o_proj, self.mlp.down_proj, self.norm_1, self.norm_2
+        h0 = h.reshape(1, H)
+        xqkv = ops.gemv_forward_ex(h0, q.qweight, q.scales, q.qzeros, q.group_size, norm_weight=n1.weight, norm_eps=n1.variance_epsilon)
+        heads, _, _ = self.attn.forward_qkv(xqkv.reshape(B, S, -1), apply_o_proj=False)
+        h1 = ops.gemv_forward_ex(heads.reshape(1, -1), o.qweight, o.scales, o.qzeros, o.group_size, add_residual=h0)
+        pw, ps, pz = self.mlp.gate_up_pairs()
+        act = ops.gemv_forward_ex(h1, pw, ps, pz, self.mlp.group_size, norm_weight=n2.weight, norm_eps=n2.variance_epsilon, silu_pairs=True)
+        h2 = ops.gemv_forward_ex(act, d.qweight, d.scales, d.qzeros, d.group_size, add_residual=h1)
+        return h2.reshape(B, S, H)
+
     def forward_stream(self, x, h, ssq=None):
         """Residual stream kept by the caller (LlamaLikeModel): `h` is the stream, `x` a previous MLP output
         that has not been added yet (or None), `ssq` the per-tile sums of squares of `h` if the projection
@@ -56,6 +86,18 @@ class LlamaLikeBlock(nn.Module):
         into its staging), attention (RoPE + cache append inside), o_proj (residual add + sums of squares in
         its epilogue), gate|up (norm from those sums), down (silu*mul while staging, residual add + sums of
         squares for the next block).  Returns (pending x | None, stream, ssq | None)."""
+        if self._can_fold_gemv(h):
+            # FIVE launches on the GEMV layout as well: qkv (norm in its prologue), attention, o_proj (+ residual), gate|up
+            # (norm in, silu * mul out), down (+ residual)
+            from ..._lib import AwqHipError
+
+            start = self.attn.start_pos
+            try:
+                return None, self._forward_stream_gemv(h if x is None else h + x), None
+            except AwqHipError as e:  # a shape the row-streaming kernel does not take (K > 16384, group size < 128): separate launches
+                if getattr(e, "code", 0) != -3 or self.attn.start_pos != start:
+                    raise
+                self._gemv_fold_refused = True
         if self._can_fold(h):
             B, S, H = h.shape
             q, o, d = self.attn.qkv_proj, self.attn.o_proj, self.mlp.down_proj

@@ -30,6 +30,7 @@ class QuantFusedMLP(nn.Module):
         self.group_size = down_proj.group_size
         self.activation = activation
         self._fused = None
+        self._pairs = None
         self._adopt(gate_proj.qweight, gate_proj.scales, gate_proj.qzeros, up_proj.qweight, up_proj.scales, up_proj.qzeros)
 
     def _adopt(self, gq, gs, gz, uq, us, uz):
@@ -37,6 +38,7 @@ class QuantFusedMLP(nn.Module):
         buffers the reference registers (mlp.py:25-32: `gate_proj_qweight` ... `up_proj_qzeros`, the names checkpoints and
         `state_dict()` use) are views into it, so loading into them, or reading them, touches the same memory."""
         dim = 0 if self.gemv_layout else 1  # GEMV layout stacks output rows, GEMM layout columns
+        self._pairs = None
         fused = tuple(torch.cat([g, u], dim=dim).contiguous() for g, u in ((gq, uq), (gs, us), (gz, uz)))
         self._fused = fused
         for name, f, g in (("qweight", fused[0], gq), ("scales", fused[1], gs), ("qzeros", fused[2], gz)):
@@ -65,6 +67,18 @@ class QuantFusedMLP(nn.Module):
             self._adopt(self.gate_proj_qweight, self.gate_proj_scales, self.gate_proj_qzeros,
                         self.up_proj_qweight, self.up_proj_scales, self.up_proj_qzeros)
         return self._fused
+
+    def gate_up_pairs(self):
+        """GEMV layout, decode: the gate and up rows INTERLEAVED (row 2 i = gate_i, row 2 i + 1 = up_i), the form
+        `ops.gemv_forward_ex(..., silu_pairs=True)` reads -- the wave that finishes a (gate, up) pair writes
+        silu(gate) * up itself, so the [1, 2 I] intermediate and the awq_silu_and_mul launch (mlp.py:64-66) disappear.
+        A second resident copy of the two projections (2 x 23 MB per 7B layer), built at the first decode step from the
+        registered buffers; `_adopt` (a `.to()`, re-assigned buffers) drops it."""
+        if self._pairs is None:
+            qw, sc, qz = self._gate_up_fused()
+            I = self.intermediate_size
+            self._pairs = tuple(torch.stack([t[:I], t[I:]], dim=1).reshape(t.shape).contiguous() for t in (qw, sc, qz))
+        return self._pairs
 
     def forward(self, x, routing_weights=None, gate_up=None):
         """`gate_up` [rows, 2 * intermediate]: the fused gate|up projection already computed by the caller

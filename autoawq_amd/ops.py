@@ -238,6 +238,47 @@ def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     return y
 
 
+GEMV_EX_SILU_PAIRS = 1  # include/awq_hip.h AWQ_GEMV_EX_SILU_PAIRS
+
+
+def gemv_forward_ex(x2d, qweight, scales, qzeros, group_size, norm_weight=None, norm_eps=0.0, add_residual=None,
+                    silu_pairs=False):
+    """GEMV-layout decode projection with the decoder block's prologue / epilogue in the same launch
+    (awq_gemv_forward_ex): norm_weight normalises x on its way into registers; add_residual stores
+    fp16(fp16(W x) + add_residual); silu_pairs: rows (2 i, 2 i + 1) are (gate_i, up_i), returns [1, N / 2] =
+    silu(gate) * up.  Raises AwqHipError with code AWQ_ERR_UNSUPPORTED (-3) for shapes the row-streaming kernel
+    does not take (M > 1, K > 16384): the caller then runs the separate launches."""
+    _require_gpu(x2d, qweight, scales, qzeros, norm_weight, add_residual)
+    if x2d.dtype != torch.float16:
+        raise _lib.AwqHipError("gemv_forward_ex expects fp16 activations")
+    x2d, qweight, scales, qzeros = x2d.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    M, K = x2d.shape
+    N, ZW = qweight.shape[0], qzeros.shape[1]
+    if qweight.shape[1] * 8 != K or scales.shape != (N, ZW * 8):
+        raise _lib.AwqHipError(f"gemv_forward_ex: shape mismatch x{tuple(x2d.shape)} qweight{tuple(qweight.shape)} "
+                               f"qzeros{tuple(qzeros.shape)} scales{tuple(scales.shape)}")
+    n_out = N // 2 if silu_pairs else N
+    y = torch.empty((M, n_out), dtype=torch.float16, device=x2d.device)
+    if add_residual is not None and (add_residual.shape != y.shape or add_residual.dtype != torch.float16
+                                     or not add_residual.is_contiguous()):
+        raise _lib.AwqHipError("gemv_forward_ex: add_residual must be a contiguous fp16 [M, N] tensor")
+    if norm_weight is not None and (norm_weight.dtype != torch.float16 or norm_weight.numel() != K):
+        raise _lib.AwqHipError("gemv_forward_ex: norm_weight must be fp16 [K]")
+    with torch.cuda.device(x2d.device):
+        e = _lib.AwqGemvEx()
+        e.struct_bytes = ctypes.sizeof(_lib.AwqGemvEx)
+        e.flags = GEMV_EX_SILU_PAIRS if silu_pairs else 0
+        e.x, e.qweight, e.scales, e.qzeros, e.y = _ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y)
+        e.M, e.K, e.N, e.group_size, e.zeros_width = M, K, N, group_size, ZW
+        e.stream = _stream()
+        e.norm_weight = _ptr(norm_weight.contiguous()) if norm_weight is not None else None
+        e.norm_eps = float(norm_eps)
+        e.add_residual = _ptr(add_residual)
+        rc = _lib.lib().awq_gemv_forward_ex(ctypes.byref(e))
+    _lib.check(rc, "awq_gemv_forward_ex")
+    return y
+
+
 def dequantize_weights_gemv(qweight, scales, qzeros, group_size):
     """GEMV-layout buffers -> fp16 W^T [N, K] (awq_dequantize_weights_gemv)."""
     _require_gpu(qweight, scales, qzeros)

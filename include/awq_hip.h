@@ -286,6 +286,35 @@ typedef struct AwqGemmEx {
 AWQ_EXPORT int64_t awq_gemm_ex_ssq_tiles(int64_t N);
 AWQ_EXPORT int awq_gemm_forward_ex(const AwqGemmEx* args);
 
+/* The GEMV-layout decode projection (awq_gemv_forward, batch 1) with the decoder block's prologue / epilogue in the same
+ * launch -- what awq/modules/fused/block.py:108-120 runs as norm -> projection -> add / silu * mul launches
+ * (awq_ext.layernorm_forward_cuda norm.py:33-36, awq_ext.gemv_forward_cuda gemv.py:178-180, mlp.py:64-66):
+ *   norm_weight != NULL   x is RMS-normalised while it is brought into registers: fp16(x * rsqrt(mean(x^2) + eps) * w), the
+ *                         arithmetic of awq_rmsnorm_forward (the row statistic is summed in a different order);
+ *   add_residual != NULL  y = fp16(fp16(W x) + add_residual)  [N]  -- the two roundings of `h + proj(x)` in torch;
+ *   AWQ_GEMV_EX_SILU_PAIRS (flags)  rows (2 i, 2 i + 1) of the matrix are (gate_i, up_i) (the caller interleaved the gate and
+ *                         up projections' rows); y [N / 2] = fp16(silu(fp16 gate) * fp16 up), == awq_silu_and_mul on the
+ *                         unfused outputs.  Not together with add_residual.
+ * Served by the row-streaming kernel only: M == 1 and K <= 16384 (a wave covers whole rows), group_size % 128 == 0, and with
+ * add_residual at most 64 rows per wave (N <= 65536); AWQ_ERR_UNSUPPORTED otherwise -- the caller then runs the separate
+ * launches.  Unused fields are 0 / NULL. */
+#define AWQ_GEMV_EX_SILU_PAIRS 1u
+typedef struct AwqGemvEx {
+    uint32_t struct_bytes; /* sizeof(AwqGemvEx) */
+    uint32_t flags;
+    const uint16_t* x;
+    const int32_t* qweight;
+    const uint16_t* scales;
+    const int32_t* qzeros;
+    uint16_t* y;
+    int64_t M, K, N, group_size, zeros_width;
+    void* stream;
+    const uint16_t* norm_weight;
+    float norm_eps;
+    const uint16_t* add_residual;
+} AwqGemvEx;
+AWQ_EXPORT int awq_gemv_forward_ex(const AwqGemvEx* args);
+
 /* awq_rope_kv_append + awq_decode_attention in ONE launch for a decode step (S = 1, full rotary,
  * head_dim = 128): qkv [B, (n_heads + 2*n_kv_heads) * 128] is the fused projection's output; query
  * heads are rotated in registers, the new token's rotated k and its v are used from registers and

@@ -367,3 +367,20 @@ def test_fused_decode_step_replayed_as_one_hipgraph():
         torch.cuda.synchronize()
         assert np.abs(logits.float().cpu().numpy()[:, 0] - ref[:, t]).max() <= 2e-2 * rng, t
     assert int(pos.item()) == 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["gemv", "gemm"])
+def test_five_launch_decode_stack_matches_the_plain_module_path(layout):
+    """tools/bench_decode_model.py on a small stack (2 layers, hidden 512, 4 heads of 128, intermediate 1024): the logits of the
+    five-launch stream path (GEMV layout: awq_gemv_forward_ex with the norm / residual / silu-pairs prologue and epilogue;
+    GEMM layout: awq_gemm_forward_ex) agree with the plain module path (separate norm, RoPE, attention, add and silu launches)
+    on the same weights and cache, and the captured hipGraph replays."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_decode_model
+
+    out = bench_decode_model.run(layers=2, contexts=(8, 40), steps=3, verbose=False, check=True, layout=layout,
+                                 hidden=512, inter=1024, vocab=256, heads=4)
+    assert set(out) == {8, 40} and all(v > 0 for v in out.values())

@@ -571,6 +571,93 @@ def test_gemv_rows_kernel_vs_oracle(ops, oracle, K, N, g):
     assert ran >= (8 if small else 2)
 
 
+# decoder-block prologue / epilogue of the row-streaming kernel (awq_gemv_forward_ex): the 7B block's four projections, the
+# 70B ones (K = 8192: one row per super-unit, so (gate, up) pairs are dealt in twos; 28672 -> 8192 needs two waves per row:
+# refused), ragged sizes
+@pytest.mark.parametrize("K,N,g", [(4096, 12288, 128), (4096, 4096, 128), (4096, 22016, 128), (11008, 4096, 128), (8192, 10240, 128),
+                                   (8192, 57344, 128), (8192, 8192, 128), (2048, 202, 2048), (384, 6, 128), (13824, 5120, 128)])
+def test_gemv_rows_block_fusions_vs_unfused_and_oracle(ops, oracle, K, N, g):
+    """norm prologue, residual epilogue and silu-pairs epilogue against the SEPARATE launches they replace (awq_rmsnorm_forward,
+    awq_gemv_forward, torch add, awq_silu_and_mul) -- bit-identical where the arithmetic is the same operation by operation
+    (residual, silu pairs); the norm's row statistic is summed in a different order, so a few inputs may round differently --
+    and against the CPU oracle end to end."""
+    qw, qz, sc, x4 = gemv_case(K, N, g, 1, seed=3 * K + N)
+    qwc, qzc, scc = qw.cuda(), qz.cuda(), sc.cuda()
+    gen = torch.Generator().manual_seed(K + N)
+    x = x4[:1].contiguous()
+    nw = (torch.rand((K,), generator=gen) + 0.5).half()
+
+    def same_bits(a, b):  # bit for bit, an overflowed output (inf -> NaN through silu) counts as equal to itself
+        return torch.allclose(a.float(), b.float(), rtol=0, atol=0, equal_nan=True)
+
+    res = torch.randn((1, N), generator=gen).half()
+    eps = 1e-5
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+    xc, nwc, resc = x.cuda(), nw.cuda(), res.cuda()
+    rows = ops.gemm_flags(kernel=GEMV_KERNEL_ROWS)
+
+    def oracle_norm(xx):
+        x32 = xx.numpy().astype(np.float32)
+        inv = np.float32(1.0) / np.sqrt(np.mean(x32.astype(np.float64) ** 2, axis=-1, keepdims=True).astype(np.float32) + np.float32(eps))
+        return ((x32 * inv) * nw.numpy().astype(np.float32)).astype(np.float16)
+
+    # ---- plain residual epilogue: fp16(fp16(W x) + res), bit for bit
+    y_plain = ops.gemv_forward(xc, qwc, scc, qzc, g, flags=rows)
+    got = ops.gemv_forward_ex(xc, qwc, scc, qzc, g, add_residual=resc)
+    assert ops.last_kernel() == "gemv_rows"
+    assert same_bits(got, y_plain + resc), "residual epilogue differs from the separate add"
+    # ---- norm prologue
+    xn = ops.rmsnorm(xc, nwc, eps)
+    want = ops.gemv_forward(xn, qwc, scc, qzc, g, flags=rows)
+    got = ops.gemv_forward_ex(xc, qwc, scc, qzc, g, norm_weight=nwc, norm_eps=eps)
+    y32, _ = oracle.matmul(oracle_norm(x), W)
+    wsig = oracle.weight_rounding_sigma(oracle_norm(x), W)
+    assert_product_close(got.cpu().numpy().astype(np.float64), y32, f"rows+norm K{K} N{N}", wsigma=wsig)
+    same = float((got == want).float().mean())
+    assert same >= 0.5, f"norm prologue: only {same:.3f} of the outputs equal the separate launches'"  # (typically 0.95-1.0)
+    d = (got.float() - want.float()).abs()
+    assert bool((d <= 2e-3 * want.float().abs() + 2e-3 * want.float().abs().mean()).all()), float(d.max())
+    got_nr = ops.gemv_forward_ex(xc, qwc, scc, qzc, g, norm_weight=nwc, norm_eps=eps, add_residual=resc)
+    assert same_bits(got_nr, got + resc)
+    # ---- silu pairs (rows (2 i, 2 i + 1) = (gate_i, up_i)): == awq_silu_and_mul on the separate outputs
+    if N % 2 == 0:
+        def unfused_silu(yy):  # awq_silu_and_mul takes widths that are multiples of 8: zero padding
+            D, D8 = N // 2, (N // 2 + 7) // 8 * 8
+            gu = torch.zeros((1, 2 * D8), dtype=torch.float16, device="cuda")
+            gu[:, :D], gu[:, D8:D8 + D] = yy[:, 0::2], yy[:, 1::2]
+            return ops.silu_and_mul(gu)[:, :D].contiguous()
+
+        want_p = unfused_silu(y_plain)
+        got_p = ops.gemv_forward_ex(xc, qwc, scc, qzc, g, silu_pairs=True)
+        assert same_bits(got_p, want_p), "silu-pairs epilogue differs from awq_silu_and_mul on the separate outputs"
+        want_np = unfused_silu(want)
+        got_np = ops.gemv_forward_ex(xc, qwc, scc, qzc, g, norm_weight=nwc, norm_eps=eps, silu_pairs=True)
+        d = (got_np.float() - want_np.float()).abs()
+        assert bool((d <= 4e-3 * want_np.float().abs() + 4e-3 * want_np.float().abs().mean()).all()), float(d.max())
+        # oracle: silu(fp16 gate) * fp16 up from the fp32 product
+        gt, up = y32[:, 0::2].astype(np.float16).astype(np.float32), y32[:, 1::2].astype(np.float16).astype(np.float32)
+        ref = (gt / (1.0 + np.exp(-gt))) * up
+        dd = np.abs(got_np.cpu().numpy().astype(np.float32) - ref)
+        assert bool((dd <= 2e-2 * np.abs(ref) + 2e-2 * np.abs(ref).mean()).all()), float(dd.max())
+    # bitwise reproducible
+    assert torch.equal(got, ops.gemv_forward_ex(xc, qwc, scc, qzc, g, norm_weight=nwc, norm_eps=eps))
+
+
+def test_gemv_forward_ex_refuses_what_the_rows_kernel_cannot_take(ops):
+    """batch > 1, two waves per row (K = 28672), silu pairs with a residual or an odd N: an error code, never a wrong answer"""
+    from autoawq_amd._lib import AwqHipError
+
+    qw, qz, sc, x4 = gemv_case(28672, 256, 128, 2, seed=9)
+    with pytest.raises(AwqHipError, match="code -3"):
+        ops.gemv_forward_ex(x4[:1].cuda(), qw.cuda(), sc.cuda(), qz.cuda(), 128, norm_weight=torch.ones(28672, dtype=torch.float16, device="cuda"))
+    qw, qz, sc, x4 = gemv_case(512, 64, 128, 2, seed=9)
+    with pytest.raises(AwqHipError, match="code -3"):
+        ops.gemv_forward_ex(x4.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), 128, add_residual=torch.zeros((2, 64), dtype=torch.float16, device="cuda"))
+    with pytest.raises(AwqHipError):
+        ops.gemv_forward_ex(x4[:1].cuda(), qw.cuda(), sc.cuda(), qz.cuda(), 128, silu_pairs=True,
+                            add_residual=torch.zeros((1, 32), dtype=torch.float16, device="cuda"))
+
+
 @pytest.mark.parametrize("K,N", [(4096, 11008), (4096, 22016), (4096, 4096), (11008, 4096), (8192, 1280), (2048, 4099), (1024, 200), (3584, 8192)])
 @pytest.mark.parametrize("M", [2, 3, 5, 8, 9, 16])
 def test_gemv_lds_kernel_vs_oracle(ops, oracle, K, N, M):

@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 H, I, V, HEADS, G = 4096, 11008, 32000, 32, 128
 
 
-def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbose=True, check=True, layout="gemm"):
+def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbose=True, check=True, layout="gemm",
+        hidden=H, inter=I, vocab=V, heads=HEADS):
     """Returns {context: ms_per_token}.  check: before timing, the logits of the five-launch stream path (norms folded
     into the projections, fused RoPE + append + attention) must agree with the plain module path (separate norm, RoPE /
     append, attention, o_proj, MLP launches) on the same weights and cache."""
@@ -27,6 +28,7 @@ def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbos
     dev = dev or torch.device("cuda")
     gen = torch.Generator(device=dev).manual_seed(0)
     lim = 0x7FFFFFFF
+    H, I, V, HEADS = hidden, inter, vocab, heads  # (tests run a small stack through the same code)
 
     def rand_linear(K, N):
         if layout == "gemv":  # the reference's WQLinear_GEMV checkpoint format: the decode layout since round 3
@@ -92,6 +94,8 @@ def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbos
                 blk.attn.use_device_positions(pos, ln)
             rel = float((fused - plain).abs().max() / plain.abs().max())
             assert rel < 3e-2, f"fused decode path differs from the plain module path by {rel}"
+            if layout == "gemv" and batch == 1:  # the five-launch path on the row-streaming kernel is the one that ran
+                assert blocks[0]._can_fold_gemv(torch.empty((1, 1, H), dtype=torch.float16, device=dev))
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=s):
             lm(tok)
@@ -114,7 +118,8 @@ def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbos
             ms = e0.elapsed_time(e1) / steps
             out[ctx] = ms
             if verbose:
-                print(f"7B-shape whole-model decode, {layers} layers, batch {batch}, context {ctx}: {ms:.3f} ms/token = "
+                name = "7B" if H == 4096 else "hidden-%d" % H
+                print(f"{name}-shape whole-model decode ({layout} layout), {layers} layers, batch {batch}, context {ctx}: {ms:.3f} ms/token = "
                       f"{batch * 1000.0 / ms:.1f} tok/s (one hipGraph per step)", flush=True)
     del graph, lm, blocks
     torch.cuda.empty_cache()
