@@ -335,10 +335,14 @@ def leg_whole_model(dev):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_decode_model
 
-    wm = bench_decode_model.run(contexts=(64, 2048), steps=48, dev=dev, verbose=False, check=True)
-    return {"unit": "tok/s", "context_64": 1000.0 / wm[64], "context_2048": 1000.0 / wm[2048],
-            "what": "synthetic 7B-shape fused decoder (32 blocks + lm_head), one hipGraph per token; logits checked against "
-                    "the unfused module path before timing",
+    # the decode layout (WQLinear_GEMV: fuse_llama(decode_layout="gemv")) and the checkpoint's own GEMM layout
+    wm = bench_decode_model.run(contexts=(64, 2048), steps=48, dev=dev, verbose=False, check=True, layout="gemv")
+    wg = bench_decode_model.run(contexts=(64, 2048), steps=48, dev=dev, verbose=False, check=True, layout="gemm")
+    return {"unit": "tok/s", "layout": "gemv", "context_64": 1000.0 / wm[64], "context_2048": 1000.0 / wm[2048],
+            "gemm_layout": {"context_64": 1000.0 / wg[64], "context_2048": 1000.0 / wg[2048]},
+            "what": "synthetic 7B-shape fused decoder (32 blocks + lm_head), one hipGraph per token, five launches per block "
+                    "(qkv with the norm in its prologue, RoPE + append + attention, o_proj + residual, gate|up with norm in and "
+                    "silu * mul out, down + residual); logits checked against the unfused module path before timing",
             "published_reference": {"value": 198.848, "context": 64, "hardware": "RTX 4090", "source": "README.md:207 (BASELINE.md)"},
             "vs_published_ctx64": (1000.0 / wm[64]) / 198.848}
 
