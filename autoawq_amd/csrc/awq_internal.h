@@ -119,4 +119,4 @@ size_t awq_decode_attention_workspace_bytes_impl(int B, int Hq, int max_splits);
 int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* v_cache, uint16_t* out,
                                 const int32_t* len_dev, int seq_len, int max_len, int B, int Hq, int Hkv, int D, int Tmax,
                                 float scale, void* workspace, size_t workspace_bytes, const float* cos_t,
-                                const float* sin_t, hipStream_t st);
+                                const float* sin_t, hipStream_t st, float softcap = 0.f, const float* alibi_slopes = nullptr);

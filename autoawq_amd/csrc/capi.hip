@@ -499,6 +499,21 @@ int awq_decode_attention(const uint16_t* q, const uint16_t* k_cache, const uint1
                                        static_cast<hipStream_t>(stream));
 }
 
+int awq_decode_attention_ex(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out,
+                            const int32_t* len_dev, int64_t seq_len, int64_t max_len, int64_t B, int64_t n_heads,
+                            int64_t n_kv_heads, int64_t head_dim, int64_t max_seq, float scale, float softcap,
+                            const float* alibi_slopes, void* workspace, size_t workspace_bytes, void* stream) {
+    if (B < 0 || B > 65535 || n_heads < 1 || n_kv_heads < 1 || n_kv_heads > 65535 || max_seq > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    if (!(softcap >= 0.f)) return AWQ_ERR_BAD_SHAPE;
+    if (B == 0) return AWQ_OK;
+    if (!q || !k_cache || !v_cache || !out) return AWQ_ERR_NULL;
+    if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out)) return AWQ_ERR_BAD_ALIGNMENT;
+    return awq_launch_decode_attention(q, const_cast<uint16_t*>(k_cache), const_cast<uint16_t*>(v_cache), out, len_dev,
+                                       (int)seq_len, (int)max_len, (int)B, (int)n_heads, (int)n_kv_heads, (int)head_dim,
+                                       (int)max_seq, scale, workspace, workspace_bytes, nullptr, nullptr,
+                                       static_cast<hipStream_t>(stream), softcap, alibi_slopes);
+}
+
 int awq_decode_attention_rope(const uint16_t* qkv, uint16_t* k_cache, uint16_t* v_cache, const float* cos_table,
                               const float* sin_table, uint16_t* out, const int32_t* pos_dev, int64_t start_pos,
                               int64_t max_len, int64_t B, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim,

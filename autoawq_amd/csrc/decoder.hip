@@ -120,13 +120,17 @@ __global__ __launch_bounds__(128) void awq_rope_kv_append_kernel(const half_t* _
 // launch -- and the one block whose chunk holds `pos` appends them to the caches.  len_dev then
 // holds the POSITION (length - 1).  Same roundings as awq_rope_kv_append followed by the plain
 // kernel: rotated values pass through fp16.
-template <int G, bool FUSED>
+// EXTRA (plain form only): logit soft-capping s := cap * tanh(s / cap) (attn.py:150,166 `softcap=`) and ALiBi, a per-head linear
+// bias slope_h * (t - pos) on the key position (attn.py:89-125,149,165 `alibi_slopes=`), in that order like flash-attn.
+template <int G, bool FUSED, bool EXTRA = false>
 __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __restrict__ q, half_t* __restrict__ kc,
                                                              half_t* __restrict__ vc, half_t* __restrict__ out,
                                                              float* __restrict__ part, const int* __restrict__ len_dev,
                                                              int seq_len, int Hq, int Hkv, int Tmax, float scale,
                                                              int chunk, const float* __restrict__ cos_t,
-                                                             const float* __restrict__ sin_t) {
+                                                             const float* __restrict__ sin_t, float softcap,
+                                                             const float* __restrict__ alibi) {
+    static_assert(!(FUSED && EXTRA), "soft-capping / ALiBi ride on the plain form");
     constexpr int D = 128;
     __shared__ float sm[4][G][D + 2];
     const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
@@ -177,6 +181,10 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
             for (int e = 0; e < 8; ++e) qf[g][e] = (float)qv[e] * scale;
         }
     }
+    float slope[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) slope[g] = (EXTRA && alibi) ? alibi[hk * G + g] : 0.f;
+    const float inv_cap = (EXTRA && softcap > 0.f) ? 1.0f / softcap : 0.f;
     float m[G], l[G], o[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -214,6 +222,10 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
                 for (int e = 0; e < 8; ++e) s += qf[g][e] * (float)kv[u][e];
 #pragma unroll
                 for (int x = 8; x > 0; x >>= 1) s += __shfl_xor(s, x, 64);  // sum over the 16 lanes of the row
+                if constexpr (EXTRA) {
+                    if (inv_cap > 0.f) s = softcap * tanhf(s * inv_cap);
+                    s += slope[g] * (float)(tb + 16 * u + r - pos);
+                }
                 if (live) {
                     const float mn = fmaxf(m[g], s);
                     const float corr = __expf(m[g] - mn), p = __expf(s - mn);
@@ -339,13 +351,13 @@ size_t awq_decode_attention_workspace_bytes_impl(int B, int Hq, int max_splits) 
     return (size_t)B * Hq * max_splits * (128 + 2) * sizeof(float);
 }
 
-template <int G, bool FUSED>
+template <int G, bool FUSED, bool EXTRA = false>
 static void launch_attn(dim3 grid, hipStream_t st, const uint16_t* q, uint16_t* kc, uint16_t* vc, uint16_t* out, float* part,
                         const int32_t* len_dev, int seq_len, int Hq, int Hkv, int Tmax, float scale, int chunk,
-                        const float* cos_t, const float* sin_t) {
-    hipLaunchKernelGGL((awq_decode_attn_kernel<G, FUSED>), grid, dim3(256), 0, st, reinterpret_cast<const half_t*>(q),
+                        const float* cos_t, const float* sin_t, float softcap = 0.f, const float* alibi = nullptr) {
+    hipLaunchKernelGGL((awq_decode_attn_kernel<G, FUSED, EXTRA>), grid, dim3(256), 0, st, reinterpret_cast<const half_t*>(q),
                        reinterpret_cast<half_t*>(kc), reinterpret_cast<half_t*>(vc), reinterpret_cast<half_t*>(out), part,
-                       len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk, cos_t, sin_t);
+                       len_dev, seq_len, Hq, Hkv, Tmax, scale, chunk, cos_t, sin_t, softcap, alibi);
 }
 
 // cos_t == nullptr: plain form (q [B, Hq, D], rows [0, len) of the caches).  Otherwise the fused form:
@@ -353,8 +365,11 @@ static void launch_attn(dim3 grid, hipStream_t st, const uint16_t* q, uint16_t* 
 int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* v_cache, uint16_t* out,
                                 const int32_t* len_dev, int seq_len, int max_len, int B, int Hq, int Hkv, int D, int Tmax,
                                 float scale, void* workspace, size_t workspace_bytes, const float* cos_t,
-                                const float* sin_t, hipStream_t st) {
+                                const float* sin_t, hipStream_t st, float softcap, const float* alibi) {
     if (D != 128) return AWQ_ERR_UNSUPPORTED;
+    const bool extra = softcap > 0.f || alibi != nullptr;
+    if (extra && cos_t) return AWQ_ERR_UNSUPPORTED;  // ALiBi models do not rotate; soft-capping takes the two-launch form
+    if (softcap < 0.f) return AWQ_ERR_BAD_SHAPE;
     if (B < 0 || Hq < 1 || Hkv < 1 || Hq % Hkv || Tmax < 1) return AWQ_ERR_BAD_SHAPE;
     const int G = Hq / Hkv;
     if (!(G == 1 || G == 2 || G == 4 || G == 8)) return AWQ_ERR_UNSUPPORTED;
@@ -380,7 +395,9 @@ int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* 
     float* part = static_cast<float*>(workspace);
 #define AWQ_ATTN_CASE(GG)                                                                                                  \
     case GG:                                                                                                               \
-        if (fused) launch_attn<GG, true>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, \
+        if (extra) launch_attn<GG, false, true>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, \
+                                                scale, chunk, nullptr, nullptr, softcap, alibi);                            \
+        else if (fused) launch_attn<GG, true>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale, \
                                          chunk, cos_t, sin_t);                                                             \
         else launch_attn<GG, false>(grid, st, q, k_cache, v_cache, out, part, len_dev, seq_len, Hq, Hkv, Tmax, scale,      \
                                     chunk, nullptr, nullptr);                                                              \

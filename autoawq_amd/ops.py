@@ -495,10 +495,11 @@ def rope_kv_append(qkv, k_cache, v_cache, cos, sin, start_pos, n_heads, n_kv_hea
 _attn_workspaces = {}
 
 
-def decode_attention(q, k_cache, v_cache, seq_len, scale=None, len_dev=None, max_len=None):
+def decode_attention(q, k_cache, v_cache, seq_len, scale=None, len_dev=None, max_len=None, softcap=0.0, alibi_slopes=None):
     """q [B, Hq, 128] fp16, caches [B, Tmax, Hkv, 128] -> [B, Hq, 128]: attention of ONE query token per
-    sequence over cache rows [0, seq_len) (awq_decode_attention)."""
-    _require_gpu(q, k_cache, v_cache, len_dev)
+    sequence over cache rows [0, seq_len) (awq_decode_attention; with logit soft-capping / ALiBi slopes [Hq] fp32:
+    awq_decode_attention_ex)."""
+    _require_gpu(q, k_cache, v_cache, len_dev, alibi_slopes)
     B, Hq, D = q.shape
     Hkv, Tmax = k_cache.shape[2], k_cache.shape[1]
     q = q.contiguous()
@@ -515,9 +516,19 @@ def decode_attention(q, k_cache, v_cache, seq_len, scale=None, len_dev=None, max
     if scale is None:
         scale = D ** -0.5
     with torch.cuda.device(q.device):
-        _lib.check(L.awq_decode_attention(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(len_dev), int(seq_len),
-                                          int(max_len if max_len is not None else seq_len), B, Hq, Hkv, D, Tmax,
-                                          float(scale), _ptr(ws), ws.numel(), _stream()), "awq_decode_attention")
+        if softcap or alibi_slopes is not None:
+            if alibi_slopes is not None:
+                alibi_slopes = alibi_slopes.to(torch.float32).contiguous()
+                if alibi_slopes.numel() != Hq:
+                    raise _lib.AwqHipError("decode_attention: alibi_slopes must hold one slope per query head")
+            _lib.check(L.awq_decode_attention_ex(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(len_dev), int(seq_len),
+                                                 int(max_len if max_len is not None else seq_len), B, Hq, Hkv, D, Tmax,
+                                                 float(scale), float(softcap), _ptr(alibi_slopes), _ptr(ws), ws.numel(),
+                                                 _stream()), "awq_decode_attention_ex")
+        else:
+            _lib.check(L.awq_decode_attention(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(len_dev), int(seq_len),
+                                              int(max_len if max_len is not None else seq_len), B, Hq, Hkv, D, Tmax,
+                                              float(scale), _ptr(ws), ws.numel(), _stream()), "awq_decode_attention")
     return out
 
 

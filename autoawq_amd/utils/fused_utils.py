@@ -55,3 +55,26 @@ def fuse_qkv(module, q_proj, k_proj, v_proj):
     for m in (q_proj, k_proj, v_proj):
         del m.qweight, m.qzeros, m.scales
     return qkv
+
+
+def get_attention_shapes(attention_shapes, n_heads, n_kv_heads, head_dim):
+    """awq/utils/fused_utils.py:165-201: how QuantAttentionFused views one fused qkv row and slices q / k / v out of it.  A
+    caller-supplied dict passes through; n_kv_heads == 0 is the multi-head form `[3, n_heads, head_dim]` (q, k, v planes);
+    otherwise the grouped-query form `[n_heads + 2 n_kv_heads, head_dim]` with the q heads first, then k, then v.  Both are the
+    q | k | v head order in memory -- the order the gfx950 kernels read."""
+    if attention_shapes is not None:
+        return attention_shapes
+    if n_kv_heads == 0:
+        kv, view = n_heads, (-1, n_heads, head_dim)
+        pick = {name: (lambda xqkv, i=i: xqkv[:, :, i]) for i, name in enumerate(("xq_slice", "xk_slice", "xv_slice"))}
+    else:
+        kv, view = n_kv_heads, (n_heads + 2 * n_kv_heads, head_dim)
+        bounds = {"xq_slice": (0, n_heads), "xk_slice": (n_heads, n_heads + kv), "xv_slice": (n_heads + kv, n_heads + 2 * kv)}
+        pick = {name: (lambda xqkv, a=a, b=b: xqkv[:, :, a:b]) for name, (a, b) in bounds.items()}
+    shapes = {"xqkv_view": view, **pick}
+    for prefix in ("", "single_"):
+        shapes[prefix + "xq_view"] = (n_heads, head_dim)
+        shapes[prefix + "xk_view"] = (kv, head_dim)
+        shapes[prefix + "xv_view"] = (kv, head_dim)
+    shapes["xk_reshape"] = (kv, head_dim // 8, 8)
+    return shapes

@@ -238,6 +238,15 @@ AWQ_EXPORT int awq_decode_attention(const uint16_t* q, const uint16_t* k_cache, 
                                     int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq, float scale,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* awq_decode_attention with the two score modifiers flash_attn_with_kvcache takes at attn.py:286-302: softcap > 0 applies
+ * s := softcap * tanh(s / softcap) to the scaled scores (`softcap=self.attn_logit_softcapping`), alibi_slopes != NULL
+ * ([n_heads] fp32, ALiBi.slopes of attn.py:89-125) then adds slope_h * (t - (len - 1)) for key row t.  0 / NULL = plain. */
+AWQ_EXPORT int awq_decode_attention_ex(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out,
+                                       const int32_t* len_dev, int64_t seq_len, int64_t max_len, int64_t B,
+                                       int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq, float scale,
+                                       float softcap, const float* alibi_slopes, void* workspace, size_t workspace_bytes,
+                                       void* stream);
+
 /* awq_rmsnorm_forward folded into the projection that follows it (decode, M <= 4, GEMM layout):
  * y = rmsnorm(x (+ residual_in)) * norm_weight @ W.  Every block of the decode kernel recomputes the
  * row statistic from the L2-resident row while its first weight requests are in flight and normalises

@@ -53,8 +53,22 @@ def rmsnorm_reference(x, w, eps):
     return (xf * inv.astype(np.float32) * np.asarray(w, np.float32)).astype(np.float16)
 
 
-def attention_reference(q, k_cache, v_cache, seq_len, scale=None):
-    """q [B, Hq, D], caches [B, Tmax, Hkv, D] numpy fp16 -> [B, Hq, D] float64."""
+def alibi_slopes_reference(n_heads, alibi_bias_max=8):
+    """ALiBi.gen_slopes (awq/modules/fused/attn.py:101-111): [n_heads] float64."""
+    import math
+
+    n2 = 2 ** math.ceil(math.log2(n_heads))
+    m = np.arange(1, n2 + 1, dtype=np.float32) * np.float32(alibi_bias_max / n2)
+    slopes = (1.0 / np.power(np.float32(2), m)).astype(np.float64)
+    if n2 != n_heads:
+        slopes = np.concatenate([slopes[1::2], slopes[::2]])[:n_heads]
+    return slopes
+
+
+def attention_reference(q, k_cache, v_cache, seq_len, scale=None, softcap=0.0, alibi_slopes=None):
+    """q [B, Hq, D], caches [B, Tmax, Hkv, D] numpy fp16 -> [B, Hq, D] float64.  softcap / alibi_slopes: the two score modifiers
+    the reference hands flash_attn_with_kvcache (attn.py:286-302): s := softcap * tanh(s / softcap), then the bias
+    slope_h * (t - (seq_len - 1)) of ALiBi.build_alibi_bias (attn.py:113-121: arange(1 - seq_len, 1) * slope)."""
     q = np.asarray(q, np.float64)
     B, Hq, D = q.shape
     Hkv = k_cache.shape[2]
@@ -66,6 +80,10 @@ def attention_reference(q, k_cache, v_cache, seq_len, scale=None):
             k = np.asarray(k_cache[b, :seq_len, h // G], np.float64)
             v = np.asarray(v_cache[b, :seq_len, h // G], np.float64)
             s = k @ q[b, h] * scale
+            if softcap:
+                s = softcap * np.tanh(s / softcap)
+            if alibi_slopes is not None:
+                s = s + alibi_slopes[h] * np.arange(1 - seq_len, 1)
             p = np.exp(s - s.max())
             out[b, h] = (p / p.sum()) @ v
     return out

@@ -128,6 +128,46 @@ def test_fused_module_surfaces():
     assert list(inspect.signature(FasterTransformerRMSNorm.__init__).parameters)[1:] == ["weight", "eps"]
 
 
+def test_alibi_and_attention_shapes_match_the_reference_classes():
+    """ALiBi slopes / bias and get_attention_shapes against vectors the reference's own classes produced
+    (tests/golden/make_golden_attention.py: attn.py:89-125, fused_utils.py:165-201), for the module and for the oracle."""
+    from autoawq_amd.modules.fused.attn import ALiBi
+    from autoawq_amd.utils.fused_utils import get_attention_shapes
+    from oracle import decoder_oracle
+
+    g = golden("attention_golden")
+    for n in (8, 12, 40):
+        slopes, bias = ALiBi.build_alibi_bias(n, 16)
+        assert np.array_equal(slopes.numpy(), g[f"alibi_slopes_{n}"]) and np.array_equal(bias.numpy(), g[f"alibi_bias_{n}"])
+        assert np.allclose(decoder_oracle.alibi_slopes_reference(n), g[f"alibi_slopes_{n}"], rtol=0, atol=0)
+    for name in ("mha_interleaved", "gqa"):
+        H, Hkv, D = (int(v) for v in g[f"{name}_meta"])
+        sh = get_attention_shapes(None, H, Hkv, D)
+        x = torch.from_numpy(g[f"{name}_xqkv"])
+        v = x.view((2, 3) + tuple(sh["xqkv_view"]))
+        for key in ("xq", "xk", "xv"):
+            assert np.array_equal(sh[key + "_slice"](v).contiguous().numpy(), g[f"{name}_{key}"]), (name, key)
+    custom = {"xqkv_view": (1,)}
+    assert get_attention_shapes(custom, 4, 2, 8) is custom
+
+
+def test_oracle_attention_score_modifiers():
+    """soft-capping and ALiBi in the oracle against a direct restatement of what flash-attn computes with those arguments"""
+    from oracle import decoder_oracle
+
+    gen = torch.Generator().manual_seed(3)
+    q = torch.randn((1, 4, 16), generator=gen).double().numpy()
+    k = torch.randn((1, 9, 2, 16), generator=gen).double().numpy()
+    v = torch.randn((1, 9, 2, 16), generator=gen).double().numpy()
+    slopes = decoder_oracle.alibi_slopes_reference(4)
+    got = decoder_oracle.attention_reference(q, k, v, 7, softcap=5.0, alibi_slopes=slopes)
+    for h in range(4):
+        s = (k[0, :7, h // 2] @ q[0, h]) * 16 ** -0.5
+        s = 5.0 * np.tanh(s / 5.0) - slopes[h] * np.arange(6, -1, -1)
+        p = np.exp(s - s.max())
+        assert np.allclose(got[0, h], (p / p.sum()) @ v[0, :7, h // 2], rtol=1e-12, atol=1e-12)
+
+
 # ------------------------------------------------------------------ GPU kernels
 
 @pytest.fixture(scope="module")
@@ -209,6 +249,117 @@ def test_decode_attention_vs_oracle(ops, B, Hq, Hkv, T):
     ln = torch.tensor([T], dtype=torch.int32, device="cuda")  # device-side length, launch sized for the whole cache
     got2 = ops.decode_attention(q.cuda(), kc.cuda(), vc.cuda(), 1, len_dev=ln, max_len=Tmax).cpu().numpy().astype(np.float64)
     assert np.abs(got2 - want).max() <= 2e-3 * np.abs(want).max() + 2 ** -11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("softcap,alibi", [(30.0, False), (0.0, True), (8.0, True)])
+@pytest.mark.parametrize("B,Hq,Hkv,T", [(1, 32, 32, 77), (2, 8, 4, 300), (1, 32, 8, 2048), (3, 16, 2, 129), (2, 12, 12, 1)])
+def test_decode_attention_softcap_and_alibi_vs_oracle(ops, B, Hq, Hkv, T, softcap, alibi):
+    """awq_decode_attention_ex: the two score modifiers of flash_attn_with_kvcache (attn.py:286-302)"""
+    from oracle import decoder_oracle
+
+    gen = torch.Generator().manual_seed(B * 7 + Hq + T)
+    Tmax = max(T + 5, 64)
+    q = (torch.randn((B, Hq, 128), generator=gen) * 2).half()
+    kc = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    vc = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    slopes = decoder_oracle.alibi_slopes_reference(Hq) if alibi else None
+    want = decoder_oracle.attention_reference(q.numpy(), kc.numpy(), vc.numpy(), T, softcap=softcap, alibi_slopes=slopes)
+    sl = torch.from_numpy(slopes).float().cuda() if alibi else None
+    got = ops.decode_attention(q.cuda(), kc.cuda(), vc.cuda(), T, softcap=softcap, alibi_slopes=sl).cpu().numpy().astype(np.float64)
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 2 ** -11
+    ln = torch.tensor([T], dtype=torch.int32, device="cuda")
+    got2 = ops.decode_attention(q.cuda(), kc.cuda(), vc.cuda(), 1, len_dev=ln, max_len=Tmax, softcap=softcap, alibi_slopes=sl)
+    assert np.abs(got2.cpu().numpy().astype(np.float64) - want).max() <= 2e-3 * np.abs(want).max() + 2 ** -11
+    plain = decoder_oracle.attention_reference(q.numpy(), kc.numpy(), vc.numpy(), T)
+    if T > 1:
+        assert np.abs(plain - want).max() > 1e-3, "the modifiers must change the result for this test to mean anything"
+
+
+class _HeadRMSNorm(torch.nn.Module):
+    """per-head RMSNorm over head_dim, the q_norm / k_norm of Qwen3 / Gemma3-style attention"""
+
+    def __init__(self, dim, gen):
+        super().__init__()
+        self.weight = torch.nn.Parameter((torch.rand(dim, generator=gen) + 0.5).half(), requires_grad=False)
+
+    def forward(self, x):
+        xf = x.float()
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * self.weight.float()).to(x.dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feature", ["alibi", "softcap", "qk_norm", "custom_shapes", "alibi_head64"])
+@torch.no_grad()
+def test_quant_attention_fused_feature_surface(feature):
+    """QuantAttentionFused with ALiBi, logit soft-capping, q / k norms and a custom `attention_shapes` (attn.py:159-203,243-302):
+    a 6-token prefill followed by 3 single-token steps through the cache equals a plain fp32 causal attention over the whole
+    sequence written out here from the reference's forward (slice -> norms -> rotate unless ALiBi -> scores * scale ->
+    soft-cap -> + slope * (key - query) -> causal softmax -> values -> o_proj)."""
+    from autoawq_amd.modules.fused.attn import ALiBi, QuantAttentionFused, RoPE
+    from oracle import decoder_oracle
+
+    gen = torch.Generator().manual_seed(hash(feature) % 1000)
+    D = 64 if feature == "alibi_head64" else 128
+    Hq, Hkv, hidden, B, T = 4, 2, 256, 2, 9
+    width = (Hq + 2 * Hkv) * D
+    qkv = torch.nn.Linear(hidden, width, bias=False).half().cuda()
+    o = torch.nn.Linear(Hq * D, hidden, bias=False).half().cuda()
+    with torch.no_grad():
+        qkv.weight.copy_((torch.randn((width, hidden), generator=gen) * 0.08).half())
+        o.weight.copy_((torch.randn((hidden, Hq * D), generator=gen) * 0.05).half())
+    kw = {}
+    shapes = None
+    if feature.startswith("alibi"):
+        kw["use_alibi"] = True
+    if feature == "softcap":
+        kw["attn_logit_softcapping"] = 4.0
+    if feature == "qk_norm":
+        kw["q_norm"], kw["k_norm"] = _HeadRMSNorm(D, gen).cuda(), _HeadRMSNorm(D, gen).cuda()
+    if feature == "custom_shapes":  # Falcon-style rows: per KV group [its query heads, k, v]
+        G = Hq // Hkv
+        shapes = {"xqkv_view": (Hkv, G + 2, D),
+                  "xq_slice": lambda x: x[:, :, :, :-2].reshape(x.shape[0], x.shape[1], -1, D),
+                  "xk_slice": lambda x: x[:, :, :, -2],
+                  "xv_slice": lambda x: x[:, :, :, -1]}
+        kw["attention_shapes"] = shapes
+    attn = QuantAttentionFused(hidden, Hq, Hkv, qkv, o, dev="cuda", max_seq_len=32, head_dim=D, **kw)
+    x = torch.randn((B, T, hidden), generator=gen).half().cuda()
+
+    # ---- the whole sequence at once, fp32
+    rows = qkv(x)
+    if shapes is not None:
+        v5 = rows.view((B, T) + shapes["xqkv_view"])
+        xq, xk, xv = shapes["xq_slice"](v5), shapes["xk_slice"](v5), shapes["xv_slice"](v5)
+    else:
+        v4 = rows.view(B, T, Hq + 2 * Hkv, D)
+        xq, xk, xv = v4[:, :, :Hq], v4[:, :, Hq:Hq + Hkv], v4[:, :, Hq + Hkv:]
+    if "q_norm" in kw:
+        xq, xk = kw["q_norm"](xq), kw["k_norm"](xk)
+    if not feature.startswith("alibi"):
+        xq, xk = decoder_oracle.rope_reference(xq.cpu(), xk.cpu(), 0, D, 32)
+        xq, xk = xq.cuda(), xk.cuda()
+    qf = xq.float().transpose(1, 2)
+    kf = xk.float().transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    vf = xv.float().transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    sc = qf @ kf.transpose(-1, -2) * D ** -0.5
+    if feature == "softcap":
+        sc = 4.0 * torch.tanh(sc / 4.0)
+    pos = torch.arange(T, device="cuda")
+    if feature.startswith("alibi"):
+        sc = sc + ALiBi.gen_slopes(Hq).cuda() * (pos.view(1, -1) - pos.view(-1, 1)).float()
+    sc = sc.masked_fill(pos.view(1, -1) > pos.view(-1, 1), float("-inf"))
+    want = o((torch.softmax(sc, -1) @ vf).transpose(1, 2).reshape(B, T, -1).half()).float()
+
+    got_prefill, _, _ = attn(x[:, :6])
+    outs = [got_prefill.float()]
+    for t in range(6, T):
+        step, _, _ = attn(x[:, t:t + 1])
+        outs.append(step.float())
+    got = torch.cat(outs, dim=1)
+    assert attn.start_pos == T
+    err = (got - want).abs().max()
+    assert float(err) <= 1e-2 * float(want.abs().max()) + 1e-3, float(err)
 
 
 @pytest.mark.gpu
