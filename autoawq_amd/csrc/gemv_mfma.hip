@@ -886,6 +886,7 @@ int awq_launch_grouped_gemm(const AwqGemmArgs& a, const int* sorted_ids, const i
                             const float* pair_weights, int num_pairs, int x_div, int max_blocks, int64_t expert_qw_words,
                             int64_t expert_z_words, int64_t expert_s_halfs) {
     if (!(a.M == 16 || a.M == 8) || max_blocks < 1 || a.x_gated > 1) return AWQ_ERR_BAD_SHAPE;
+    if (max_blocks > 65535) return AWQ_ERR_UNSUPPORTED;  // token blocks ride in gridDim.z; prefill-sized routings take the per-expert path
     if (!awq_gemv_mfma_supports(a.M, a.K, a.N, a.g, 2) || a.g % 32) return AWQ_ERR_UNSUPPORTED;
     GemvCfg c{2, 4, 0, 0, 0, 0, 0};
     AwqGemmArgs probe = a;

@@ -50,11 +50,24 @@ class QuantFusedMLP(nn.Module):
                     self.register_buffer(proj + name, view)
 
     def _apply(self, fn, recurse=True):
-        # .to() / .cuda() / .half() give every buffer a storage of its own: fuse the moved tensors again
+        # .to() / .cuda() / .half() give every buffer a storage of its own: fuse the moved tensors again -- unless nothing
+        # moved (a no-op .to(): the views still sit in the fused storage)
         super()._apply(fn, recurse)
-        self._adopt(self.gate_proj_qweight, self.gate_proj_scales, self.gate_proj_qzeros,
-                    self.up_proj_qweight, self.up_proj_scales, self.up_proj_qzeros)
+        base = self._fused[0].untyped_storage().data_ptr() if self._fused is not None else None
+        if base is None or self.gate_proj_qweight.untyped_storage().data_ptr() != base:
+            self._adopt(self.gate_proj_qweight, self.gate_proj_scales, self.gate_proj_qzeros,
+                        self.up_proj_qweight, self.up_proj_scales, self.up_proj_qzeros)
         return self
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        # the six registered buffers are views into the fused [gate | up] tensors: hand out tensors with storages of their
+        # own (safetensors' save_file rejects tensors that share memory)
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        for proj in ("gate_proj_", "up_proj_"):
+            for name in ("qweight", "scales", "qzeros"):
+                key = prefix + proj + name
+                if key in destination:
+                    destination[key] = destination[key].clone()
 
     def _gate_up_fused(self):
         """Concatenated [gate | up] buffers (re-fused if a caller re-assigned one of the registered views)."""

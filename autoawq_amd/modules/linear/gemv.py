@@ -19,9 +19,10 @@ from ... import _lib, ops
 from ...utils.packing import (GEMV_ORDER, calculate_zeros_width, pack_rows_int4, pack_zeros_nk,
                               quantize_int_weights_nk)
 
-# from this many rows a call is prefill-shaped: the fused MFMA GEMM kernels on a cached GEMM-layout repack of the same integers
-# instead of ceil(M/16) passes of the decode kernel (the reference switches kernels at 8 rows, gemv.py:168)
-PREFILL_MIN_ROWS = 65
+# from this many rows a call runs the fused MFMA GEMM kernels (gemm_skinny / gemm_tiled / gemm_regb by row count) on a cached
+# GEMM-layout repack of the same integers instead of ceil(M/16) passes of the 16-row decode kernel (4096 x 11008, M = 32:
+# 14 us vs 2 x 24; the reference switches to its batched kernel at 8 rows, gemv.py:168)
+PREFILL_MIN_ROWS = 17
 
 
 def _gemm_layout_copy(m):

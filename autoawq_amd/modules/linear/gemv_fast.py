@@ -17,7 +17,7 @@ from ... import _lib, ops
 from ...utils.packing import calculate_zeros_width, pack_intweight_fast, quantize_int_weights_nk
 from .gemv import _gemm_layout_copy
 
-PREFILL_MIN_ROWS = 65
+PREFILL_MIN_ROWS = 17
 
 
 class WQLinear_GEMVFast(torch.nn.Module):

@@ -96,6 +96,13 @@ def test_fused_mlp_keeps_one_copy_of_gate_up():
     sd = mlp.state_dict()
     assert {"gate_proj_qweight", "gate_proj_scales", "gate_proj_qzeros", "up_proj_qweight", "up_proj_scales", "up_proj_qzeros"} <= set(sd)
     assert torch.equal(sd["up_proj_qweight"], uq) and torch.equal(sd["up_proj_scales"], us)
+    # state_dict hands out tensors with storages of their own (safetensors' save_file rejects shared memory)
+    assert len({sd[k].untyped_storage().data_ptr() for k in sd if k.startswith(("gate_proj_", "up_proj_"))}) == 6
+    import os, tempfile
+    from safetensors.torch import load_file, save_file
+    with tempfile.TemporaryDirectory() as tmp:
+        save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(tmp, "mlp.safetensors"))
+        assert torch.equal(load_file(os.path.join(tmp, "mlp.safetensors"))["up_proj_qweight"], uq)
     # load into another instance: the copy lands in the fused tensors
     other = QuantFusedMLP(lin(256, 512), lin(512, 256), lin(256, 512))
     other.load_state_dict(sd)
