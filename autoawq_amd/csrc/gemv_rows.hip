@@ -35,6 +35,8 @@
 //  * Cross-lane: two DPP rotations per round, then lanes 12-15 of each 16-lane row park four partial sums per unit in
 //    LDS; at the end a lane adds the 4 * SL (* wk) partials of a row and writes y.  Bitwise reproducible.
 //  * Static partition: SUs dealt evenly to (block, row group); the grid is a multiple of the CU count.
+#include <type_traits>
+
 #include "awq_device.h"
 #include "awq_internal.h"
 
@@ -120,6 +122,14 @@ AWQ_DEV float4_t mfma4(u32x2 a, u32x2 b, float4_t c) {
 struct Round {  // four units in flight
     u32x4 q[4];
 };
+
+template <int I, int N, class F>
+AWQ_DEV void static_for(F&& f) {  // f(integral_constant<int, I>) ... f(integral_constant<int, N - 1>)
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 constexpr int rows_per_su(int SL) { return SL == 1 || SL == 3 ? 4 : (SL == 2 || SL == 6 ? 2 : 1); }
 
@@ -340,15 +350,14 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     const int red_step = RPU * NC * 4;
     ROWS_STAMP(3);
 
-    // ---- stream the super-units
-    for (int tbase = 0; tbase < nt; tbase += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int t = tbase + d;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                Round& Rd = ring[d][r];
-                AWQ_ROWS_WAIT(Rd, AWQ_ROWS_LPR * (R * D - 1));  // in flight behind it: every other round of the ring
+    // ---- one round: wait until at most NEWER later operations are outstanding (= this round has landed), consume it, and --
+    // in the main phase -- request the same round of super-unit t + D into the registers just freed
+    auto do_round = [&](auto newer_c, auto rerequest_c, Round& Rd, const int t, const int r) __attribute__((always_inline)) {
+        constexpr int NEWER = decltype(newer_c)::value;
+        constexpr bool REREQUEST = decltype(rerequest_c)::value;
+        {
+            {
+                AWQ_ROWS_WAIT(Rd, NEWER);
 #ifdef AWQ_GEMV_TRACE
                 if (t == 0 && r == 0) ROWS_STAMP(4);
 #endif
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                 // at the request, so the round keeps its registers (no copy of a register with a load in flight)
 #pragma unroll
                 for (int m = 0; m < MM; ++m) asm volatile("" ::"v"(pu[m][0]), "v"(pu[m][1]), "v"(pu[m][2]), "v"(pu[m][3]));
-                request(Rd, t + D, r);
+                if constexpr (REREQUEST) request(Rd, t + D, r);
 #pragma unroll
                 for (int m = 0; m < MM; ++m) {
                     float v;
@@ -427,12 +436,35 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                         v += dpp_mov<0x124>(v);  // row_ror:4
                         v += dpp_mov<0x128>(v);  // row_ror:8  -> sum over the four quads of this 16-lane row
                     }
-                    if (writer && t < nt) red[(m * rows_blk * NC) * 4 + red_lane[r] + t * red_step] = v;
+                    if (writer) red[(m * rows_blk * NC) * 4 + red_lane[r] + t * red_step] = v;
                 }
             }
         }
+    };
+    // ---- stream.  Main phase: super-units [0, nt - D), every consumed round re-requested D super-units ahead (always a live
+    // one), so exactly the R D - 1 other rounds of the ring are in flight behind the one being waited for.  Drain phase: the
+    // last D super-units, oldest first, no requests, the allowed count falling by one round each time.  (The first version kept
+    // requesting 16-byte dummies past the end to keep ONE wait count: every wave then ended on a full memory round trip.)
+    // The launcher gives every row group a multiple of D super-units (D = 2 only when they divide evenly), so the ring position
+    // of every super-unit is static: ONE straight-line drain, no alternative register mappings for the compiler to reconcile
+    // with copies of registers whose loads are still in flight (it did exactly that for a two-variant drain; tools/isa_audit.py
+    // audit_inflight_regs, run by tests/test_boundary.py, reads the ISA back).
+    const int n_main = nt - D;  // nt == 0 (a row group without work) skips both phases
+    for (int tbase = 0; tbase < n_main; tbase += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                do_round(std::integral_constant<int, AWQ_ROWS_LPR * (R * D - 1)>{}, std::true_type{}, ring[d][r], tbase + d, r);
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the short repeats past the last SU
+    if (nt > 0) {
+        static_for<0, R * D>([&](auto i_c) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_c)::value, dpos = i / R, r = i % R;
+            do_round(std::integral_constant<int, AWQ_ROWS_LPR * (R * D - 1 - i)>{}, std::false_type{}, ring[dpos][r], n_main + dpos, r);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the 16-byte dummies of a row group without work; nothing is outstanding otherwise
     ROWS_STAMP(5);
     if constexpr (!(AWQ_ROWS_DBG & 8)) {
         // ---- add the 4 * wk * SL partials of every row, write y.  wk == 1: a wave folds the rows it produced itself
@@ -612,6 +644,7 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     const bool one_round = SL * RPU == 4;
     if (depth < 1 || depth > 2) depth = p.su_max >= 2 && p.su_max <= 8 && bpc == 1 && one_round ? 2 : 1;
     if (!one_round || (SL == 4 && M > 1) || (SL == 2 && M > 3)) depth = 1;  // instantiated combinations (register budget)
+    if (p.su_rem != 0 || (p.su_base * p.su_gran) % 2) depth = 1;  // two in flight only when every row group gets an even count
     p.trace = nullptr;
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_rows_trace;

@@ -209,6 +209,21 @@ def test_hand_counted_asm_loads_are_hazard_safe():
         assert blocks >= min_blocks, (name, blocks)
 
 
+def test_row_streaming_kernel_never_touches_registers_with_loads_in_flight():
+    """csrc/gemv_rows.hip requests ring slots in asm blocks and releases them with hand-counted waits that NAME the registers.
+    hipcc believes a destination is written when the request block ends, so it may copy or reuse it while the load is still
+    in flight (it did, for a drain phase with two alternative slot orders: v_mov of ring registers in front of the wait).
+    tools/isa_audit.py walks every path from each request to the wait that releases it in the generated ISA."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    name, checked, bad = mod.audit_inflight_regs(os.path.join(ROOT, "autoawq_amd", "csrc", "gemv_rows.hip"))
+    assert not bad, (name, bad[:5])
+    assert checked >= 100, checked
+
+
 def test_auto_dispatch_table_host_only():
     """awq_gemm_auto_kernel is a host-only query (no launch, no GPU): which kernel awq_gemm_forward's AUTO dispatch takes
     for the BASELINE shapes, by token count -- the table DESIGN.md section 1 (row a4/a5) describes."""

@@ -43,8 +43,7 @@ def child(bits):
     dev = torch.device("cuda")
     gen = torch.Generator(device=dev).manual_seed(0)
     res = []
-    for K, N, fl in [(4096, 4096, dict(waves=8, unit=1, splitk=1)), (4096, 12288, dict(waves=8, unit=1, splitk=1)),
-                     (4096, 22016, dict(waves=8, unit=2, splitk=1)), (11008, 4096, dict(waves=8, unit=1, splitk=1))]:
+    for K, N, fl in [(4096, 4096, {}), (4096, 12288, {}), (4096, 22016, {}), (11008, 4096, {})]:  # the launcher's defaults
         nsets = max(4, min(96, (640 << 20) // (K * N // 2)))
         sets = [rand_nk(K, N, 128) for _ in range(nsets)]
         x = torch.randn((1, K), device=dev, generator=gen).half()
