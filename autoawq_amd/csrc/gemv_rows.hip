@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     constexpr int RPU = rows_per_su(SL);  // rows per super-unit
     constexpr int R = SL * RPU / 4;       // rounds per super-unit; unit u of an SU = (row u / SL, slot u % SL)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: xs[MM][4 pieces][Cp] x 16 bytes (piece j of chunk c at (j * Cp + c) * 16) | red[MM][rows of the block][wk * SL][4]
+    // LDS: xs[MM][4 pieces][Cp + 1] x 16 bytes (piece j of chunk c at (j * (Cp + 1) + c) * 16; chunk Cp = zeros) | scales / zeros | red[MM][rows of the block][wk * SL][4]
     const int lane = threadIdx.x & 63;
     const int wki = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rgi = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -169,6 +169,11 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     const int last_row = p.N - 1;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic segment
     const int sc_off = p.x_bytes + (rgi * p.wk + wki) * (p.sc_pitch + p.z_pitch), z_off = sc_off + p.sc_pitch;
+    // activation planes have a pitch of Cp + 1 chunks: chunk Cp of every plane is ZERO, and a lane without a chunk of its own
+    // (ragged rows) reads that one -- no per-element select in the prologue
+    const int Cq = p.Cp + 1;
+    constexpr int PLANES = 4 * (MM + ((FX & FX_NORM) ? 1 : 0));
+    if (threadIdx.y == 0 && threadIdx.x < PLANES) *reinterpret_cast<u32x4*>(smem + (size_t)((threadIdx.x * Cq + p.Cp) * 16)) = u32x4{0u, 0u, 0u, 0u};
 
     // ---- 1. activations first (they must be in registers when the first weights land): this wave's share of the block's
     //         LDS-DMA copy, piece j of 64 chunks per instruction
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
             for (int jm = rgi; jm < 4 * MM; jm += p.rg) {
                 const int j = jm & 3, m = jm >> 2;
                 const uint32_t src = (uint32_t)((m * p.K + 32 * c + 8 * j) * 2);
-                const uint32_t dst = lds0 + (uint32_t)(((m * 4 + j) * p.Cp + cb * 64) * 16);
+                const uint32_t dst = lds0 + (uint32_t)(((m * 4 + j) * Cq + cb * 64) * 16);
                 AWQ_ROWS_DMA16(src, p.x, dst);
             }
         }
@@ -191,18 +196,21 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
             const int cb = s * p.wk + wki;
             const int c = min(cb * 64 + lane, p.C - 1);
             for (int j = rgi; j < 4; j += p.rg)
-                AWQ_ROWS_DMA16((uint32_t)((32 * c + 8 * j) * 2), p.norm_w, lds0 + (uint32_t)(((MM * 4 + j) * p.Cp + cb * 64) * 16));
+                AWQ_ROWS_DMA16((uint32_t)((32 * c + 8 * j) * 2), p.norm_w, lds0 + (uint32_t)(((MM * 4 + j) * Cq + cb * 64) * 16));
         }
     }
     // ---- 2. scales and zero words of every row this wave will touch: contiguous in this layout, copied as they are
-    if constexpr (!(AWQ_ROWS_DBG & 16)) {
-        const int rows_w = max(min((t0 + nt) * RPU, p.N) - t0 * RPU, 0);
-        const int sc_bytes = rows_w * p.SW * 2, zd = rows_w * p.ZW;
-        const uint32_t sc_src = (uint32_t)(t0 * RPU * p.SW * 2), z_src = (uint32_t)(t0 * RPU * p.ZW * 4);  // byte offsets
-        for (int o = 0; o < sc_bytes; o += 1024)
-            AWQ_ROWS_DMA16(sc_src + (uint32_t)min(o + 16 * lane, sc_bytes - 16), p.scales, lds0 + (uint32_t)(sc_off + o));
-        for (int o = 0; o < zd; o += 64) AWQ_ROWS_DMA4(z_src + 4u * (uint32_t)min(o + lane, zd - 1), p.qzeros, lds0 + (uint32_t)(z_off + 4 * o));
-    }
+    auto issue_scales = [&]() __attribute__((always_inline)) {
+        if constexpr (!(AWQ_ROWS_DBG & 16)) {
+            const int rows_w = max(min((t0 + nt) * RPU, p.N) - t0 * RPU, 0);
+            const int sc_bytes = rows_w * p.SW * 2, zd = rows_w * p.ZW;
+            const uint32_t sc_src = (uint32_t)(t0 * RPU * p.SW * 2), z_src = (uint32_t)(t0 * RPU * p.ZW * 4);  // byte offsets
+            for (int o = 0; o < sc_bytes; o += 1024)
+                AWQ_ROWS_DMA16(sc_src + (uint32_t)min(o + 16 * lane, sc_bytes - 16), p.scales, lds0 + (uint32_t)(sc_off + o));
+            for (int o = 0; o < zd; o += 64) AWQ_ROWS_DMA4(z_src + 4u * (uint32_t)min(o + lane, zd - 1), p.qzeros, lds0 + (uint32_t)(z_off + 4 * o));
+        }
+    };
+    if constexpr (!(AWQ_ROWS_DBG & 128)) issue_scales();
 
     // FX_RES: lane e adds the residual of row e of this wave (at most 64 rows, the launcher checks); requested here, ahead of
     // the ring, so that it has landed long before the fold (a load issued at the fold would expose its whole round trip)
@@ -223,8 +231,8 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
         const int nl = p.lines_base + (ws < p.lines_rem ? 1 : 0);
         const int c = 8 * l0 + lane;
         act[s] = lane < 8 * nl && c < p.C;
-        cidx[s] = act[s] ? c : 0;
-        woff[s] = nl > 0 ? 16u * (uint32_t)cidx[s] : 0u;  // bytes; a slot without lines (padding) reads one 16-byte piece per request
+        cidx[s] = act[s] ? c : p.Cp;  // the zero chunk
+        woff[s] = nl > 0 && act[s] ? 16u * (uint32_t)c : 0u;  // bytes; a lane or slot without weights (padding) reads the row's first 16 bytes
     }
     Round ring[D][R];
     auto request = [&](Round& Rd, int t, int r) {  // round r of SU t of this row group
@@ -240,7 +248,13 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int r = 0; r < R; ++r) request(ring[d][r], d, r);
+        for (int r = 0; r < R; ++r) {
+            request(ring[d][r], d, r);
+            // (experiment 128: scales / zeros right behind the FIRST round -- still older than the R D - 1 rounds every wait
+            // leaves in flight, so they have landed when the first round is consumed)
+            if constexpr (AWQ_ROWS_DBG & 128)
+                if (d == 0 && r == 0) issue_scales();
+        }
     ROWS_STAMP(1);
 
     // ---- 4. off the critical path: lane j of a quad finishes unit 4 r + j of every SU in round r -- that unit's row within
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     const QuadSel sel4{uj == 0 ? ~0u : 0u, uj == 1 ? ~0u : 0u, uj == 2 ? ~0u : 0u};
     int grp[SL];
 #pragma unroll
-    for (int s = 0; s < SL; ++s) grp[s] = (int)__umulhi((uint32_t)(32 * cidx[s]), p.g_magic);
+    for (int s = 0; s < SL; ++s) grp[s] = (int)__umulhi((uint32_t)(32 * min(cidx[s], p.C - 1)), p.g_magic);
     int myslot[R], myrow[R], sc_at[R], z_at[R];
     uint32_t zsh[R];
 #pragma unroll
@@ -276,17 +290,19 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     uint32_t xp[MM][SL][16];
     float c0g[MM][R], sxg[MM][R];
     float inv = 1.f;
+    const u32x2 sum_rows = {(lane & 3) == 0 ? 0x3C003C00u : ((lane & 3) == 1 ? 0x64006400u : 0u),
+                            (lane & 3) == 0 ? 0x3C003C00u : ((lane & 3) == 1 ? 0x54005400u : 0u)};
     if constexpr (FX & FX_NORM) {  // the row statistic: a wave covers the whole row (wk == 1), inactive lanes add nothing
         float ss = 0.f;
 #pragma unroll
         for (int s = 0; s < SL; ++s)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const u32x4 d = *reinterpret_cast<const u32x4*>(smem + (size_t)((j * p.Cp + cidx[s]) * 16));
+                const u32x4 d = *reinterpret_cast<const u32x4*>(smem + (size_t)((j * Cq + cidx[s]) * 16));
                 float q = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) q = dot2(d[i], d[i], q);
-                ss += act[s] ? q : 0.f;
+                ss += q;  // (a lane without a chunk reads the zero chunk)
             }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -295,46 +311,62 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
         float c0s[SL], sxs[SL];
+        // The LDS reads are inline asm, a BATCH of slots at a time behind ONE wait (left to the compiler, the reads of a slot
+        // went out two at a time with a wait after each pair: 0.48 us for 8 reads at K = 4096, 1.28 us at K = 11008, on the
+        // critical path of the launch -- profiles/r03_gemv_rows_trace.txt); the C0 / SX sums run as four independent chains.
+        constexpr int SB = SL <= 3 ? SL : (SL == 8 ? 1 : 2);  // slots per batch: 16 SB registers in flight (SL = 8 has none to spare)
+        static_assert(SL % SB == 0, "batches cover the slots");
 #pragma unroll
-        for (int s = 0; s < SL; ++s) {
-            float se = 0.f, so = 0.f;
-            u32x4 dj[4];
+        for (int s0 = 0; s0 < SL; s0 += SB) {
+            u32x4 dj[SB][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {  // the four LDS reads of a slot are issued together
-                dj[j] = u32x4{0x3C003C00u + lane, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
-                if constexpr (!(AWQ_ROWS_DBG & 2)) dj[j] = *reinterpret_cast<const u32x4*>(smem + (size_t)(((m * 4 + j) * p.Cp + cidx[s]) * 16));
-            }
+            for (int sb = 0; sb < SB; ++sb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32x4 d = dj[j];
-                if constexpr (FX & FX_NORM) {
-                    const u32x4 wv = *reinterpret_cast<const u32x4*>(smem + (size_t)(((MM * 4 + j) * p.Cp + cidx[s]) * 16));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const half2_t a = u2h2(d[i]), gw = u2h2(wv[i]);
-                        half2_t o;
-                        o[0] = (half_t)((float)a[0] * inv * (float)gw[0]);  // == awq_rmsnorm_kernel
-                        o[1] = (half_t)((float)a[1] * inv * (float)gw[1]);
-                        d[i] = h22u(o);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    dj[sb][j] = u32x4{0x3C003C00u + lane, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+                    if constexpr (!(AWQ_ROWS_DBG & 2))
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(dj[sb][j]) : "v"(lds0 + (uint32_t)(((m * 4 + j) * Cq + cidx[s0 + sb]) * 16)));
                 }
-                if (!act[s]) d = u32x4{0u, 0u, 0u, 0u};
-                xp[m][s][4 * j + 0] = __builtin_amdgcn_perm(d[2], d[0], 0x05040100u);  // (x0, x4)  bias 1024
-                xp[m][s][4 * j + 1] = __builtin_amdgcn_perm(d[2], d[0], 0x07060302u);  // (x1, x5)  bias 64
-                xp[m][s][4 * j + 2] = __builtin_amdgcn_perm(d[3], d[1], 0x05040100u);  // (x2, x6)  bias 1024
-                xp[m][s][4 * j + 3] = __builtin_amdgcn_perm(d[3], d[1], 0x07060302u);  // (x3, x7)  bias 64
-                se = dot2(xp[m][s][4 * j + 0], 0x3C003C00u, se);
-                so = dot2(xp[m][s][4 * j + 1], 0x3C003C00u, so);
-                se = dot2(xp[m][s][4 * j + 2], 0x3C003C00u, se);
-                so = dot2(xp[m][s][4 * j + 3], 0x3C003C00u, so);
+            if constexpr (!(AWQ_ROWS_DBG & 2)) {
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb)  // (LDS operations return in order: the first wait covers every read of the batch)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dj[sb][0]), "+v"(dj[sb][1]), "+v"(dj[sb][2]), "+v"(dj[sb][3]));
             }
-            float c0 = 1024.f * se + 64.f * so, sx = se + so;
-            c0 += dpp_mov<0xB1>(c0);  // quad_perm [1,0,3,2]
-            sx += dpp_mov<0xB1>(sx);
-            c0 += dpp_mov<0x4E>(c0);  // quad_perm [2,3,0,1]
-            sx += dpp_mov<0x4E>(sx);
-            c0s[s] = c0;
-            sxs[s] = sx;
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                const int s = s0 + sb;
+                float4_t sums = {0.f, 0.f, 0.f, 0.f};  // [0] = sum x, [1] = sum bias * x of this lane's 32 activations
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u32x4 d = dj[sb][j];
+                    if constexpr (FX & FX_NORM) {
+                        const u32x4 wv = *reinterpret_cast<const u32x4*>(smem + (size_t)(((MM * 4 + j) * Cq + cidx[s]) * 16));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const half2_t a = u2h2(d[i]), gw = u2h2(wv[i]);
+                            half2_t o;
+                            o[0] = (half_t)((float)a[0] * inv * (float)gw[0]);  // == awq_rmsnorm_kernel
+                            o[1] = (half_t)((float)a[1] * inv * (float)gw[1]);
+                            d[i] = h22u(o);
+                        }
+                    }
+                    xp[m][s][4 * j + 0] = __builtin_amdgcn_perm(d[2], d[0], 0x05040100u);  // (x0, x4)  bias 1024
+                    xp[m][s][4 * j + 1] = __builtin_amdgcn_perm(d[2], d[0], 0x07060302u);  // (x1, x5)  bias 64
+                    xp[m][s][4 * j + 2] = __builtin_amdgcn_perm(d[3], d[1], 0x05040100u);  // (x2, x6)  bias 1024
+                    xp[m][s][4 * j + 3] = __builtin_amdgcn_perm(d[3], d[1], 0x07060302u);  // (x3, x7)  bias 64
+                    // the group constants off the VALU: a 4x4x4 MFMA whose A rows are (1, 1, 1, 1) [lane 0 of the quad] and
+                    // (1024, 1024, 64, 64) [lane 1] leaves sum x in register 0 and sum bias * x in register 1 of every lane
+                    sums = mfma4(sum_rows, u32x2{xp[m][s][4 * j + 0], xp[m][s][4 * j + 1]}, sums);
+                    sums = mfma4(sum_rows, u32x2{xp[m][s][4 * j + 2], xp[m][s][4 * j + 3]}, sums);
+                }
+                float c0 = sums[1], sx = sums[0];
+                c0 += dpp_mov<0xB1>(c0);  // quad_perm [1,0,3,2]
+                sx += dpp_mov<0xB1>(sx);
+                c0 += dpp_mov<0x4E>(c0);  // quad_perm [2,3,0,1]
+                sx += dpp_mov<0x4E>(sx);
+                c0s[s] = c0;
+                sxs[s] = sx;
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -541,12 +573,21 @@ int launch_rows(const RowsParams& p, int blocks, size_t lds, hipStream_t st) {
 // the decoder-block variants (batch 1): every (SL, D) of the plain kernel x {norm, residual, norm + residual, silu pairs, norm + silu pairs}
 template <int SL, int D>
 int launch_rows_fx(int fx, const RowsParams& p, int blocks, size_t lds, hipStream_t st) {
+    if constexpr (SL == 8) {  // K > 12288: 128 activation registers leave no room for the norm's temporaries (it would spill)
+        if (fx & FX_NORM) return AWQ_ERR_UNSUPPORTED;
+    }
     switch (fx) {
-        case FX_NORM: return launch_rows<SL, D, 1, FX_NORM>(p, blocks, lds, st);
+        case FX_NORM:
+            if constexpr (SL != 8) return launch_rows<SL, D, 1, FX_NORM>(p, blocks, lds, st);
+            return AWQ_ERR_UNSUPPORTED;
         case FX_RES: return launch_rows<SL, D, 1, FX_RES>(p, blocks, lds, st);
-        case FX_NORM | FX_RES: return launch_rows<SL, D, 1, FX_NORM | FX_RES>(p, blocks, lds, st);
+        case FX_NORM | FX_RES:
+            if constexpr (SL != 8) return launch_rows<SL, D, 1, FX_NORM | FX_RES>(p, blocks, lds, st);
+            return AWQ_ERR_UNSUPPORTED;
         case FX_PAIRS: return launch_rows<SL, D, 1, FX_PAIRS>(p, blocks, lds, st);
-        case FX_NORM | FX_PAIRS: return launch_rows<SL, D, 1, FX_NORM | FX_PAIRS>(p, blocks, lds, st);
+        case FX_NORM | FX_PAIRS:
+            if constexpr (SL != 8) return launch_rows<SL, D, 1, FX_NORM | FX_PAIRS>(p, blocks, lds, st);
+            return AWQ_ERR_UNSUPPORTED;
         default: return AWQ_ERR_UNSUPPORTED;
     }
 }
@@ -649,7 +690,7 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_rows_trace;
 #endif
-    p.x_bytes = (M + ((fx & FX_NORM) ? 1 : 0)) * 4 * p.Cp * 16;
+    p.x_bytes = (M + ((fx & FX_NORM) ? 1 : 0)) * 4 * (p.Cp + 1) * 16;  // chunk Cp of every plane is the zero chunk
     p.sc_pitch = (p.su_max * RPU * p.SW * 2 + 1023) / 1024 * 1024;
     p.z_pitch = (p.su_max * RPU * p.ZW * 4 + 255) / 256 * 256;
     const size_t lds = (size_t)p.x_bytes + (size_t)p.rg * p.wk * (p.sc_pitch + p.z_pitch) +

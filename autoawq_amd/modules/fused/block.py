@@ -64,8 +64,10 @@ class LlamaLikeBlock(nn.Module):
             return False
         # what awq_gemv_forward_ex takes (include/awq_hip.h): a wave covers whole rows (K <= 16384), groups of 128 k, and with a
         # residual at most 64 rows per wave; every projection of the block must qualify, or the block runs the separate launches
-        return all(l.in_features <= 16384 and l.group_size % 128 == 0 and l.out_features <= 65536 and l.in_features >= 128
-                   for l in (a.qkv_proj, a.o_proj, m.down_proj)) and 2 * m.intermediate_size <= 131072
+        # (the norm prologue, which qkv and gate|up carry, stops at K = 12288: eight 1-KiB slots per wave leave no registers for it)
+        return (all(l.in_features <= 16384 and l.group_size % 128 == 0 and l.out_features <= 65536 and l.in_features >= 128
+                    for l in (a.qkv_proj, a.o_proj, m.down_proj)) and 2 * m.intermediate_size <= 131072
+                and a.qkv_proj.in_features <= 12288 and m.in_features <= 12288)
 
     def _forward_stream_gemv(self, h):
         B, S, H = h.shape

@@ -304,7 +304,8 @@ AWQ_EXPORT int awq_gemm_forward_ex(const AwqGemmEx* args);
  *   AWQ_GEMV_EX_SILU_PAIRS (flags)  rows (2 i, 2 i + 1) of the matrix are (gate_i, up_i) (the caller interleaved the gate and
  *                         up projections' rows); y [N / 2] = fp16(silu(fp16 gate) * fp16 up), == awq_silu_and_mul on the
  *                         unfused outputs.  Not together with add_residual.
- * Served by the row-streaming kernel only: M == 1 and K <= 16384 (a wave covers whole rows), group_size % 128 == 0, and with
+ * Served by the row-streaming kernel only: M == 1 and K <= 16384 (a wave covers whole rows; K <= 12288 with norm_weight),
+ * group_size % 128 == 0, and with
  * add_residual at most 64 rows per wave (N <= 65536); AWQ_ERR_UNSUPPORTED otherwise -- the caller then runs the separate
  * launches.  Unused fields are 0 / NULL. */
 #define AWQ_GEMV_EX_SILU_PAIRS 1u

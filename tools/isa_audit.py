@@ -117,6 +117,9 @@ def audit_inflight_regs(src):
             i = j
         i += 1
     checked, bad = 0, []
+    for k, t in enumerate(lines):  # scratch traffic (spills) counts in vmcnt and would break the counted waits
+        if t.startswith(("scratch_", "buffer_store_dword v", "buffer_load_dword v")) and "Spill" in t or t.startswith("scratch_"):
+            bad.append((k + 1, "scratch access: " + t))
     for start, (end, kind, dst) in blocks.items():
         if kind != "request":
             continue

@@ -19,7 +19,7 @@ L = _lib.lib()
 L.awq_debug_set_trace_rows.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda")
 gen = torch.Generator(device=dev).manual_seed(0)
-cases = [(4096, 4096, 8, 1, 1, 1), (4096, 12288, 8, 1, 1, 1), (4096, 22016, 8, 2, 1, 1), (11008, 4096, 8, 1, 1, 1)]
+cases = [(4096, 4096, 0, 0, 0, 1), (4096, 12288, 0, 0, 0, 1), (4096, 22016, 0, 0, 0, 1), (11008, 4096, 0, 0, 0, 1)]  # 0 = the launcher's defaults
 if os.environ.get("CASES"):
     cases = [tuple(int(v) for v in c.split(",")) for c in os.environ["CASES"].split(";")]
 for (K, N, wv, dp, bpc, M) in cases:
