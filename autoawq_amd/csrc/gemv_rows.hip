@@ -74,6 +74,7 @@ struct RowsParams {
     float norm_eps;
     const half_t* res;          // FX_RES: y := fp16(fp16(W x) + res), the two roundings of the unfused add
     int su_gran;                // super-units are dealt in multiples of this (2: row PAIRS never straddle two waves)
+    int sc_regs;                // a wave's scales (<= 1 KiB) and zero words (<= 64) travel through registers, not LDS-DMA
 };
 
 // FX bits of the kernel template
@@ -200,14 +201,25 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
         }
     }
     // ---- 2. scales and zero words of every row this wave will touch: contiguous in this layout, copied as they are
+    // (When a wave's share is at most 1 KiB of scales and 64 zero words -- every 7B / 70B decode shape -- it travels through two
+    // REGISTERS instead: one 16-byte and one 4-byte load per lane, written to the wave's LDS region once they have landed.)
+    u32x4 scv;    // (deliberately not initialised: a zeroing move on the other path would sit between request and wait)
+    uint32_t zv;
     auto issue_scales = [&]() __attribute__((always_inline)) {
         if constexpr (!(AWQ_ROWS_DBG & 16)) {
             const int rows_w = max(min((t0 + nt) * RPU, p.N) - t0 * RPU, 0);
             const int sc_bytes = rows_w * p.SW * 2, zd = rows_w * p.ZW;
             const uint32_t sc_src = (uint32_t)(t0 * RPU * p.SW * 2), z_src = (uint32_t)(t0 * RPU * p.ZW * 4);  // byte offsets
-            for (int o = 0; o < sc_bytes; o += 1024)
-                AWQ_ROWS_DMA16(sc_src + (uint32_t)min(o + 16 * lane, sc_bytes - 16), p.scales, lds0 + (uint32_t)(sc_off + o));
-            for (int o = 0; o < zd; o += 64) AWQ_ROWS_DMA4(z_src + 4u * (uint32_t)min(o + lane, zd - 1), p.qzeros, lds0 + (uint32_t)(z_off + 4 * o));
+            if (p.sc_regs) {
+                const uint32_t so = sc_bytes > 0 ? sc_src + (uint32_t)min(16 * lane, sc_bytes - 16) : 0u;
+                const uint32_t zo = zd > 0 ? z_src + 4u * (uint32_t)min(lane, zd - 1) : 0u;
+                asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dword %1, %3, %5"
+                             : "=&v"(scv), "=&v"(zv) : "v"(so), "v"(zo), "s"(p.scales), "s"(p.qzeros) : "memory");
+            } else {
+                for (int o = 0; o < sc_bytes; o += 1024)
+                    AWQ_ROWS_DMA16(sc_src + (uint32_t)min(o + 16 * lane, sc_bytes - 16), p.scales, lds0 + (uint32_t)(sc_off + o));
+                for (int o = 0; o < zd; o += 64) AWQ_ROWS_DMA4(z_src + 4u * (uint32_t)min(o + lane, zd - 1), p.qzeros, lds0 + (uint32_t)(z_off + 4 * o));
+            }
         }
     };
     if constexpr (!(AWQ_ROWS_DBG & 128)) issue_scales();
@@ -278,8 +290,13 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     const int sc_step = RPU * p.SW * 2, z_step = RPU * p.ZW * 4;
 
     // ---- 5. the DMA pieces have landed (they are older than the ring); the activations are shared by the block
-    if constexpr (FX & FX_RES) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(resv) : "n"(AWQ_ROWS_LPR * R * D) : "memory");
-    else if constexpr (!(AWQ_ROWS_DBG & 2) || !(AWQ_ROWS_DBG & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AWQ_ROWS_LPR * R * D) : "memory");
+    asm volatile("s_waitcnt vmcnt(%3) ; releases %0 %1 %2" : "+v"(resv), "+v"(scv), "+v"(zv) : "n"(AWQ_ROWS_LPR * R * D) : "memory");
+    if constexpr (!(AWQ_ROWS_DBG & 16)) {
+        if (p.sc_regs) {  // the wave's own LDS region: its later reads follow these writes in order, no barrier needed
+            *reinterpret_cast<u32x4*>(smem + sc_off + 16 * lane) = scv;
+            *reinterpret_cast<uint32_t*>(smem + z_off + 4 * lane) = zv;
+        }
+    }
     if constexpr (!(AWQ_ROWS_DBG & 2)) __builtin_amdgcn_s_barrier();
     ROWS_STAMP(2);
 
@@ -393,6 +410,14 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #ifdef AWQ_GEMV_TRACE
                 if (t == 0 && r == 0) ROWS_STAMP(4);
 #endif
+                // this round's scale and zero word are requested from LDS NOW (left to the compiler the two reads sat behind the
+                // last MFMA with a wait right after them: a full LDS round trip per round, 0.4-0.8 us per launch)
+                uint32_t scl_raw = 0x3C00u, z_raw = 0u;
+                if constexpr (!(AWQ_ROWS_DBG & 16))
+                    asm volatile("ds_read_u16 %0, %2\n\tds_read_b32 %1, %3"
+                                 : "=&v"(scl_raw), "=&v"(z_raw)
+                                 : "v"(lds0 + (uint32_t)(sc_at[r] + t * sc_step)), "v"(lds0 + (uint32_t)(z_at[r] + t * z_step))
+                                 : "memory");
                 float pu[MM][4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -442,11 +467,9 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #pragma unroll
                     for (int m = 0; m < MM; ++m) pu[m][u] = pa[m] + pb[m];
                 }
-                float scl = 1.f, zf = 0.f;
-                if constexpr (!(AWQ_ROWS_DBG & 16)) {
-                    scl = (float)*reinterpret_cast<const half_t*>(smem + sc_at[r] + t * sc_step);
-                    zf = (float)((*reinterpret_cast<const uint32_t*>(smem + z_at[r] + t * z_step) >> zsh[r]) & 15u);
-                }
+                if constexpr (!(AWQ_ROWS_DBG & 16)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(scl_raw), "+v"(z_raw));
+                const float scl = (float)__builtin_bit_cast(half_t, (unsigned short)scl_raw);
+                const float zf = (float)((z_raw >> zsh[r]) & 15u);
                 // every value derived from the round exists before the round is requested again: the old contents are dead
                 // at the request, so the round keeps its registers (no copy of a register with a load in flight)
 #pragma unroll
@@ -691,6 +714,7 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     p.trace = g_rows_trace;
 #endif
     p.x_bytes = (M + ((fx & FX_NORM) ? 1 : 0)) * 4 * (p.Cp + 1) * 16;  // chunk Cp of every plane is the zero chunk
+    p.sc_regs = (AWQ_ROWS_DBG & 256) ? 0 : (p.su_max * RPU * p.SW * 2 <= 1024 && p.su_max * RPU * p.ZW <= 64);
     p.sc_pitch = (p.su_max * RPU * p.SW * 2 + 1023) / 1024 * 1024;
     p.z_pitch = (p.su_max * RPU * p.ZW * 4 + 255) / 256 * 256;
     const size_t lds = (size_t)p.x_bytes + (size_t)p.rg * p.wk * (p.sc_pitch + p.z_pitch) +

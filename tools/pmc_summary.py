@@ -30,19 +30,20 @@ if len(sys.argv) > 2:
             print(f"  {k}: {sorted(v)[len(v) // 2]:.0f} KiB reported for 8192 KiB read -> factor {8192 / sorted(v)[len(v) // 2]:.3f} (n={len(v)})")
 shapes = {"qkv 4096->12288": (HIDDEN, 3 * HIDDEN), "o 4096->4096": (HIDDEN, HIDDEN), "gate+up 4096->22016": (HIDDEN, 2 * INTER),
           "down 11008->4096": (INTER, HIDDEN)}
-by_grid = collections.defaultdict(list)
-for r in rows(sys.argv[1]):
+by_shape = collections.defaultdict(list)  # every dispatch is matched to the shape whose algorithmic bytes are closest to its traffic
+for r in rows(sys.argv[1]):                # (the row-streaming kernel launches o and qkv with the same grid and template arguments)
     if KERNEL in r["Kernel_Name"]:
         targs = r["Kernel_Name"].split("<")[1].split(">")[0] if "<" in r["Kernel_Name"] else ""
-        by_grid[(int(r["Grid_Size"]), int(r["Workgroup_Size"]), targs)].append(float(r["Counter_Value"]))
-print(f"\nbench.py decode kernels ({KERNEL}), traffic = FETCH_SIZE x {factor:.0f} x 1024 B; by grid size (threads):")
+        t = float(r["Counter_Value"]) * factor * 1024
+        name = min(shapes, key=lambda k: abs(algorithmic_bytes(shapes[k][0], shapes[k][1], 1, GROUP) - t))
+        by_shape[(name, int(r["Grid_Size"]), int(r["Workgroup_Size"]), targs)].append(t)
+print(f"\nbench.py decode kernels ({KERNEL}), traffic = FETCH_SIZE x {factor:.0f} x 1024 B; by shape (grid size in threads):")
 tot_t = tot_a = n = 0
-for g, v in sorted(by_grid.items()):
-    med = sorted(v)[len(v) // 2] * factor * 1024
-    # which shape: blocks = tiles * S; match by algorithmic bytes closest to the traffic
-    name, (K, N) = min(shapes.items(), key=lambda kv: abs(algorithmic_bytes(kv[1][0], kv[1][1], 1, GROUP) - med))
+for g, v in sorted(by_shape.items()):
+    med = sorted(v)[len(v) // 2]
+    K, N = shapes[g[0]]
     alg = algorithmic_bytes(K, N, 1, GROUP)
-    print(f"  grid {g[0]:7d} wg {g[1]:3d} <{g[2]}>: traffic {med / 1e6:8.3f} MB  ~ {name:22s} algorithmic {alg / 1e6:8.3f} MB  ratio {med / alg:5.3f}  (n={len(v)})")
+    print(f"  {g[0]:22s} grid {g[1]:7d} wg {g[2]:3d} <{g[3]}>: traffic {med / 1e6:8.3f} MB  algorithmic {alg / 1e6:8.3f} MB  ratio {med / alg:5.3f}  (n={len(v)})")
     tot_t += med * len(v); tot_a += alg * len(v); n += len(v)
 if n:
     print(f"\nper launch (weighted mean): traffic {tot_t / n / 1e6:.3f} MB, algorithmic {tot_a / n / 1e6:.3f} MB, ratio {tot_t / tot_a:.3f}")

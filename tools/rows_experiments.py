@@ -12,7 +12,8 @@ CSRC = os.path.join(ROOT, "autoawq_amd", "csrc")
 VARIANTS = [(0, "the kernel"), (64, "dot products on the VALU (v_dot2c) instead of MFMA 4x4x4"), (1, "no decode / dot products"),
             (2, "no x DMA / barrier"), (4, "no scale / transpose-reduce"), (8, "no final fold"), (16, "no scale / zero loads"),
             (32, "x requested after the first weights"), (31, "1+2+4+8+16 (weight requests + waits + LDS partials)"),
-            (128, "scales / zeros requested behind the first round instead of ahead of the ring")]
+            (128, "scales / zeros requested behind the first round instead of ahead of the ring"),
+            (256, "scales / zeros by LDS-DMA even when they fit two registers per lane")]
 
 
 def so(bits):
