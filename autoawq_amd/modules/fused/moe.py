@@ -18,7 +18,11 @@ from ... import ops
 BLOCK_ROWS = 16        # token rows per grouped-GEMM block (moe.py:55: moe_align_block_size(topk_ids, 16, E))
 DECODE_BLOCK_ROWS = 8  # decode-sized batches: 8-row blocks run the selector-row kernel (one MFMA per fragment)
 DECODE_MAX_PAIRS = 64
-FUSE_ACTIVATION_INTO_W2 = True
+# silu(gate) * up applied by the w2 grouped GEMM while it stages its activations (awq_grouped_gemm_forward_ex,
+# AWQ_GEMM_FLAG_X_GATED_SILU): one launch and one [pairs, I] round trip less, bit-identical -- but every one of the 16 column
+# tiles of w2 re-evaluates the activation for its K slice, and at Mixtral's bs = 4 that costs more than the launch it saves
+# (144 us per block against 133 us: tools/dbg_moe_ab.py, profiles/r03_moe_silu_fold_ab.txt).  Off by default.
+FUSE_ACTIVATION_INTO_W2 = False
 
 
 class FusedSparseMoeBlock(torch.nn.Module):
