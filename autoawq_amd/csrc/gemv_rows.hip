@@ -65,6 +65,10 @@ struct RowsParams {
     int su_total;               // super-units of the matrix: ceil(N / RPU)
     int su_base, su_rem;        // super-units per row group, in units of su_gran: base (+1 for the first rem groups)
     int su_max;                 // most SUs any row group gets
+    // (these two sit HERE, inside the run of fields the prologue reads first: at the end of the struct they were fetched by a
+    // second, dependent scalar load in the middle of the prologue)
+    int su_gran;                // super-units are dealt in multiples of this (2: row PAIRS never straddle two waves)
+    int sc_regs;                // a wave's scales (<= 1 KiB) and zero words (<= 64) travel through registers, not LDS-DMA
     int x_bytes;                // LDS: activations [MM][4][Cp] x 16 bytes
     int sc_pitch, z_pitch;      // LDS per wave: its rows' scales (whole KiB) and zero words (whole 256 bytes)
     uint32_t g_magic;           // (k * g_magic) >> 32 == k / g
@@ -73,8 +77,6 @@ struct RowsParams {
     const half_t* norm_w;       // FX_NORM: x := fp16(x * rsqrt(mean(x^2) + eps) * norm_w), == awq_rmsnorm_kernel's arithmetic
     float norm_eps;
     const half_t* res;          // FX_RES: y := fp16(fp16(W x) + res), the two roundings of the unfused add
-    int su_gran;                // super-units are dealt in multiples of this (2: row PAIRS never straddle two waves)
-    int sc_regs;                // a wave's scales (<= 1 KiB) and zero words (<= 64) travel through registers, not LDS-DMA
 };
 
 // FX bits of the kernel template
