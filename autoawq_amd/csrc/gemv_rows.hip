@@ -181,6 +181,15 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     // ---- 1. activations first (they must be in registers when the first weights land): this wave's share of the block's
     //         LDS-DMA copy, piece j of 64 chunks per instruction
     if constexpr (!(AWQ_ROWS_DBG & 2)) {
+        if (p.rg == 4 * MM) {  // the usual shape (4 waves, batch 1): every wave moves exactly ONE piece per slot -- no loop, no
+#pragma unroll                 // scalar bookkeeping ahead of the first requests
+            for (int s = 0; s < SL; ++s) {
+                const int cb = s * p.wk + wki;
+                const int c = min(cb * 64 + lane, p.C - 1);
+                const int j = rgi & 3, m = rgi >> 2;
+                AWQ_ROWS_DMA16((uint32_t)((m * p.K + 32 * c + 8 * j) * 2), p.x, lds0 + (uint32_t)(((m * 4 + j) * Cq + cb * 64) * 16));
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < SL; ++s) {
             const int cb = s * p.wk + wki;
