@@ -704,19 +704,32 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     p.su_total = (N + RPU - 1) / RPU;
     p.su_gran = (fx & FX_PAIRS) && RPU == 1 ? 2 : 1;  // a (gate, up) row pair stays with one wave
     const int su_units = p.su_total / p.su_gran;      // N is even with pairs
-    if (bpc <= 0) bpc = p.su_total > 8 * 256 * p.rg ? 2 : 1;
-    int blocks = 256 * bpc;
-    const int max_blocks = (su_units + p.rg - 1) / p.rg;  // at least one SU per row group
-    if (blocks > max_blocks) blocks = max_blocks;
-    const int groups = blocks * p.rg;
-    p.su_base = su_units / groups;
-    p.su_rem = su_units % groups;
-    p.su_max = (p.su_base + (p.su_rem ? 1 : 0)) * p.su_gran;
+    const bool bpc_auto = bpc <= 0;
+    if (bpc_auto) bpc = p.su_total > 8 * 256 * p.rg ? 2 : 1;
+    const bool one_round = SL * RPU == 4;
+    int blocks = 0;
+    auto partition = [&](int per_cu) {
+        blocks = 256 * per_cu;
+        const int max_blocks = (su_units + p.rg - 1) / p.rg;  // at least one SU per row group
+        if (blocks > max_blocks) blocks = max_blocks;
+        const int groups = blocks * p.rg;
+        p.su_base = su_units / groups;
+        p.su_rem = su_units % groups;
+        p.su_max = (p.su_base + (p.su_rem ? 1 : 0)) * p.su_gran;
+    };
+    partition(bpc);
+    // Two super-units in flight per wave need an even count in EVERY row group (one straight-line drain).  Where the rows do
+    // not divide that way (4096 x 11008: 5504 super-units over 1024 row groups) the same bytes stay in flight through two
+    // blocks per CU with one super-unit each instead (7.0 us; one block per CU and one in flight: 8.0).
+    if (bpc_auto && bpc == 1 && (depth < 1 || depth > 2) && one_round && p.su_max >= 2 && p.su_max <= 8 &&
+        (p.su_rem != 0 || (p.su_base * p.su_gran) % 2)) {
+        bpc = 2;
+        partition(bpc);
+    }
     if ((fx & FX_RES) && p.su_max * RPU > 64) return AWQ_ERR_UNSUPPORTED;  // one residual element per lane
     p.norm_w = fxa ? reinterpret_cast<const half_t*>(fxa->norm_w) : nullptr;
     p.norm_eps = fxa ? fxa->norm_eps : 0.f;
     p.res = fxa ? reinterpret_cast<const half_t*>(fxa->res) : nullptr;
-    const bool one_round = SL * RPU == 4;
     if (depth < 1 || depth > 2) depth = p.su_max >= 2 && p.su_max <= 8 && bpc == 1 && one_round ? 2 : 1;
     if (!one_round || (SL == 4 && M > 1) || (SL == 2 && M > 3)) depth = 1;  // instantiated combinations (register budget)
     if (p.su_rem != 0 || (p.su_base * p.su_gran) % 2) depth = 1;  // two in flight only when every row group gets an even count
