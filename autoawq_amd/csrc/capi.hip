@@ -354,6 +354,18 @@ int awq_grouped_gemm_forward_ex(const uint16_t* x, const int32_t* qweight, const
 
 /* ---- GEMV layout ------------------------------------------------------------------------- */
 
+// Which kernel awq_gemv_forward's AUTO dispatch takes (host only, no launch): the row-streaming kernel at batch 1, and at batch 2
+// while a wave still covers whole rows (K <= 6144: profiles/r03_gemv_rows_sweep.txt); the LDS-streaming MFMA kernel from five
+// batch rows on matrices of 8192 rows and more (4096 x 11008, M = 8: 11.6 us vs 19.0 for the tile kernel; 4096 x 22016: 16.7 vs
+// 35.7; below that the tile kernel is level or ahead); the 16-row MFMA tile kernel otherwise.  -1: no kernel takes the shape.
+int awq_gemv_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size) {
+    if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0 || K % group_size || K % 8 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return -1;
+    const int m = (int)M, k = (int)K, n = (int)N, g = (int)group_size;
+    if ((M == 1 || (M == 2 && K <= 6144)) && awq_gemv_rows_supports(m, k, n, g)) return (int)AWQ_GEMV_KERNEL_ROWS;
+    if (M >= 5 && N >= 8192 && awq_gemv_lds_supports(m, k, n, g)) return (int)AWQ_GEMV_KERNEL_LDS;
+    return awq_gemv_nk_supports(m, k, n, g) ? (int)AWQ_GEMV_KERNEL_TILE16 : -1;
+}
+
 int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                      uint16_t* y, int64_t M, int64_t K, int64_t N, int64_t group_size, int64_t zeros_width,
                      uint32_t flags, void* stream) {
@@ -364,11 +376,9 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     if (!x || !qweight || !scales || !qzeros || !y) return AWQ_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales)) return AWQ_ERR_BAD_ALIGNMENT;
     const uint32_t kern = AWQ_GEMM_FLAG_KERNEL(flags);
-    // AUTO: the row-streaming kernel at batch 1, and at batch 2 while a wave still covers whole rows (K <= 6144); the
-    // 16-row MFMA tile kernel otherwise (profiles/r03_gemv_rows_sweep.txt)
-    const bool rows_auto = M == 1 || (M == 2 && K <= 6144);
-    if ((kern == AWQ_GEMV_KERNEL_ROWS || (kern == AWQ_GEMV_KERNEL_AUTO && rows_auto)) &&
-        awq_gemv_rows_supports((int)M, (int)K, (int)N, (int)group_size)) {
+    const int auto_k = kern == AWQ_GEMV_KERNEL_AUTO ? awq_gemv_auto_kernel(M, K, N, group_size) : -1;
+    if ((kern == AWQ_GEMV_KERNEL_ROWS && awq_gemv_rows_supports((int)M, (int)K, (int)N, (int)group_size)) ||
+        auto_k == (int)AWQ_GEMV_KERNEL_ROWS) {
         g_last_kernel = "gemv_rows";
         return awq_launch_gemv_rows(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,
                                     (int)AWQ_GEMM_FLAG_WAVES(flags), (int)AWQ_GEMM_FLAG_UNIT(flags),
@@ -376,11 +386,8 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
                                     static_cast<hipStream_t>(stream));
     }
     if (kern == AWQ_GEMV_KERNEL_ROWS) return AWQ_ERR_UNSUPPORTED;
-    // AUTO: the LDS-streaming MFMA kernel from five batch rows on matrices of 8192 rows and more (4096 x 11008, M = 8: 11.6 us
-    // vs 19.0 for the tile kernel; 4096 x 22016: 16.7 vs 35.7); below that the tile kernel is level or ahead
-    const bool lds_auto = M >= 5 && N >= 8192;
-    if ((kern == AWQ_GEMV_KERNEL_LDS || (kern == AWQ_GEMV_KERNEL_AUTO && lds_auto)) &&
-        awq_gemv_lds_supports((int)M, (int)K, (int)N, (int)group_size)) {
+    if ((kern == AWQ_GEMV_KERNEL_LDS && awq_gemv_lds_supports((int)M, (int)K, (int)N, (int)group_size)) ||
+        auto_k == (int)AWQ_GEMV_KERNEL_LDS) {
         g_last_kernel = "gemv_lds";
         return awq_launch_gemv_lds(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,
                                    (int)AWQ_GEMM_FLAG_SPLITK(flags), (int)AWQ_GEMM_FLAG_UNIT(flags), static_cast<hipStream_t>(stream));

@@ -178,6 +178,9 @@ AWQ_EXPORT int awq_grouped_gemm_forward_ex(const uint16_t* x, const int32_t* qwe
 #define AWQ_GEMV_KERNEL_TILE16 1u /* 16 rows per block through v_mfma_f32_16x16x32_f16, M <= 16 */
 #define AWQ_GEMV_KERNEL_ROWS 2u   /* row-streaming kernel (1 KiB of one row per wave instruction, activations in registers), M <= 4 */
 #define AWQ_GEMV_KERNEL_LDS 3u    /* weights through LDS by DMA into MFMA 16x16x32, 2 <= M <= 16 with M K <= 32768; _SPLITK: waves per tile */
+/* Which AWQ_GEMV_KERNEL_* the AUTO dispatch of awq_gemv_forward takes for this shape (host only; -1: none takes it).  A pure
+ * function of its arguments -- what awq_hip_last_kernel (a per-thread diagnostic) reports after the call. */
+AWQ_EXPORT int awq_gemv_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size);
 AWQ_EXPORT int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
                                 const int32_t* qzeros, uint16_t* y, int64_t M, int64_t K, int64_t N,
                                 int64_t group_size, int64_t zeros_width, uint32_t flags, void* stream);
