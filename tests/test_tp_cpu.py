@@ -235,6 +235,50 @@ def test_row_parallel_forward_and_layer_sharding_world2_gloo():
         assert r["gemm"][4] == ((0, 512) if rank == 0 else (512, 896))   # 7 groups over 2 ranks: 4 + 3
 
 
+def test_row_parallel_collective_argument_and_missing_process_group(monkeypatch):
+    """`RowParallelWQLinear(collective=...)`: a decode-sized output goes through the given collective (the role of
+    autoawq_amd.comm.OneShotAllReduce), anything it cannot take falls back to the process group, and with NEITHER the forward
+    raises instead of returning this rank's partial sum.  In process, two ranks one after the other; the per-shard
+    arithmetic is the oracle's."""
+    from autoawq_amd import WQLinear_GEMM, tp
+
+    monkeypatch.setattr(WQLinear_GEMM, "forward", _oracle_forward_gemm)
+    gen = torch.Generator().manual_seed(4)
+    lim, K, N, g = 0x7FFFFFFF, 512, 64, 128
+    full = WQLinear_GEMM(4, g, K, N, False, "cpu")
+    full.qweight = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, generator=gen)
+    full.qzeros = torch.randint(-lim - 1, lim, (K // g, N // 8), dtype=torch.int32, generator=gen)
+    full.scales = (torch.rand((K // g, N), generator=gen) * 0.02 + 0.005).half()
+    x = torch.randn((1, K), generator=gen).half()
+    want = _oracle_forward_gemm(full, x).float()
+
+    class SumWithPeer:  # stands in for the one-shot all-reduce: adds the other rank's partial in place
+        max_halfs = 64
+
+        def __init__(self):
+            self.calls, self.peer = 0, None
+
+        def __call__(self, y):
+            self.calls += 1
+            y += self.peer
+            return y
+
+    ar = SumWithPeer()
+    r0 = tp.RowParallelWQLinear(full, 0, 2, collective=ar)
+    r1 = tp.RowParallelWQLinear(full, 1, 2, collective=ar)
+    ar.peer = r1.shard(x[:, r1.bounds[0]:r1.bounds[1]])
+    got = r0(x[:, r0.bounds[0]:r0.bounds[1]]).float()
+    assert ar.calls == 1
+    assert float((got - want).abs().max()) <= 4e-3 * float(want.abs().max())
+    # an output the collective cannot take (more elements than its buffers) needs the process group: none here -> error
+    ar.max_halfs = 32
+    with pytest.raises(RuntimeError, match="partial sum"):
+        r0(x[:, r0.bounds[0]:r0.bounds[1]])
+    with pytest.raises(RuntimeError, match="partial sum"):
+        tp.RowParallelWQLinear(full, 0, 2)(x[:, r0.bounds[0]:r0.bounds[1]])
+    assert tp.RowParallelWQLinear(full, 0, 1)(x).shape == (1, N)  # world 1: no collective involved
+
+
 def test_gemv_layout_row_shard_repacks_zero_width(oracle):
     """A GEMV-layout row shard re-pads its zero points / scales to the SHARD's zeros width (11008 rows -> 11 words;
     a 1408-row shard -> 2): dequantising the shard gives exactly the rows of the full matrix."""
