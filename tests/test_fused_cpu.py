@@ -116,3 +116,35 @@ def test_fused_mlp_keeps_one_copy_of_gate_up():
     other.up_proj_qweight = new_up
     assert torch.equal(other._gate_up_fused()[0], torch.cat([gq, new_up], 1))
     assert other.up_proj_qweight.untyped_storage().data_ptr() == other._gate_up_fused()[0].untyped_storage().data_ptr()
+
+
+def test_fused_mlp_gate_up_pairs_interleave_rows_gemv_layout():
+    """QuantFusedMLP.gate_up_pairs (GEMV layout, decode): row 2 i = gate row i, row 2 i + 1 = up row i in all three buffers -- the
+    form `awq_gemv_forward_ex(..., AWQ_GEMV_EX_SILU_PAIRS)` reads; built lazily from the registered buffers, dropped when they move."""
+    from autoawq_amd import WQLinear_GEMV
+    from autoawq_amd.modules.fused.mlp import QuantFusedMLP
+    from autoawq_amd.utils.packing import calculate_zeros_width
+
+    gen = torch.Generator().manual_seed(6)
+    lim = 0x7FFFFFFF
+
+    def lin(K, N):
+        zw = calculate_zeros_width(K, 128)
+        m = WQLinear_GEMV(4, 128, K, N, False, "cpu")
+        m.qweight = torch.randint(-lim - 1, lim, (N, K // 8), dtype=torch.int32, generator=gen)
+        m.qzeros = torch.randint(-lim - 1, lim, (N, zw), dtype=torch.int32, generator=gen)
+        m.scales = torch.rand((N, zw * 8), generator=gen).half()
+        return m
+
+    gate, up, down = lin(256, 48), lin(256, 48), lin(384, 256)
+    gq, uq, gs, us, gz, uz = (t.clone() for t in (gate.qweight, up.qweight, gate.scales, up.scales, gate.qzeros, up.qzeros))
+    mlp = QuantFusedMLP(gate, down, up)
+    assert mlp.gemv_layout and mlp._pairs is None
+    pq, ps, pz = mlp.gate_up_pairs()
+    assert pq.shape == (96, 32) and pq.is_contiguous()
+    for pairs, g_, u_ in ((pq, gq, uq), (ps, gs, us), (pz, gz, uz)):
+        assert torch.equal(pairs[0::2], g_) and torch.equal(pairs[1::2], u_)
+    assert mlp.gate_up_pairs()[0] is pq                      # cached
+    mlp.up_proj_qweight = uq.flip(0).contiguous()            # a loader re-assigns a buffer: the fused tensors and the pairs follow
+    mlp._gate_up_fused()
+    assert mlp._pairs is None and torch.equal(mlp.gate_up_pairs()[0][1::2], uq.flip(0))
