@@ -19,19 +19,27 @@
 //    barrier, and from there a wave shares nothing with anybody: no barrier at the end, no exchange, no workspace.
 //    (Larger batches or K: wk waves side by side on a row, and one barrier before y is written.)
 //  * Per unit a lane spends 5 VALU ops per packed word on the decode (nibbles stay in place under the fp16
-//    exponents 2^10 / 2^6, see gemv_mfma.hip) and 16 v_dot2c_f32_f16 (exact products, fp32 accumulation).
+//    exponents 2^10 / 2^6, see gemv_mfma.hip); the dot products are eight v_mfma_f32_4x4x4_16b_f16 (16 independent
+//    4 x 4 x 4 products, one per lane quad; the lane's own product is the diagonal element; exact products, fp32
+//    accumulation) -- level with 16 v_dot2c_f32_f16 in time, half the VALU issue slots.
 //  * Four units form a ROUND.  Group scale and zero point come off once per round and lane: a 4 x 4 transpose-reduce
 //    inside each lane quad (a quad = the four chunks of one 128-wide group) leaves lane j of the quad with the group
-//    sum of unit j, so ONE scale and ONE zero word per lane serve four units (read from LDS: the scales / zeros of all
-//    the rows a wave will touch are contiguous in this layout and arrive by two or three LDS-DMA instructions in the
-//    prologue, so the stream itself carries packed weights only):
+//    sum of unit j, so ONE scale and ONE zero word per lane serve four units (read from LDS at the START of the round: the
+//    scales / zeros of all the rows a wave will touch are contiguous in this layout and arrive in the prologue -- by two
+//    registers per lane when they fit 1 KiB / 64 words, else by two or three LDS-DMA instructions -- so the stream itself
+//    carries packed weights only):
 //        y[n] += s[n,g] * (P - C0 - z[n,g] * SX),   P = sum x*(bias + w),  C0 = sum bias*x,  SX = sum x  over the group,
 //    C0 / SX constants of the launch.  One-hot and zero inputs stay exact (tests).
 //  * A super-unit (SU) is RPU whole rows = SL * RPU units = R rounds with a compile-time (row, slot) pattern
 //    (SL 1: 4 rows, 2: 2 rows, 3: 4 rows / 3 rounds, 4: 1 row, 6: 2 rows / 3 rounds, 8: 1 row / 2 rounds).
 //  * Every load of the stream is inline asm with hand-counted `s_waitcnt vmcnt(N)` (vector-memory operations retire
 //    in order; hipcc falls back to vmcnt(0) at the loop head for a ring it cannot see through): D super-units
-//    stay in flight per wave, a round is re-requested right after it is consumed.
+//    stay in flight per wave, a round is re-requested right after it is consumed (main phase); the last D super-units
+//    are DRAINED with falling wait counts and no requests (requesting dummies past the end to keep one count made every
+//    wave end on a memory round trip).  tools/isa_audit.py audit_inflight_regs reads the ISA back (tests/test_boundary.py).
+//  * With ONE wave per SIMD nothing hides instruction latency: the prologue's instruction count is launch time
+//    (profiles/r03_gemv_rows_trace.txt).  Hence the zero chunk instead of per-element selects, the group constants by one
+//    MFMA chain, batched asm LDS reads, the one-piece-per-wave DMA fast path and the kernel-argument field order.
 //  * Cross-lane: two DPP rotations per round, then lanes 12-15 of each 16-lane row park four partial sums per unit in
 //    LDS; at the end a lane adds the 4 * SL (* wk) partials of a row and writes y.  Bitwise reproducible.
 //  * Static partition: SUs dealt evenly to (block, row group); the grid is a multiple of the CU count.
