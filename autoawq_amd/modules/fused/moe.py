@@ -79,7 +79,7 @@ def _apply_moe_prefill(w1, w2, x, gating_output, topk, renormalize):
 def apply_moe_weights(w1: Dict[str, torch.Tensor], w2: Dict[str, torch.Tensor], x: torch.Tensor,
                       gating_output: torch.Tensor, topk: int, renormalize: bool) -> torch.Tensor:
     num_experts = w1.qweight.shape[0]
-    if x.shape[0] * topk >= PREFILL_MIN_PAIRS and not torch.cuda.is_current_stream_capturing():
+    if x.shape[0] * topk >= PREFILL_MIN_PAIRS and x.is_cuda and not torch.cuda.is_current_stream_capturing():
         in_dtype = x.dtype
         out = _apply_moe_prefill(w1, w2, x.half() if in_dtype != torch.float16 else x, gating_output, topk, renormalize)
         return out.to(in_dtype) if in_dtype != torch.float16 else out

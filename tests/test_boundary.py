@@ -112,6 +112,35 @@ def test_cpu_tensors_fail_loudly():
     assert out.shape == (0, 5, 64) and out.dtype == torch.float32
 
 
+def test_round3_entry_points_fail_loudly_on_cpu_tensors():
+    """No CPU fallback behind the new entry points either: the block-fusion GEMV, the score-modified attention, the MoE prefill
+    path and the one-shot all-reduce wrapper raise on non-HIP tensors instead of computing something else."""
+    from autoawq_amd import ops
+    from autoawq_amd._lib import AwqHipError
+    from autoawq_amd.comm import OneShotAllReduce
+    from autoawq_amd.modules.fused import moe
+
+    K, N, zw = 256, 16, 2
+    x = torch.zeros((1, K), dtype=torch.float16)
+    qw, qz, sc = torch.zeros((N, K // 8), dtype=torch.int32), torch.zeros((N, zw), dtype=torch.int32), torch.zeros((N, zw * 8), dtype=torch.float16)
+    with pytest.raises(AwqHipError):
+        ops.gemv_forward_ex(x, qw, sc, qz, 128, norm_weight=torch.ones(K, dtype=torch.float16))
+    q = torch.zeros((1, 4, 128), dtype=torch.float16)
+    kv = torch.zeros((1, 8, 4, 128), dtype=torch.float16)
+    with pytest.raises(AwqHipError):
+        ops.decode_attention(q, kv, kv, 4, softcap=30.0)
+
+    class Stack:
+        pass
+    w1, w2 = Stack(), Stack()
+    w1.qweight, w1.qzeros, w1.scales = torch.zeros((2, 128, 32), dtype=torch.int32), torch.zeros((2, 1, 32), dtype=torch.int32), torch.zeros((2, 1, 256), dtype=torch.float16)
+    w2.qweight, w2.qzeros, w2.scales = torch.zeros((2, 128, 16), dtype=torch.int32), torch.zeros((2, 1, 16), dtype=torch.int32), torch.zeros((2, 1, 128), dtype=torch.float16)
+    with pytest.raises(AwqHipError):  # 512 tokens x top-1 pairs: the prefill path
+        moe.apply_moe_weights(w1, w2, torch.zeros((512, 128), dtype=torch.float16), torch.zeros((512, 2)), 1, True)
+    with pytest.raises((AwqHipError, RuntimeError, AssertionError)):
+        OneShotAllReduce.local_group(2, 64, device="cpu")
+
+
 # ------------------------------------------------------------------ WQLinear_GEMV surface (CPU)
 
 @pytest.mark.parametrize("name", ["packed_K512_N64_g128", "packed_K256_N32_g64", "packed_K128_N32_g32"])
