@@ -378,9 +378,15 @@ int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* 
     // the split must not depend on a length that only the device knows: size it for max_len
     const int len_for_split = len_dev ? max_len : seq_len + (fused ? 1 : 0);
     if (len_for_split < 1 || len_for_split > Tmax) return AWQ_ERR_BAD_SHAPE;
-    // ~1024 blocks in flight, at least 64 rows per block
-    int splits = (1024 + B * Hkv - 1) / (B * Hkv);
-    const int max_by_rows = (len_for_split + 63) / 64;
+    // ~1024 blocks in flight, at least 64 rows per block (both overridable in experiment builds: tools/attn_split_ab.py)
+#ifndef AWQ_ATTN_BLOCKS
+#define AWQ_ATTN_BLOCKS 1024
+#endif
+#ifndef AWQ_ATTN_MIN_ROWS
+#define AWQ_ATTN_MIN_ROWS 64
+#endif
+    int splits = (AWQ_ATTN_BLOCKS + B * Hkv - 1) / (B * Hkv);
+    const int max_by_rows = (len_for_split + AWQ_ATTN_MIN_ROWS - 1) / AWQ_ATTN_MIN_ROWS;
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;  // the combine kernel's one-lane-per-split step
