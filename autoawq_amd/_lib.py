@@ -40,6 +40,11 @@ SIGNATURES = {
     "awq_allreduce_flag_bytes": (c_size_t, []),
     "awq_allreduce_state_bytes": (c_size_t, []),
     "awq_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "awq_allreduce_alloc": (c_int, [c_void_p, c_size_t]),
+    "awq_allreduce_free": (c_int, [c_void_p]),
+    "awq_allreduce_ipc_export": (c_int, [c_void_p, c_void_p]),
+    "awq_allreduce_ipc_open": (c_int, [c_void_p, c_void_p]),
+    "awq_allreduce_ipc_close": (c_int, [c_void_p]),
     "awq_allreduce_oneshot_group": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "awq_hip_abi_version": (c_int, []),
     "awq_hip_error_string": (ctypes.c_char_p, [c_int]),

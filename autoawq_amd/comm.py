@@ -17,7 +17,49 @@ import torch
 from . import _lib
 
 
+class _DeviceBytes:
+    """`nbytes` of zeroed UNCACHED fine-grained device memory from awq_allreduce_alloc (flags and staging are polled by their
+    owner while peer GPUs write them: ordinary coarse-grained memory gives a spinning kernel no guarantee to ever see the store),
+    or this process's mapping of a peer's buffer (awq_allreduce_ipc_open).  Handed to torch through
+    `__cuda_array_interface__`; freed / unmapped when the last tensor over it is gone."""
+
+    def __init__(self, nbytes=None, handle=None):
+        L = _lib.lib()
+        p = ctypes.c_void_p()
+        self._peer = handle is not None
+        if self._peer:
+            buf = ctypes.create_string_buffer(bytes(handle), len(handle))
+            _lib.check(L.awq_allreduce_ipc_open(buf, ctypes.byref(p)), "awq_allreduce_ipc_open")
+        else:
+            _lib.check(L.awq_allreduce_alloc(ctypes.byref(p), nbytes), "awq_allreduce_alloc")
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+    def tensor(self, device):
+        return torch.as_tensor(self, device=device)
+
+    def ipc_handle(self):
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(_lib.lib().awq_allreduce_ipc_export(ctypes.c_void_p(self.ptr), buf), "awq_allreduce_ipc_export")
+        return bytes(buf.raw)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                L = _lib.lib()
+                (L.awq_allreduce_ipc_close if self._peer else L.awq_allreduce_free)(ctypes.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class OneShotSetupError(RuntimeError):
+    """Raised by EVERY rank of the group when the setup of ANY rank failed (the ranks agree before anybody returns)."""
+
+
 class OneShotAllReduce:
+    CHECK_EVERY = 256  # calls between two looks at the sticky error word (asynchronous copy; `check()` forces one)
+
     def __init__(self, rank, world, staging, flags, state, max_halfs, keepalive=None):
         """staging / flags: lists of `world` uint8 tensors (entry `rank` is this rank's own, the others are peer mappings)."""
         assert 1 <= world <= 8 and 0 <= rank < world and len(staging) == world and len(flags) == world
@@ -27,49 +69,76 @@ class OneShotAllReduce:
         self._sp = (ctypes.c_void_p * world)(*[t.data_ptr() for t in staging])
         self._fp = (ctypes.c_void_p * world)(*[t.data_ptr() for t in flags])
         self.device = state.device
+        self._calls = 0
+        self._err_host = torch.zeros(4, dtype=torch.int32).pin_memory() if state.is_cuda else None
+        self._err_event = None
 
     # ---- construction -----------------------------------------------------------------------------------------------
     @staticmethod
     def _alloc(max_halfs, device):
+        """(staging, flags) as raw uncached allocations + their uint8 tensor views, and the private state tensor."""
         L = _lib.lib()
-        st = torch.zeros(L.awq_allreduce_staging_bytes(max_halfs), dtype=torch.uint8, device=device)
-        fl = torch.zeros(L.awq_allreduce_flag_bytes(), dtype=torch.uint8, device=device)
-        state = torch.zeros(L.awq_allreduce_state_bytes(), dtype=torch.uint8, device=device)
+        device = torch.device(device)
+        with torch.cuda.device(device):
+            st = _DeviceBytes(L.awq_allreduce_staging_bytes(max_halfs))
+            fl = _DeviceBytes(L.awq_allreduce_flag_bytes())
+            state = torch.zeros(L.awq_allreduce_state_bytes(), dtype=torch.uint8, device=device)
         return st, fl, state
 
     @classmethod
     def local_group(cls, world, max_halfs, device="cuda"):
         """`world` ranks in ONE process on ONE device (tests, single-GPU graph-capture checks)."""
+        device = torch.device(device if torch.device(device).index is not None else f"cuda:{torch.cuda.current_device()}")
         bufs = [cls._alloc(max_halfs, device) for _ in range(world)]
         torch.cuda.synchronize(device)
-        return [cls(r, world, [b[0] for b in bufs], [b[1] for b in bufs], bufs[r][2], max_halfs) for r in range(world)]
+        st, fl = [b[0].tensor(device) for b in bufs], [b[1].tensor(device) for b in bufs]
+        return [cls(r, world, st, fl, bufs[r][2], max_halfs) for r in range(world)]
 
     @classmethod
     def from_process_group(cls, max_halfs, group=None, device=None):
-        """One process per GPU (torch.distributed initialised): allocate, zero, exchange CUDA-IPC handles of the staging and
-        flag buffers through the process group, map the peers'.  Collective: every rank of `group` must call it."""
+        """One process per GPU (torch.distributed initialised): allocate (uncached, zeroed), exchange the IPC handles of the
+        staging and flag buffers through the process group, map the peers'.  COLLECTIVE: every rank of `group` must call it, and
+        every rank gets the same outcome -- the ranks agree after each step, so a failure on ONE rank (a refused allocation, a
+        hipIpcOpenMemHandle that fails) raises OneShotSetupError on ALL of them instead of leaving some inside a barrier while
+        others fall back to another collective."""
         import torch.distributed as dist
-        from torch.multiprocessing.reductions import reduce_tensor
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        st, fl, state = cls._alloc(max_halfs, device)
-        torch.cuda.synchronize(device)
-        mine = (reduce_tensor(st), reduce_tensor(fl))
+
+        def agree(ok, what, err):
+            oks = [None] * world
+            dist.all_gather_object(oks, (bool(ok), None if ok else f"rank {rank}: {what}: {err}"), group=group)
+            bad = [m for o, m in oks if not o]
+            if bad:
+                raise OneShotSetupError("; ".join(bad))
+
+        st = fl = state = None
+        mine, err = None, None
+        try:
+            st, fl, state = cls._alloc(max_halfs, device)
+            torch.cuda.synchronize(device)
+            mine = (st.ipc_handle(), st.nbytes, fl.ipc_handle(), fl.nbytes)
+        except Exception as e:  # noqa: BLE001 -- reported to every rank below
+            err = e
+        agree(mine is not None, "allocation / IPC export", err)
         everyone = [None] * world
         dist.all_gather_object(everyone, mine, group=group)
-        staging, flags, keep = [], [], []
-        for r, ((fs, as_), (ff, af)) in enumerate(everyone):
-            if r == rank:
-                staging.append(st)
-                flags.append(fl)
-            else:
-                ps, pf = fs(*as_), ff(*af)  # rebuild_cuda_tensor: hipIpcOpenMemHandle under the owner's device index
-                staging.append(ps)
-                flags.append(pf)
-                keep += [ps, pf]
+        staging, flags, err = [], [], None
+        try:
+            with torch.cuda.device(device):
+                for r, (hs, ns, hf, nf) in enumerate(everyone):
+                    if r == rank:
+                        staging.append(st.tensor(device))
+                        flags.append(fl.tensor(device))
+                    else:
+                        staging.append(_DeviceBytes(ns, handle=hs).tensor(device))
+                        flags.append(_DeviceBytes(nf, handle=hf).tensor(device))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        agree(err is None, "mapping the peers' buffers", err)
         dist.barrier(group=group)  # nobody launches before everybody has mapped (and zeroed) everything
-        return cls(rank, world, staging, flags, state, max_halfs, keepalive=keep)
+        return cls(rank, world, staging, flags, state, max_halfs)
 
     # ---- use --------------------------------------------------------------------------------------------------------
     def __call__(self, x, out=None):
@@ -84,7 +153,32 @@ class OneShotAllReduce:
             rc = _lib.lib().awq_allreduce_oneshot(self._sp, self._fp, self.rank, self.world, x.data_ptr(), out.data_ptr(), n,
                                                   self.max_halfs, self.state.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "awq_allreduce_oneshot")
+        self._calls += 1
+        if self._calls % self.CHECK_EVERY == 0 and not torch.cuda.is_current_stream_capturing():
+            self._poll_error()
         return out
+
+    def _poll_error(self):
+        """The sticky error word, looked at without stalling the stream: an asynchronous copy to pinned memory every
+        CHECK_EVERY calls, read when the NEXT look finds it complete (same scheme as ops._Workspace)."""
+        if self._err_event is not None and self._err_event.query():
+            if int(self._err_host[1]) != 0:
+                raise _lib.AwqHipError(f"OneShotAllReduce: rank {self.rank} gave up waiting for peer {int(self._err_host[1]) - 1} "
+                                       f"(sticky error word); the affected outputs were written as NaN")
+            self._err_event = None
+        if self._err_event is None:
+            self._err_host.copy_(self.state.view(torch.int32), non_blocking=True)
+            self._err_event = torch.cuda.Event()
+            self._err_event.record()
+
+    def check(self):
+        """Synchronising look at the sticky error word: call at the host sync points of a step loop (end of a token, after a
+        graph replay).  Raises if a launch of this rank ever gave up on a peer."""
+        epochs, err = self.status()
+        if err:
+            raise _lib.AwqHipError(f"OneShotAllReduce: rank {self.rank} gave up waiting for peer {err - 1} after {epochs} completed "
+                                   f"all-reduces; the affected outputs were written as NaN")
+        return epochs
 
     @staticmethod
     def group_call(ranks, xs, outs=None):
@@ -111,3 +205,33 @@ class OneShotAllReduce:
         """(epochs completed, sticky error word) -- synchronises."""
         s = self.state.view(torch.int32).cpu()
         return int(s[0]), int(s[1])
+
+
+def make_collective(max_halfs, device, group=None):
+    """The all-reduce a tensor-parallel decode step should use, decided THE SAME WAY ON EVERY RANK: the one-shot kernel if its
+    setup and a self-check (against `dist.all_reduce`) succeed on all ranks, else RCCL through torch.distributed.
+    Returns (callable summing a contiguous fp16 tensor over the ranks in place, description, OneShotAllReduce | None)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ar, why = None, None
+    try:
+        ar = OneShotAllReduce.from_process_group(max_halfs=max_halfs, group=group, device=device)  # same outcome on every rank
+    except OneShotSetupError as e:
+        why = f"setup failed: {str(e)[:160]}"
+    if ar is not None:
+        ok = 0
+        try:
+            probe = torch.full((max_halfs // 4 * 4,), float(rank + 1), dtype=torch.float16, device=device)
+            ar(probe)
+            torch.cuda.synchronize(device)
+            ok = int(bool((probe == world * (world + 1) / 2).all()) and ar.status()[1] == 0)
+        except Exception:  # noqa: BLE001 -- a local failure must not desynchronise the ranks: it becomes a vote
+            ok = 0
+        vote = torch.tensor([ok], device=device)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+        if int(vote.item()) != 1:
+            ar, why = None, "self-check against the expected sum failed on at least one rank"
+    if ar is not None:
+        return ar, "one-shot xGMI all-reduce (csrc/allreduce.hip; uncached fine-grained flags + staging), hipGraph-captured", ar
+    return (lambda t: dist.all_reduce(t, group=group)), f"RCCL all_reduce via torch.distributed (one-shot {why})", None

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ..linear.gemm import WQLinear_GEMM
-from ..linear.gemv import WQLinear_GEMV
+from ..linear.gemv import WQLinear_GEMV, tensor_key
 
 
 class QuantFusedMLP(nn.Module):
@@ -86,12 +86,13 @@ class QuantFusedMLP(nn.Module):
         `ops.gemv_forward_ex(..., silu_pairs=True)` reads -- the wave that finishes a (gate, up) pair writes
         silu(gate) * up itself, so the [1, 2 I] intermediate and the awq_silu_and_mul launch (mlp.py:64-66) disappear.
         A second resident copy of the two projections (2 x 23 MB per 7B layer), built at the first decode step from the
-        registered buffers; `_adopt` (a `.to()`, re-assigned buffers) drops it."""
-        if self._pairs is None:
-            qw, sc, qz = self._gate_up_fused()
+        registered buffers; rebuilt when they are re-assigned, moved or written in place (`load_state_dict`)."""
+        qw, sc, qz = self._gate_up_fused()
+        key = tensor_key(qw, sc, qz)  # re-assigned views re-fuse (new pointers); an in-place load bumps the versions
+        if self._pairs is None or self._pairs[0] != key:
             I = self.intermediate_size
-            self._pairs = tuple(torch.stack([t[:I], t[I:]], dim=1).reshape(t.shape).contiguous() for t in (qw, sc, qz))
-        return self._pairs
+            self._pairs = (key, tuple(torch.stack([t[:I], t[I:]], dim=1).reshape(t.shape).contiguous() for t in (qw, sc, qz)))
+        return self._pairs[1]
 
     def forward(self, x, routing_weights=None, gate_up=None):
         """`gate_up` [rows, 2 * intermediate]: the fused gate|up projection already computed by the caller

@@ -25,11 +25,17 @@ from ...utils.packing import (GEMV_ORDER, calculate_zeros_width, pack_rows_int4,
 PREFILL_MIN_ROWS = 17
 
 
+def tensor_key(*tensors):
+    """Identity AND content version of tensors a derived cache was built from: `data_ptr` changes when a buffer is re-assigned,
+    `_version` when it is written in place (`load_state_dict`, `.copy_()`) -- ADVICE r03: a key of pointers alone went stale."""
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+
+
 def _gemm_layout_copy(m):
     """The same integers repacked (bit-exactly, utils/convert.py) into the GEMM layout, built on first use and kept: batches the
     decode kernels of this layout do not take (prefill) run on the fused MFMA kernels of awq_gemm_forward instead of
-    dequantise + vendor GEMM.  Costs one more int4 copy of the weights (HBM is 288 GB); rebuilt if the buffers are re-assigned."""
-    key = (m.qweight.data_ptr(), m.scales.data_ptr(), m.qzeros.data_ptr())
+    dequantise + vendor GEMM.  Costs one more int4 copy of the weights (HBM is 288 GB); rebuilt if the buffers are re-assigned or written in place."""
+    key = tensor_key(m.qweight, m.scales, m.qzeros)
     c = m.__dict__.get("_gemm_copy")
     if c is None or c[0] != key:
         from ...utils.convert import pack_linear, unpack_linear

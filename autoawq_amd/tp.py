@@ -148,22 +148,39 @@ class RowParallelWQLinear(nn.Module):
 
 # ---- a whole decoder layer: which columns / rows each rank owns
 def llama_layer_bounds(n_heads, n_kv_heads, head_dim, intermediate, group_size, rank, world):
-    """Megatron-style split of one Llama-style decoder layer.  Attention is split by HEADS (a rank keeps
-    whole query heads and the whole KV heads they attend to, so GQA groups stay together: n_kv_heads must be
-    divisible by world or world by n_kv_heads is not supported here); the MLP by whole quantisation GROUPS
-    of the down projection's input rows, gate / up columns following the same bounds (uneven splits allowed:
-    86 groups over 8 ranks = 6 x 11 + 2 x 10).  Returns a dict of [start, stop) bounds."""
-    if n_kv_heads % world:
-        raise ValueError(f"n_kv_heads {n_kv_heads} must be divisible by the tensor-parallel degree {world}")
+    """Megatron-style split of one Llama-style decoder layer.  Attention is split by HEADS: a rank keeps whole query heads
+    and the whole KV head(s) they attend to, so GQA groups stay together.
+      * n_kv_heads % world == 0: a rank owns n_kv_heads / world KV heads and all their query heads;
+      * world % n_kv_heads == 0 (fewer KV heads than ranks, e.g. 4 KV heads at TP = 8): KV-head REPLICATION -- each KV head
+        is kept by world / n_kv_heads ranks, which divide its query heads among themselves (the k / v projections and the
+        cache rows of that head exist on each of them; the query heads, hence the o_proj rows, are still a partition, so the
+        all-reduce after o_proj is unchanged).  `kv_replicas` says how many ranks hold this rank's KV head.
+    The MLP is split by whole quantisation GROUPS of the down projection's input rows, gate / up columns following the same
+    bounds (uneven splits allowed: 86 groups over 8 ranks = 6 x 11 + 2 x 10).  Returns a dict of [start, stop) bounds."""
+    if n_heads % n_kv_heads:
+        raise ValueError(f"n_heads {n_heads} must be a multiple of n_kv_heads {n_kv_heads}")
     gq = n_heads // n_kv_heads
-    kv0, kvc = split_even_units(n_kv_heads, world)[rank]
-    q0, q1 = kv0 * gq * head_dim, (kv0 + kvc) * gq * head_dim
+    if n_kv_heads % world == 0:
+        rep = 1
+        kv0, kvc = split_even_units(n_kv_heads, world)[rank]
+        h0, h1 = kv0 * gq, (kv0 + kvc) * gq
+    elif world % n_kv_heads == 0 and gq % (world // n_kv_heads) == 0:
+        rep = world // n_kv_heads
+        kv0, kvc = rank // rep, 1
+        per = gq // rep                                  # query heads of this KV head per replica
+        h0 = kv0 * gq + (rank % rep) * per
+        h1 = h0 + per
+    else:
+        raise ValueError(f"n_kv_heads {n_kv_heads} (x {gq} query heads each) cannot be split or replicated over {world} ranks: "
+                         "need n_kv_heads % world == 0, or world % n_kv_heads == 0 with the query heads of a KV head "
+                         "divisible by world / n_kv_heads")
+    q0, q1 = h0 * head_dim, h1 * head_dim
     k0, k1 = kv0 * head_dim, (kv0 + kvc) * head_dim
     if intermediate % group_size:
         raise ValueError("intermediate size must be a multiple of the group size")
     g0, gc = split_even_units(intermediate // group_size, world)[rank]
     i0, i1 = g0 * group_size, (g0 + gc) * group_size
-    return {"q": (q0, q1), "kv": (k0, k1), "heads": (kv0 * gq, (kv0 + kvc) * gq), "kv_heads": (kv0, kv0 + kvc),
+    return {"q": (q0, q1), "kv": (k0, k1), "heads": (h0, h1), "kv_heads": (kv0, kv0 + kvc), "kv_replicas": rep,
             "mlp": (i0, i1)}
 
 

@@ -490,25 +490,13 @@ def main():
 
     # the TP collective: the one-shot xGMI all-reduce of csrc/allreduce.hip (a plain kernel launch: the whole step stays one
     # hipGraph); RCCL through torch.distributed if its setup (CUDA-IPC mapping of the peers' buffers) fails
-    allreduce, collective = None, "none"
+    allreduce, collective, oneshot = None, "none", None
     if world > 1:
-        try:
-            from autoawq_amd.comm import OneShotAllReduce
+        from autoawq_amd.comm import make_collective
 
-            allreduce = OneShotAllReduce.from_process_group(max_halfs=cfg["hidden"], device=dev)
-            probe = torch.full((1, cfg["hidden"]), float(rank + 1), dtype=torch.float16, device=dev)
-            allreduce(probe)
-            torch.cuda.synchronize()
-            ok = torch.tensor([int(bool((probe == world * (world + 1) / 2).all()) and allreduce.status()[1] == 0)], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) != 1:
-                raise RuntimeError("one-shot all-reduce self-check failed")
-            collective = "one-shot xGMI all-reduce (csrc/allreduce.hip), 8-16 KiB, hipGraph-captured"
-        except Exception as e:
-            allreduce = dist.all_reduce
-            collective = f"RCCL all_reduce via torch.distributed (one-shot setup failed: {type(e).__name__}: {str(e)[:120]})"
-            if rank == 0:
-                print(f"[bench] {collective}", file=sys.stderr)
+        allreduce, collective, oneshot = make_collective(cfg["hidden"], dev)  # every rank takes the same branch
+        if rank == 0:
+            print(f"[bench] collective: {collective}", file=sys.stderr)
 
     stream = torch.cuda.Stream(device=dev)
     graph, used_graph, capture_note = None, False, None
@@ -542,6 +530,8 @@ def main():
         e1.synchronize()
         torch.cuda.synchronize()
         ms_total = e0.elapsed_time(e1)
+        if oneshot is not None:
+            oneshot.check()  # a rank that gave up on a peer wrote NaN and raised the sticky word: the timing would be meaningless
         sustained = None
         if world == 1 and not a.no_secondary:  # the same replay for >= 1 s: a leg the GPU-busy sampler of the driver can see
             t_end, n_sus = time.perf_counter() + 1.2, 0

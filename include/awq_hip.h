@@ -345,12 +345,16 @@ AWQ_EXPORT int awq_decode_attention_rope(const uint16_t* qkv, uint16_t* k_cache,
  * [M, hidden] outputs of row-parallel projections (n_halfs % 4 == 0, n_halfs <= max_halfs; <= 64 KiB is what it is built for).
  * One launch per rank, no host involvement, hipGraph-replayable; see csrc/allreduce.hip for the protocol.
  * Setup (once): every rank allocates awq_allreduce_staging_bytes(max_halfs) of staging and awq_allreduce_flag_bytes() of
- * flags -- both ZEROED, both mapped by every peer (hipIpc / P2P) -- and awq_allreduce_state_bytes() of private, zeroed state.
+ * flags -- both ZEROED, both mapped by every peer (hipIpc / P2P), both FINE-GRAINED / UNCACHED device memory when the peers are
+ * other GPUs (awq_allreduce_alloc below: a kernel that spins on a flag a peer GPU writes is only guaranteed to see the store
+ * in such memory) -- and awq_allreduce_state_bytes() of private, zeroed state (any device memory).
  * peer_staging[r] / peer_flags[r] are THIS process's addresses of rank r's buffers (entry `rank` = its own); every rank must
  * pass the same max_halfs and issue the same sequence of calls.  A peer that never arrives raises a sticky error word
- * (state[1] != 0) after a bounded spin instead of hanging the GPU. */
+ * (state[1] != 0) after a bounded spin instead of hanging the GPU, and the slices that gave up are written as NaN: a late
+ * rank can not produce a plausible-looking wrong sum. */
 #define AWQ_AR_MAX_RANKS 8
 #define AWQ_AR_BLOCKS 16
+#define AWQ_AR_IPC_HANDLE_BYTES 64
 AWQ_EXPORT size_t awq_allreduce_staging_bytes(int64_t max_halfs);
 AWQ_EXPORT size_t awq_allreduce_flag_bytes(void);
 AWQ_EXPORT size_t awq_allreduce_state_bytes(void);
@@ -363,6 +367,14 @@ AWQ_EXPORT int awq_allreduce_oneshot(const void* const* peer_staging, void* cons
 AWQ_EXPORT int awq_allreduce_oneshot_group(const void* const* peer_staging, void* const* peer_flags, int64_t world,
                                            const uint16_t* const* ins, uint16_t* const* outs, int64_t n_halfs,
                                            int64_t max_halfs, void* const* states, void* stream);
+/* Setup-time helpers (the ONLY entry points that allocate; nothing on the launch path does): uncached fine-grained device
+ * memory on the current device, zeroed and synchronised; its IPC handle (AWQ_AR_IPC_HANDLE_BYTES opaque bytes a peer process
+ * opens with awq_allreduce_ipc_open -- it then owns a mapping it closes with awq_allreduce_ipc_close). */
+AWQ_EXPORT int awq_allreduce_alloc(void** ptr, size_t bytes);
+AWQ_EXPORT int awq_allreduce_free(void* ptr);
+AWQ_EXPORT int awq_allreduce_ipc_export(void* ptr, void* handle64);
+AWQ_EXPORT int awq_allreduce_ipc_open(const void* handle64, void** ptr);
+AWQ_EXPORT int awq_allreduce_ipc_close(void* ptr);
 
 #ifdef __cplusplus
 }

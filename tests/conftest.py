@@ -11,8 +11,50 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def install_guard_allocator():
+    """AWQ_GUARD_ALLOC=end|start: every device allocation of this process comes from tests/guard/libguard_alloc.so -- its own
+    mapping with unmapped address space on both sides, the block flush against the end (or start) of the mapping, so that an
+    access one byte outside ANY operand is a GPU memory fault instead of a silent read of a neighbouring tensor.  Must run
+    before the first device allocation.  Returns the placement or None."""
+    mode = os.environ.get("AWQ_GUARD_ALLOC", "")
+    if mode not in ("end", "start"):
+        return None
+    import torch
+
+    so = os.path.join(ROOT, "tests", "guard", "libguard_alloc.so")
+    if not os.path.exists(so):
+        raise RuntimeError(so + " missing: run `python tests/guard/build.py` (or __graft_entry__.build())")
+    alloc = torch.cuda.memory.CUDAPluggableAllocator(so, "guard_alloc", "guard_free")
+    torch.cuda.memory.change_current_allocator(alloc)
+    return mode
+
+
+def guard_stats():
+    import ctypes
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "guard", "libguard_alloc.so"))
+    out = (ctypes.c_long * 4)()
+    lib.guard_stats(out)
+    return {"granularity": out[0], "allocations": out[1], "driver_allocations": out[2], "placement": "end" if out[3] == 1 else "start"}
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    config.addinivalue_line("markers", "guard_skip: not run under the guard-band allocator (AWQ_GUARD_ALLOC)")
+    install_guard_allocator()
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("AWQ_GUARD_ALLOC", "") in ("end", "start"):
+        skip = pytest.mark.skip(reason="not under the guard-band allocator")
+        for it in items:
+            if "guard_skip" in it.keywords:
+                it.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if os.environ.get("AWQ_GUARD_ALLOC", "") in ("end", "start"):
+        terminalreporter.write_line("guard-band allocator: " + repr(guard_stats()))
 
 
 def golden(name):

@@ -147,4 +147,49 @@ def test_fused_mlp_gate_up_pairs_interleave_rows_gemv_layout():
     assert mlp.gate_up_pairs()[0] is pq                      # cached
     mlp.up_proj_qweight = uq.flip(0).contiguous()            # a loader re-assigns a buffer: the fused tensors and the pairs follow
     mlp._gate_up_fused()
-    assert mlp._pairs is None and torch.equal(mlp.gate_up_pairs()[0][1::2], uq.flip(0))
+    assert torch.equal(mlp.gate_up_pairs()[0][1::2], uq.flip(0))
+
+
+def test_derived_weight_caches_follow_in_place_loads():
+    """`_gemm_layout_copy` (prefill repack of a GEMV-layout module) and `QuantFusedMLP.gate_up_pairs` were keyed on
+    data pointers only; `load_state_dict` / `.copy_()` write IN PLACE (same pointers), after which prefill, the five-launch decode
+    and the registered buffers disagreed silently.  The keys now carry the tensors' versions."""
+    from autoawq_amd import WQLinear_GEMV
+    from autoawq_amd.modules.fused.mlp import QuantFusedMLP
+    from autoawq_amd.modules.linear.gemv import _gemm_layout_copy
+    from autoawq_amd.utils.convert import convert_linear
+    from autoawq_amd.utils.packing import calculate_zeros_width
+
+    gen = torch.Generator().manual_seed(16)
+    lim = 0x7FFFFFFF
+
+    def lin(K, N):
+        zw = calculate_zeros_width(K, 128)
+        m = WQLinear_GEMV(4, 128, K, N, False, "cpu")
+        m.qweight = torch.randint(-lim - 1, lim, (N, K // 8), dtype=torch.int32, generator=gen)
+        m.qzeros = torch.randint(-lim - 1, lim, (N, zw), dtype=torch.int32, generator=gen)
+        m.scales = torch.rand((N, zw * 8), generator=gen).half()
+        return m
+
+    a, b = lin(256, 64), lin(256, 64)
+    first = [t.clone() for t in _gemm_layout_copy(a)]
+    assert all(torch.equal(x, y) for x, y in zip(_gemm_layout_copy(a), first))
+    assert _gemm_layout_copy(a)[0] is _gemm_layout_copy(a)[0]           # cached while nothing changes
+    ptr = a.qweight.data_ptr()
+    a.load_state_dict(b.state_dict())                                   # in place: same storage, new contents
+    assert a.qweight.data_ptr() == ptr and torch.equal(a.qweight, b.qweight)
+    want = convert_linear(b, "gemm")
+    got = _gemm_layout_copy(a)
+    assert torch.equal(got[0], want.qweight) and torch.equal(got[1], want.scales) and torch.equal(got[2], want.qzeros)
+    assert not torch.equal(got[0], first[0])
+
+    mlp = QuantFusedMLP(lin(256, 48), lin(384, 256), lin(256, 48))
+    other = QuantFusedMLP(lin(256, 48), lin(384, 256), lin(256, 48))
+    p0 = mlp.gate_up_pairs()[0].clone()
+    mlp.load_state_dict(other.state_dict())
+    pq, ps, pz = mlp.gate_up_pairs()
+    assert torch.equal(pq[0::2], other.gate_proj_qweight) and torch.equal(pq[1::2], other.up_proj_qweight)
+    assert torch.equal(ps[0::2], other.gate_proj_scales) and torch.equal(pz[1::2], other.up_proj_qzeros)
+    assert not torch.equal(pq, p0)
+    mlp.gate_proj_scales.mul_(2)                                        # any in-place write, not only load_state_dict
+    assert torch.equal(mlp.gate_up_pairs()[1][0::2], mlp.gate_proj_scales)

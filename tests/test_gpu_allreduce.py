@@ -98,3 +98,22 @@ def test_oneshot_allreduce_missing_peer_raises_the_error_word_instead_of_hanging
     torch.cuda.synchronize()
     done, err = ranks[0].status()
     assert done == 1 and err != 0
+    assert bool(torch.isnan(x).all()), "a rank that gave up on a peer must not return a plausible-looking sum (ADVICE r03)"
+    with pytest.raises(Exception, match="gave up waiting for peer 1"):
+        ranks[0].check()
+
+
+def test_oneshot_allreduce_buffers_are_library_allocated_uncached_memory():
+    """Flags and staging come from awq_allreduce_alloc (uncached fine-grained device memory, zeroed), not from torch's pool."""
+    from autoawq_amd.comm import OneShotAllReduce, _DeviceBytes
+
+    ranks = OneShotAllReduce.local_group(2, max_halfs=256)
+    for t in ranks[0].staging + ranks[0].flags:
+        assert t.dtype == torch.uint8 and t.is_cuda and int(t.sum()) == 0
+    b = _DeviceBytes(4096)
+    t = b.tensor(torch.device("cuda", torch.cuda.current_device()))
+    assert t.data_ptr() == b.ptr and t.numel() == 4096 and len(b.ipc_handle()) == 64
+    xs = [torch.full((256,), float(r + 1), device="cuda", dtype=torch.float16) for r in range(2)]
+    OneShotAllReduce.group_call(ranks, xs)
+    torch.cuda.synchronize()
+    assert all(bool((x == 3).all()) for x in xs) and ranks[0].check() == 1

@@ -1,0 +1,51 @@
+"""Guard-band runs: the kernels once more, in a child process whose EVERY device allocation sits flush
+against unmapped address space (tests/guard/guard_alloc.cpp through torch's pluggable-allocator hook) -- at the END of its own
+mapping (an over-read or over-write of one byte past any operand faults) and at the START (one byte before).  torch's caching
+allocator packs tensors into shared 2 MiB / 20 MiB segments, where such an access lands in a neighbour and goes unnoticed.
+A GPU memory fault aborts the child: the assertion shows the last test it had started."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = [pytest.mark.gpu, pytest.mark.guard_skip]
+
+# the kernel-facing tests (every HIP kernel family, BASELINE shapes + ragged ones, M = 1 ... 16 and prefill sizes); the
+# whole suite runs under the same allocator by tools/guard_run.sh (profiles/r04_fault_hunt/)
+SUBSET = ("test_gemv_rows_kernel_vs_oracle or test_gemv_rows_block_fusions or config4 or dequant or unpack or gemv_lds or gemvfast or "
+          "test_gemm_vs_oracle_all_variants or attention or rmsnorm or rope or silu or moe or chain")
+
+
+def _env(mode):
+    env = dict(os.environ)
+    env["AWQ_GUARD_ALLOC"] = mode
+    return env
+
+
+def _lib_built():
+    from tests.guard import build
+
+    return build.build()
+
+
+@pytest.mark.parametrize("mode", ["end", "start"])
+def test_guard_allocator_faults_on_an_access_outside_an_allocation(mode):
+    """The checker itself: a read 8 KiB outside a guarded allocation must kill the child (else the runs below prove nothing)."""
+    _lib_built()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard_selfcheck.py")], env=_env(mode), cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert "inside:" in r.stdout, r.stdout + r.stderr
+    assert r.returncode != 0 and "must not get here" not in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+
+
+@pytest.mark.parametrize("mode", ["end", "start"])
+def test_kernels_touch_nothing_outside_their_operands(mode):
+    _lib_built()
+    cmd = [sys.executable, "-X", "faulthandler", "-m", "pytest", "tests", "-m", "gpu", "-v", "-p", "no:cacheprovider", "-x", "-k", SUBSET]
+    r = subprocess.run(cmd, env=_env(mode), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    tail = "\n".join(r.stdout.splitlines()[-12:])
+    assert r.returncode == 0, f"guard-band run ({mode}) rc {r.returncode}:\n{tail}\n{r.stderr[-1500:]}"
+    assert "guard-band allocator: {" in r.stdout and f"'placement': '{mode}'" in r.stdout, tail  # the hook really was active
+    assert " passed" in tail and "failed" not in tail, tail
