@@ -6,6 +6,23 @@
 #include <stdint.h>
 
 #include "../../include/awq_hip.h"
+#include <atomic>
+
+// The opt-in to more than 64 KB of dynamic LDS is an attribute of a kernel ON A DEVICE: asked for once per (kernel, device)
+// -- the call sites keep one bit per device ordinal -- thread-safe, idempotent, no other process-wide state (a
+// function-local `static const bool` did it once per PROCESS, i.e. for the first device only).
+inline bool awq_lds_opt_in(const void* kernel, std::atomic<unsigned long long>& done, int bytes = 160 * 1024) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 
 int awq_launch_dequant(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out,
                        int64_t K, int64_t N, int64_t g, hipStream_t stream);

@@ -354,14 +354,17 @@ int awq_grouped_gemm_forward_ex(const uint16_t* x, const int32_t* qweight, const
 
 /* ---- GEMV layout ------------------------------------------------------------------------- */
 
-// Which kernel awq_gemv_forward's AUTO dispatch takes (host only, no launch): the row-streaming kernel at batch 1, and at batch 2
-// while a wave still covers whole rows (K <= 6144: profiles/r03_gemv_rows_sweep.txt); the LDS-streaming MFMA kernel from five
+// Which kernel awq_gemv_forward's AUTO dispatch takes (host only, no launch): the row-streaming kernel at batches 1 and 2, and at
+// batches 3 .. 4 while K <= 6144 (profiles/r03_gemv_rows_sweep.txt); the LDS-streaming MFMA kernel from five
 // batch rows on matrices of 8192 rows and more (4096 x 11008, M = 8: 11.6 us vs 19.0 for the tile kernel; 4096 x 22016: 16.7 vs
 // 35.7; below that the tile kernel is level or ahead); the 16-row MFMA tile kernel otherwise.  -1: no kernel takes the shape.
 int awq_gemv_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0 || K % group_size || K % 8 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return -1;
     const int m = (int)M, k = (int)K, n = (int)N, g = (int)group_size;
-    if ((M == 1 || (M == 2 && K <= 6144)) && awq_gemv_rows_supports(m, k, n, g)) return (int)AWQ_GEMV_KERNEL_ROWS;
+    // round 4: batch 2 at every K and batches 3 .. 4 while K <= 6144 also run the row-streaming kernel -- it is ahead of the
+    // 16-row tile kernel there on all four 7B shapes (profiles/r03_gemv_rows_sweep.txt: M = 2 4.65 / 7.05 / 10.77 / 8.57 us vs
+    // 6.18 / 9.96 / 16.65 / 10.73; M = 4 at K = 4096 5.79 / 9.79 / 14.39 vs 6.59 / 10.40 / 18.29; at K = 11008 12.25 vs 11.79)
+    if ((M <= 2 || (M <= 4 && K <= 6144)) && awq_gemv_rows_supports(m, k, n, g)) return (int)AWQ_GEMV_KERNEL_ROWS;
     if (M >= 5 && N >= 8192 && awq_gemv_lds_supports(m, k, n, g)) return (int)AWQ_GEMV_KERNEL_LDS;
     return awq_gemv_nk_supports(m, k, n, g) ? (int)AWQ_GEMV_KERNEL_TILE16 : -1;
 }

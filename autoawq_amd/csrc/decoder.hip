@@ -139,6 +139,10 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
     // device-side lengths are clamped to the cache (see awq_rope_kv_append_kernel): never a row >= Tmax
     const int T = max(1, min((len_dev ? *len_dev : seq_len) + (FUSED ? 1 : 0), Tmax));
     const int pos = T - 1;  // FUSED: the new token's position
+    // The rows are dealt to the splits of the launch HERE, from the length the device knows (round 4): a launch sized on the host
+    // for a longer context (a hipGraph serves every length up to its bucket's bound) still spreads the rows that exist over
+    // all of its splits instead of leaving them to the first few.  16-row granularity (a wave instruction covers 4 rows).
+    if (chunk <= 0) chunk = (((T + (int)gridDim.x - 1) / (int)gridDim.x) + 15) & ~15;
     const int t0 = split * chunk, t1 = min(T, t0 + chunk);
 
     float qf[G][8];
@@ -378,25 +382,28 @@ int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* 
     // the split must not depend on a length that only the device knows: size it for max_len
     const int len_for_split = len_dev ? max_len : seq_len + (fused ? 1 : 0);
     if (len_for_split < 1 || len_for_split > Tmax) return AWQ_ERR_BAD_SHAPE;
-    // ~1024 blocks in flight, at least 64 rows per block (both overridable in experiment builds: tools/attn_split_ab.py)
+    // Splits per KV head: about 256 rows each (AWQ_ATTN_ROWS), at most ~1024 blocks (AWQ_ATTN_BLOCKS) and 64 splits (the
+    // combine kernel's one-lane-per-split step).  ONE split up to 256 rows: no partials, no combine launch at all -- what a
+    // short context pays for a 32-way split sized for the whole cache was 9.5 + 5 us per layer (profiles/r03_whole_model_gemv_
+    // kernel_stats.txt); callers that know the context on the host (modules/fused/decode.py: one hipGraph per length bucket)
+    // pass the bucket's bound as max_len.  (Both constants overridable in experiment builds: tools/attn_split_ab.py.)
 #ifndef AWQ_ATTN_BLOCKS
 #define AWQ_ATTN_BLOCKS 1024
 #endif
-#ifndef AWQ_ATTN_MIN_ROWS
-#define AWQ_ATTN_MIN_ROWS 64
+#ifndef AWQ_ATTN_ROWS
+#define AWQ_ATTN_ROWS 256
 #endif
-    int splits = (AWQ_ATTN_BLOCKS + B * Hkv - 1) / (B * Hkv);
-    const int max_by_rows = (len_for_split + AWQ_ATTN_MIN_ROWS - 1) / AWQ_ATTN_MIN_ROWS;
-    if (splits > max_by_rows) splits = max_by_rows;
+    int splits = (len_for_split + AWQ_ATTN_ROWS - 1) / AWQ_ATTN_ROWS;
+    const int max_by_blocks = AWQ_ATTN_BLOCKS / (B * Hkv) > 1 ? AWQ_ATTN_BLOCKS / (B * Hkv) : 1;
+    if (splits > max_by_blocks) splits = max_by_blocks;
     if (splits < 1) splits = 1;
-    if (splits > 64) splits = 64;  // the combine kernel's one-lane-per-split step
+    if (splits > 64) splits = 64;
     if (splits > 1 && (!workspace || workspace_bytes < awq_decode_attention_workspace_bytes_impl(B, Hq, splits))) {
         const size_t per = awq_decode_attention_workspace_bytes_impl(B, Hq, 1);
         splits = workspace ? (int)(workspace_bytes / per) : 1;
         if (splits < 1) splits = 1;
     }
-    const int chunk = ((len_for_split + splits - 1) / splits + 15) / 16 * 16;
-    splits = (len_for_split + chunk - 1) / chunk;
+    const int chunk = 0;  // dealt in the kernel from the length it reads
     const dim3 grid((unsigned)splits, (unsigned)Hkv, (unsigned)B);
     float* part = static_cast<float*>(workspace);
 #define AWQ_ATTN_CASE(GG)                                                                                                  \

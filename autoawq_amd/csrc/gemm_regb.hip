@@ -378,12 +378,8 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
     }
 #endif
     if (bm == 256) {
-        // one-time, idempotent opt-in to > 64 KB of dynamic LDS (thread-safe initialisation; no other process-wide state)
-        static const bool lds_opt_in = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024) == hipSuccess;
-        }();
-        if (!lds_opt_in) return AWQ_ERR_LAUNCH;
+        static std::atomic<unsigned long long> opted{0};  // > 64 KB of dynamic LDS: once per device (awq_internal.h)
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2>), opted)) return AWQ_ERR_LAUNCH;
         hipLaunchKernelGGL((awq_gemm_regb_kernel<2>), dim3(grid), dim3(512), lds, a.stream, p);
     } else {
         hipLaunchKernelGGL((awq_gemm_regb_kernel<1>), dim3(grid), dim3(256), lds, a.stream, p);

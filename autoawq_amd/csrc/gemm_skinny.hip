@@ -332,13 +332,8 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
 
 template <int MI>
 int launch_skinny(const SkinnyParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    static const bool lds_opt_in = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_skinny_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        (void)hipGetLastError();
-        return true;
-    }();
-    (void)lds_opt_in;
+    static std::atomic<unsigned long long> opted{0};
+    (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_skinny_kernel<MI>), opted);
     hipLaunchKernelGGL((awq_gemm_skinny_kernel<MI>), grid, dim3(512), lds, st, p);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

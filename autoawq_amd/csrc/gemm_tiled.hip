@@ -383,15 +383,9 @@ void awq_gemm_tiled_kernel(TiledParams p) {
 template <int BM, int BN, int BK = BK_DEFAULT, bool FAT = false>
 void launch_tiled(const TiledParams& p, unsigned grid, hipStream_t st) {
     constexpr size_t lds = 2 * (BM * (BK + 8) * 2 + BK * BN * 2);
-    static const bool lds_opt_in = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, false, BK, FAT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if constexpr (!FAT)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, true, BK, FAT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)lds_opt_in;
+    static std::atomic<unsigned long long> opted{0}, opted_split{0};
+    (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, false, BK, FAT>), opted);
+    if constexpr (!FAT) (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_tiled_kernel<BM, BN, true, BK, FAT>), opted_split);
     constexpr int NTHR = (FAT ? BM / 64 : (BM >= 128 ? 2 : 1)) * (BN >= 256 ? (FAT ? 2 : 4) : (BM >= 128 ? 2 : 4)) * 64;
     if constexpr (FAT) {  // chip-filling grids only: never split (its split-K form would spill)
         hipLaunchKernelGGL((awq_gemm_tiled_kernel<BM, BN, false, BK, FAT>), dim3(grid), dim3(NTHR), lds, st, p);

@@ -291,9 +291,8 @@ int awq_launch_gemv_lds(const uint16_t* x, const int32_t* qweight, const uint16_
     const size_t lds = (size_t)p.ybuf_off + ybuf_bytes;
 #define AWQ_LDS_CASE(NWV, RDV)                                                                                                        \
     if (NW == NWV && RD == RDV) {                                                                                                      \
-        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemv_lds_kernel<NWV, RDV>),                      \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;              \
-        if (!ok) return AWQ_ERR_LAUNCH;                                                                                                \
+        static std::atomic<unsigned long long> opted{0};                                                                               \
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_lds_kernel<NWV, RDV>), opted)) return AWQ_ERR_LAUNCH;              \
         hipLaunchKernelGGL((awq_gemv_lds_kernel<NWV, RDV>), dim3((unsigned)blocks), dim3(NWV * 64), lds, st, p);                       \
         return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;                                                              \
     }

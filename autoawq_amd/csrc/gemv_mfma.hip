@@ -686,14 +686,9 @@ __global__ __launch_bounds__(256) void awq_gemv_mfma_reduce_kernel(const float* 
 template <int WPL, int NWAVES, int UNIT, bool SEL, int NREG, int FOLDS, int GATED = 0>
 void launch6(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
     // dynamic LDS above 64 KiB needs the opt-in once per kernel (host-side attribute, no sync)
-    static const bool lds_opt_in = [] {
-        (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true, false, GATED>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (160 - (GATED == 2 ? 1 : 0)) * 1024);  // mode 2 has 144 static bytes
-        (void)hipGetLastError();
-        return true;
-    }();
-    (void)lds_opt_in;
+    static std::atomic<unsigned long long> opted{0};
+    (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true, false, GATED>), opted,
+                         (160 - (GATED == 2 ? 1 : 0)) * 1024);  // mode 2 has 144 static bytes
     hipLaunchKernelGGL((awq_gemv_mfma_kernel<WPL, NWAVES, UNIT, SEL, NREG, FOLDS, true, false, GATED>), grid,
                        dim3(NWAVES * 64), lds, st, p);
 }
@@ -849,13 +844,8 @@ bool gemv_config(const AwqGemmArgs& a, bool two_pass, GemvCfg& c) {
 namespace {
 template <int UNIT, bool SEL, int XMODE>
 void launch_moe_x(const GemvMfmaParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    static const bool lds_opt_in = [] {
-        (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true, XMODE>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)lds_opt_in;
+    static std::atomic<unsigned long long> opted{0};
+    (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true, XMODE>), opted);
     hipLaunchKernelGGL((awq_gemv_mfma_kernel<2, 4, UNIT, SEL, 4, 1, true, true, XMODE>), grid, dim3(256), lds, st, p);
 }
 // x_gated: the pair rows are [gate | up] of 2K halves (the w1|w3 output) and silu(gate) * up is applied while the block stages

@@ -234,12 +234,8 @@ void launch_nk(const GemvNkParams& p, size_t lds, hipStream_t st) {
     dim3 grid((unsigned)((p.N + 15) / 16));
 #define AWQ_NK_LAUNCH(NGV)                                                                              \
     {                                                                                                   \
-        static const bool opt_in = [] {                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemv_nk_kernel<NWAVES, U, NGV>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);          \
-            return true;                                                                                \
-        }();                                                                                            \
-        (void)opt_in;                                                                                   \
+        static std::atomic<unsigned long long> opted{0};                                                \
+        (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_nk_kernel<NWAVES, U, NGV>), opted); \
         hipLaunchKernelGGL((awq_gemv_nk_kernel<NWAVES, U, NGV>), grid, dim3(NWAVES * 64), lds, st, p);   \
     }
     if (p.g % 128 == 0) AWQ_NK_LAUNCH(1)

@@ -605,9 +605,10 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 
 template <int SL, int D, int MM, int FX = 0>
 int launch_rows(const RowsParams& p, int blocks, size_t lds, hipStream_t st) {
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemv_rows_kernel<SL, D, MM, FX>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> opted{0};
+        (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_rows_kernel<SL, D, MM, FX>), opted);
+    }
     hipLaunchKernelGGL((awq_gemv_rows_kernel<SL, D, MM, FX>), dim3((unsigned)blocks), dim3(64 * p.wk, p.rg), lds, st, p);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

@@ -122,6 +122,12 @@ class QuantAttentionFused(nn.Module):
         start position and the cache length after the append; the caller advances them."""
         self._pos_dev, self._len_dev = pos_dev, len_dev
 
+    def _len_bound(self):
+        """What a decode launch with a DEVICE-side length is sized for: the cache window, or the tighter bound a caller that
+        knows the context on the host has set (`decode_len_bound`, modules/fused/decode.py: one hipGraph per length bucket)."""
+        b = getattr(self, "decode_len_bound", None)
+        return self.max_seq_len if b is None else max(1, min(int(b), self.max_seq_len))
+
     def _resize_cache(self, bsz):
         if bsz != self.cache_batch_size:
             if bsz > self.cache_batch_size:
@@ -187,7 +193,7 @@ class QuantAttentionFused(nn.Module):
             # decode: rotation, cache append and attention in ONE launch (awq_decode_attention_rope)
             out = ops.decode_attention_rope(xqkv, self.cache.k, self.cache.v, self.rope.cos, self.rope.sin, self.start_pos,
                                             self.n_heads, self.n_kv_heads, pos_dev=self._pos_dev if device_pos else None,
-                                            max_len=self.max_seq_len if device_pos else None)
+                                            max_len=self._len_bound() if device_pos else None)
             attention_weight = out.reshape(bsz, 1, -1)
             attn_output = self.o_proj(attention_weight) if apply_o_proj else attention_weight
             self.start_pos += 1
@@ -224,7 +230,7 @@ class QuantAttentionFused(nn.Module):
                     output = F.scaled_dot_product_attention(xq.transpose(1, 2), k, v).transpose(1, 2).reshape(bsz, 1, -1)
             else:
                 out = ops.decode_attention(xq[:, 0], self.cache.k, self.cache.v, self.start_pos + 1,
-                                           len_dev=self._len_dev if device_pos else None, max_len=self.max_seq_len,
+                                           len_dev=self._len_dev if device_pos else None, max_len=self._len_bound(),
                                            softcap=self.attn_logit_softcapping,
                                            alibi_slopes=self.alibi.slopes if self.alibi is not None else None)
                 output = out.reshape(bsz, 1, -1)

@@ -43,19 +43,40 @@ MODELS = {  # hidden, intermediate, layers, heads, kv heads
     "70b": dict(hidden=8192, inter=28672, layers=80, heads=64, kv_heads=8, name="Llama-3-70B"),
 }
 HIDDEN, INTER, LAYERS = 4096, 11008, 32  # the headline model (kept as names for tools/ that import them)
-PMC_FILE = "r03_pmc_fetch_size.txt"      # rocprofv3 --pmc FETCH_SIZE pass of the headline command (tools/prof_r03.sh)
+PMC_FILE = "r04_pmc_fetch_size.txt"      # rocprofv3 --pmc FETCH_SIZE pass of the headline command (tools/prof_r04.sh)
 KERNEL_OF_LAYOUT = {"gemv": "awq_gemv_rows_kernel", "gemm": "awq_gemv_mfma_kernel", "gemvfast": "awq_gemv_fast_kernel"}
 
 
+def kernel_fingerprint():
+    """sha1 over the sources libawq_hip.so is built from (csrc/*.hip, csrc/*.h, include/awq_hip.h): what a committed profile
+    records, so that a counter file taken from an OLDER build of the kernels is recognised as such (there is no .git on the
+    GPU box to ask for the head)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "autoawq_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    for f in files + [os.path.join(ROOT, "include", "awq_hip.h")]:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_per_launch():
-    """Mean HBM bytes per launch of the headline kernels from the committed FETCH_SIZE pass (profiles/, tools/prof_r02.sh)."""
+    """(mean HBM bytes per launch of the headline kernels from the committed FETCH_SIZE pass, note).  The pass is its own
+    rocprofv3 run (tools/prof_r04.sh); its file records the kernel-source fingerprint it was taken at, and a file taken from
+    other kernel sources than the ones in this tree is NOT reported as this build's traffic."""
     import re
 
     try:
         txt = open(os.path.join(ROOT, "profiles", PMC_FILE)).read()
-        return float(re.search(r"per launch \(weighted mean\): traffic ([0-9.]+) MB", txt).group(1)) * 1e6
+        val = float(re.search(r"per launch \(weighted mean\): traffic ([0-9.]+) MB", txt).group(1)) * 1e6
     except (OSError, AttributeError):
-        return None
+        return None, "profiles/" + PMC_FILE + " not found"
+    m = re.search(r"kernel source fingerprint: ([0-9a-f]+)", txt)
+    if not m or m.group(1) != kernel_fingerprint():
+        return None, (f"profiles/{PMC_FILE} was taken at kernel sources {m.group(1) if m else 'unrecorded'}, this tree is "
+                      f"{kernel_fingerprint()}: {val / 1e6:.3f} MB per launch there, not reported as this build's traffic")
+    return val, "kernel sources of the counter pass == this tree (" + m.group(1) + ")"
 
 
 def algorithmic_bytes(K, N, M, g, bias=False):
@@ -564,6 +585,8 @@ def main():
         # (N=1), so its average launch duration (incl. inter-kernel gap) = step time / launches.
         achieved = (bytes_step / launches) / (ms_step * 1e-3 / launches) / 1e9  # this rank's GB/s
         shape_txt = ", ".join(f"{n} {K}->{N}" for n, K, N, _ in shapes)
+        traffic, traffic_note = (pmc_traffic_per_launch() if (world == 1 and a.model == "7b" and a.layout == "gemv" and layers == cfg["layers"])
+                                 else (None, "headline configuration only"))
         out = {
             "metric": f"decode tok/s @bs=1 (int4 linears), {a.model.upper()} AWQ-int4 g128", "value": tok_s, "unit": "tok/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -581,7 +604,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          # HBM bytes per launch need the TCC fabric counters of a separate rocprofv3 --pmc pass
                          # (MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950): not measurable from inside this process
-                         "traffic": pmc_traffic_per_launch() if (world == 1 and a.model == "7b" and a.layout == "gemv" and layers == cfg["layers"]) else None,
+                         "traffic": traffic, "traffic_note": traffic_note,
                          "traffic_unit": "bytes per launch",
                          "traffic_measured_in": "profiles/" + PMC_FILE + " (own rocprofv3 --pmc FETCH_SIZE pass of this command, x 2 gfx950 correction, calibrated on a linear read; the file names the git head it was taken at)",
                          "bytes_per_launch": bytes_step / launches, "avg_launch_us": ms_step * 1e3 / launches,
@@ -589,7 +612,7 @@ def main():
                          "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "
                                  "HIP-event-timed replay of the captured stream / launches, i.e. it contains the "
                                  "dispatch gap exactly as rocprofv3's back-to-back kernel durations do "
-                                 "(profiles/r03_bench_kernel_trace_stats.txt)"},
+                                 "(profiles/r04_bench_kernel_trace_stats.txt)"},
         }
         if capture_note:
             out["config"]["capture_note"] = capture_note

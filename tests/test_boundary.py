@@ -239,7 +239,7 @@ def test_hand_counted_asm_loads_are_hazard_safe():
 
 
 def test_gemv_layout_auto_dispatch_table_host_only():
-    """awq_gemv_auto_kernel (host only): the row-streaming kernel at batch 1 (and 2 while a wave covers whole rows), the LDS-DMA
+    """awq_gemv_auto_kernel (host only): the row-streaming kernel at batches 1 - 2 (3 - 4 while K <= 6144), the LDS-DMA
     -> MFMA kernel for 5..16 rows of tall matrices within its LDS budget, the 16-row tile kernel otherwise -- DESIGN.md 3.0 / 3.0b."""
     from autoawq_amd import _lib
 
@@ -247,9 +247,10 @@ def test_gemv_layout_auto_dispatch_table_host_only():
     ROWS, LDS, TILE = 2, 3, 1
     for K, N in [(4096, 4096), (4096, 12288), (4096, 22016), (11008, 4096), (8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192)]:
         assert q(1, K, N) == ROWS, (K, N)
-    assert q(2, 4096, 12288) == ROWS and q(2, 11008, 4096) == TILE   # two waves per row at K = 11008, batch 2
+    assert q(2, 4096, 12288) == ROWS and q(2, 11008, 4096) == ROWS   # batch 2: ahead of the tile kernel on every 7B shape (r03 sweep)
+    assert q(3, 4096, 22016) == ROWS and q(4, 4096, 11008) == ROWS and q(4, 11008, 4096) == TILE and q(3, 8192, 1280) == TILE
     assert q(8, 4096, 11008) == LDS and q(8, 4096, 22016) == LDS and q(16, 4096, 11008) == TILE  # M K <= 32768
-    assert q(8, 4096, 4096) == TILE and q(4, 4096, 11008) == TILE
+    assert q(8, 4096, 4096) == TILE
     assert q(1, 4096, 4096, 64) == TILE       # groups below 128: the tile kernel
     assert q(0, 4096, 4096) == -1 and q(1, 4100, 4096) == -1
 

@@ -521,6 +521,57 @@ def test_fused_decode_step_replayed_as_one_hipgraph():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("version", ["gemm", "gemv"])
+def test_graphed_decoder_buckets_match_reference_logits(version):
+    """modules/fused/decode.py: prefill eagerly, then one hipGraph replay per token, the graph chosen by LENGTH BUCKET (bounds 10
+    and 16 here, so the four steps cross a bucket boundary and use two graphs); every step's logits equal the reference's
+    full-sequence logits, the device-side positions follow, and the first graph is reused when the decoder is sought back."""
+    from autoawq_amd.modules.fused.decode import GraphedDecoder
+
+    g = golden("tiny_llama_awq_gemm_outputs")
+    ref = g["logits"]
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    lm = _fused(version)
+    dec = GraphedDecoder(lm, batch=2, buckets=(10, 16))
+    assert dec.bounds == [10, 16, 32] and dec.bucket(9) == 10 and dec.bucket(11) == 16 and dec.bucket(17) == 32
+    rng = np.abs(ref).max()
+    out = dec.prefill(ids[:, :8]).float().cpu().numpy()
+    assert np.abs(out - ref[:, :8]).max() <= 2e-2 * rng and dec.position == 8
+    for t in range(8, 12):
+        step = dec.step(ids[:, t:t + 1]).float().cpu().numpy()
+        assert step.shape == (2, 1, 64)
+        assert np.abs(step[:, 0] - ref[:, t]).max() <= 2e-2 * rng, t
+    assert sorted(dec.graphs) == [10, 16] and dec.position == 12 and int(dec.pos.item()) == 12 and int(dec.len.item()) == 13
+    assert lm.model.blocks[0].attn.start_pos == 12
+    dec.seek(8)   # the cache rows are still there: decode the same four tokens again through the cached graphs
+    for t in range(8, 12):
+        step = dec.step(ids[:, t:t + 1]).float().cpu().numpy()
+        assert np.abs(step[:, 0] - ref[:, t]).max() <= 2e-2 * rng, t
+    assert sorted(dec.graphs) == [10, 16]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Hq,Hkv,T,bound", [(1, 32, 32, 65, 256), (1, 32, 32, 65, 2120), (1, 32, 8, 2049, 4096), (2, 8, 4, 300, 1024),
+                                              (1, 32, 32, 1, 4096), (1, 32, 32, 1000, 1024), (3, 16, 2, 129, 130)])
+def test_decode_attention_device_length_under_a_longer_bound(ops, B, Hq, Hkv, T, bound):
+    """A launch sized for `bound` rows (a hipGraph's length bucket) with the true length on the device: the rows that exist are
+    dealt to the launch's splits in the kernel; splits without rows contribute nothing."""
+    from oracle import decoder_oracle
+
+    gen = torch.Generator().manual_seed(B * 11 + Hq + T + bound)
+    Tmax = bound + 3
+    q = torch.randn((B, Hq, 128), generator=gen).half()
+    kc = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    vc = torch.randn((B, Tmax, Hkv, 128), generator=gen).half()
+    kc[:, T:] = 100.0  # rows past the length must not be read
+    vc[:, T:] = 100.0
+    want = decoder_oracle.attention_reference(q.numpy(), kc.numpy(), vc.numpy(), T)
+    ln = torch.tensor([T], dtype=torch.int32, device="cuda")
+    got = ops.decode_attention(q.cuda(), kc.cuda(), vc.cuda(), 1, len_dev=ln, max_len=bound).cpu().numpy().astype(np.float64)
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 2 ** -11
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["gemv", "gemm"])
 def test_five_launch_decode_stack_matches_the_plain_module_path(layout):
     """tools/bench_decode_model.py on a small stack (2 layers, hidden 512, 4 heads of 128, intermediate 1024): the logits of the

@@ -19,7 +19,7 @@ def build():
     for v in VARIANTS[1:]:
         obj = os.path.join(ROOT, "tools", "bin", "decoder_x.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                               "-fno-slp-vectorize", "-Wno-inline-asm", f"-DAWQ_ATTN_BLOCKS={v[0]}", f"-DAWQ_ATTN_MIN_ROWS={v[1]}",
+                               "-fno-slp-vectorize", "-Wno-inline-asm", f"-DAWQ_ATTN_BLOCKS={v[0]}", f"-DAWQ_ATTN_ROWS={v[1]}",
                                "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, "decoder.hip"), "-o", obj])
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so(v), obj] + others)
         os.remove(obj)

@@ -57,71 +57,60 @@ def run(layers=32, contexts=(64, 512, 2048), batch=1, steps=64, dev=None, verbos
     emb = nn.Embedding(V, H).half().to(dev)
     head = nn.Linear(H, V, bias=False).half().to(dev)
     lm = FusedCausalLM(LlamaLikeModel(V, blocks, emb, FasterTransformerRMSNorm(ones(), 1e-5)), head)
-    for blk in blocks:
-        blk.attn._resize_cache(batch)
-    pos = torch.zeros(1, dtype=torch.int32, device=dev)
-    ln = torch.ones(1, dtype=torch.int32, device=dev)
-    for blk in blocks:
-        blk.attn.use_device_positions(pos, ln)
+    from autoawq_amd.modules.fused.decode import GraphedDecoder
+
+    dec = GraphedDecoder(lm, batch=batch)  # one hipGraph per length bucket (256 / 1024 / 4096 ... rows); positions on the device
     tok = torch.randint(0, V, (batch, 1), device=dev, generator=gen)
     out = {}
-    s = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(s):
-        for blk in blocks:  # pretend a context is cached: random K / V rows
-            blk.attn.cache.k.normal_(generator=gen)
-            blk.attn.cache.v.normal_(generator=gen)
-        lm(tok)
-        s.synchronize()
-        if check:
-            pos.fill_(40)
-            ln.fill_(41)
-            for blk in blocks:
-                blk.attn.start_pos = 40
-            fused = lm(tok).float().clone()
-            pos.fill_(40)
-            ln.fill_(41)
-            for blk in blocks:
-                blk.attn.start_pos = 40
-                blk.attn.use_device_positions(None, None)
-            saved = (LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS, type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION)
-            LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS = False
-            type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION = False
-            try:
-                plain = lm(tok).float()
-            finally:
-                LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS, type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION = saved
-            for blk in blocks:
-                blk.attn.use_device_positions(pos, ln)
-            rel = float((fused - plain).abs().max() / plain.abs().max())
-            assert rel < 3e-2, f"fused decode path differs from the plain module path by {rel}"
-            if layout == "gemv" and batch == 1:  # the five-launch path on the row-streaming kernel is the one that ran
-                assert blocks[0]._can_fold_gemv(torch.empty((1, 1, H), dtype=torch.float16, device=dev))
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
-            lm(tok)
-            pos.add_(1)
-            ln.add_(1)
-        for ctx in contexts:
-            pos.fill_(ctx)
-            ln.fill_(ctx + 1)
-            for _ in range(4):
-                graph.replay()
-            pos.fill_(ctx)
-            ln.fill_(ctx + 1)
+    for blk in blocks:  # pretend a context is cached: random K / V rows
+        blk.attn.cache.k.normal_(generator=gen)
+        blk.attn.cache.v.normal_(generator=gen)
+    if check:
+        dec.seek(40)
+        fused = dec.step(tok).float().clone()          # captured + replayed: the path that is timed below
+        torch.cuda.synchronize()
+        assert dec.position == 41 and int(dec.pos.item()) == 41 and int(dec.len.item()) == 42
+        for blk in blocks:
+            blk.attn.start_pos = 40
+            blk.attn.use_device_positions(None, None)
+        lm.model.last_forward_num_tokens = 40
+        saved = (LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS, type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION)
+        LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS = False
+        type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION = False
+        try:
+            plain = lm(tok).float()
+        finally:
+            LlamaLikeBlock.FOLD_NORMS_INTO_PROJECTIONS, type(blocks[0].attn).FUSE_ROPE_INTO_ATTENTION = saved
+        for blk in blocks:
+            blk.attn.use_device_positions(dec.pos, dec.len)
+        rel = float((fused - plain).abs().max() / plain.abs().max())
+        assert rel < 3e-2, f"fused decode path differs from the plain module path by {rel}"
+        if layout == "gemv" and batch == 1:  # the five-launch path on the row-streaming kernel is the one that ran
+            assert blocks[0]._can_fold_gemv(torch.empty((1, 1, H), dtype=torch.float16, device=dev))
+    for ctx in contexts:
+        dec.seek(ctx)
+        dec.step(tok)                                  # captures this bucket's graph on first use
+        s = dec.stream
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                dec.replay()
+            s.synchronize()
+            dec.seek(ctx)
             s.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
             for _ in range(steps):
-                graph.replay()
+                dec.replay()
             e1.record(s)
             e1.synchronize()
-            ms = e0.elapsed_time(e1) / steps
-            out[ctx] = ms
-            if verbose:
-                name = "7B" if H == 4096 else "hidden-%d" % H
-                print(f"{name}-shape whole-model decode ({layout} layout), {layers} layers, batch {batch}, context {ctx}: {ms:.3f} ms/token = "
-                      f"{batch * 1000.0 / ms:.1f} tok/s (one hipGraph per step)", flush=True)
-    del graph, lm, blocks
+        ms = e0.elapsed_time(e1) / steps
+        out[ctx] = ms
+        if verbose:
+            name = "7B" if H == 4096 else "hidden-%d" % H
+            print(f"{name}-shape whole-model decode ({layout} layout), {layers} layers, batch {batch}, context {ctx}: {ms:.3f} ms/token = "
+                  f"{batch * 1000.0 / ms:.1f} tok/s (one hipGraph replay per step, bucket <= {dec.bucket(ctx + 1)} rows)", flush=True)
+    del dec
+    del lm, blocks
     torch.cuda.empty_cache()
     return out
 
