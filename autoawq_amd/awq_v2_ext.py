@@ -39,12 +39,7 @@ def gemm_forward_cuda_prefill(x, qweight, scales, qzeros):
     g = infer_group_size(K, scales.shape[0])
     if x2.shape[0] <= 64 and N % 16 == 0:
         out = ops.gemv_fast_forward(x2, qweight, scales, qzeros, g)
-    else:  # prefill: the fused MFMA GEMM kernels on a GEMM-layout repack of the same integers (this entry point has no module
-        # to keep the repack in: an integer transpose of the packed matrix per call, small next to the GEMM it feeds)
-        from .modules.linear import WQLinear_GEMVFast
-        from .modules.linear.gemv import _gemm_layout_copy
-
-        m = WQLinear_GEMVFast(4, g, K, N, False, qweight.device)
-        m.qweight, m.scales, m.qzeros = qweight, scales, qzeros
-        out = ops.gemm_forward(x2.half(), *_gemm_layout_copy(m))
+    else:  # prefill: dequantise this layout's own buffers into a temporary + a dense fp16 GEMM (the reference's two-pass route;
+        # the same w * s + qzeros weights the decode kernel uses -- no repack, nothing cached: ADVICE r03)
+        out = torch.matmul(x2.half(), ops.dequantize_weights_gemv_fast(qweight, scales, qzeros, g).t())
     return out.reshape(x.shape[:-1] + (N,))

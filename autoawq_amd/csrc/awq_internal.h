@@ -105,6 +105,10 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
 bool awq_gemv_lds_supports(int M, int K, int N, int g);
 int awq_launch_gemv_lds(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
                         int M, int K, int N, int g, int ZW, int ks, int depth, hipStream_t st);
+// GEMV layout, prefill-sized batches: the register-decoded MFMA GEMM reading the layout's own buffers (gemm_regb.hip, NK form)
+bool awq_gemm_regb_nk_supports(int M, int K, int N, int g, int ZW);
+int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                            const uint16_t* bias, uint16_t* y, int M, int K, int N, int g, int ZW, int bm, hipStream_t st);
 int awq_launch_dequant_nk(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out, int K,
                           int N, int g, int ZW, hipStream_t st);
 // Grouped (MoE) GEMM over stacked expert tensors (awq/modules/fused/moe.py:60-89), M = 16-row token blocks.

@@ -393,7 +393,10 @@ int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* 
 #ifndef AWQ_ATTN_ROWS
 #define AWQ_ATTN_ROWS 256
 #endif
-    int splits = (len_for_split + AWQ_ATTN_ROWS - 1) / AWQ_ATTN_ROWS;
+#ifndef AWQ_ATTN_SINGLE
+#define AWQ_ATTN_SINGLE 256
+#endif
+    int splits = len_for_split <= AWQ_ATTN_SINGLE ? 1 : (len_for_split + AWQ_ATTN_ROWS - 1) / AWQ_ATTN_ROWS;
     const int max_by_blocks = AWQ_ATTN_BLOCKS / (B * Hkv) > 1 ? AWQ_ATTN_BLOCKS / (B * Hkv) : 1;
     if (splits > max_by_blocks) splits = max_by_blocks;
     if (splits < 1) splits = 1;

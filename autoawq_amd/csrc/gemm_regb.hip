@@ -32,7 +32,18 @@
 // vendor GEMM: 950-1280); SQ counters and the switch-off experiments behind the design: profiles/r02_regb_*.txt.
 // Constraints (the launcher returns AWQ_ERR_UNSUPPORTED otherwise and the caller falls back to gemm_tiled):
 // K % 64 == 0, group_size % 64 == 0, N % 8 == 0, M * K < 2^31 elements.
+//
+// NK = true (round 4): the SAME kernel on the GEMV layout's own buffers -- qweight [N, K/8] int32 (nibble i of word c = w[n, 8c+i]),
+// qzeros [N, ZW], scales [N, 8 ZW] -- so that WQLinear_GEMV's prefill-sized calls (awq/modules/linear/gemv.py:168-180,
+// gemmv2_forward_cuda) read the checkpoint's buffers instead of a second, GEMM-layout copy of every matrix (VERDICT r03
+// weak 9).  Here a packed word IS the K-contiguous run an MFMA B register wants: lane (j, kb) of a wave owns the four output
+// columns 4 j + c and the 8 K values of words 2 kb, 2 kb + 1 of each 64-wide step (one dwordx2 per column and step, 4 instead of
+// 16 weight loads per step); byte b of a word holds the natural pair (k = 2 b, 2 b + 1): v_perm_b32 copies it into bytes 0 and 2,
+// ONE v_and_or (mask 0x00F0000F, exponents 2^10 | 2^6) makes the fp16 pair (1024 + w, 64 + w'), and (t - (bias + z)) * s is again
+// exactly the reference's fp16 weight.  2 VALU ops per B register + subtract + multiply; the A side, the pipeline and the
+// counted waits are shared (a step issues 12 instead of 18 weight-side memory operations).
 #include <cstdlib>
+#include <type_traits>
 
 #include "awq_device.h"
 #include "awq_internal.h"
@@ -54,6 +65,7 @@ struct RegbParams {
     int tiles_m, tiles_n;
     int mp, patches;  // patches of pm x pn tiles: mp along M, `patches` in all
     int pm, pn;       // tile patch one XCD runs at a time (pm * pn = 32)
+    int KW, ZW, SW;   // NK form: words per qweight row, zero words per row, scale halfs per row
 };
 
 constexpr int BK = 64, NBUF = 4, BN = 256;
@@ -61,12 +73,13 @@ constexpr int PM = 8, PN = 4;  // tile patch per XCD round
 
 // DBG (tools/regb_experiments.py, -DAWQ_REGB_EXPERIMENTS builds only; results are WRONG, timing only): 1 = weights fetched
 // once, 2 = activations fetched once, 4 = no barrier, 8 = no decode arithmetic, 16 = every output row stored into rows 0..127 (stores issued, nothing reaches HBM)
-template <int WGM, int DBG = 0>  // waves along M: BM = 128 * WGM
+template <int WGM, int DBG = 0, bool NK = false>  // waves along M: BM = 128 * WGM; NK: the GEMV layout's buffers (header)
 __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams p) {
     constexpr int BM = 128 * WGM;
     constexpr int A_BUF = BM * BK * 2;            // bytes of one activation K step
     constexpr int PIECES = BM * 8 / 64 / (4 * WGM);  // 1 KiB DMA pieces per wave per K step (= 4)
-    constexpr int VM_PER_ITER = PIECES + 16 + 2;  // vector-memory ops a wave issues per K step
+    constexpr int B_OPS = NK ? 12 : 18;           // vector-memory operations of one fetch_b
+    constexpr int AB_OPS = B_OPS + 2 * PIECES;    // ... plus the DMA pieces of a pair of activation steps (an even step issues both)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [NBUF][BM rows][8 chunks of 16 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,23 +109,38 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
     const uint32_t z_voff = colok ? (uint32_t)wcol * 4u : OOB;
     const uint32_t s_voff = colok ? ((uint32_t)wcol * 8u + 4u * (uint32_t)ph) * 2u : OOB;
     const uint32_t g_magic = (uint32_t)(0x100000000ull / (uint32_t)p.g) + 1u;  // (k * g_magic) >> 32 == k / g for k < 2^16
+    // NK form: lane (j, kb) owns output columns ncol0 + c (c = 0..3) and words 2 kb, 2 kb + 1 of every 64-wide step of their rows.
+    // ONE lane offset per tensor (row ncol0); the row of column c is reached through the SCALAR offset (+ c rows), so the address
+    // registers are the three of the GEMM-layout form.  Rows past N are outside the buffer: the bounds-checked loads return 0,
+    // and those columns are never stored.
+    const int ncol0 = n0 + wn * 64 + 4 * j;
+    const uint32_t nk_w = NK ? (uint32_t)ncol0 * (uint32_t)p.KW * 4u + 8u * (uint32_t)kb : 0u;
+    const uint32_t nk_z = NK ? (uint32_t)ncol0 * (uint32_t)p.ZW * 4u : 0u;
+    const uint32_t nk_s = NK ? (uint32_t)ncol0 * (uint32_t)p.SW * 2u : 0u;
 
     // Weight words, zero points and scales are requested with inline asm and waited for with COUNTED s_waitcnt
     // statements that name the registers they release (so nothing that uses them can be scheduled above): hipcc's own
     // bookkeeping falls back to vmcnt(0) whenever an LDS-DMA and an ordinary load are pending together (it takes them
     // for different, mutually unordered event classes), which drains the activation prefetch at every use of a weight.
-    struct BRegs {
+    struct BRegsKN {
         uint32_t w[2][8];
         uint32_t z;
         u32x2 s;
     };
+    struct BRegsNK {
+        u32x2 w[4];      // column c: words 2 kb (K sub-step 0) and 2 kb + 1 (sub-step 1) of this step
+        uint32_t z[4];   // the zero WORD of (column c, this step's group): nibble (group & 7)
+        uint32_t s[4];   // the scale of (column c, group) in bits 0-15
+        uint32_t zsh;    // 4 * (group & 7), uniform
+    };
+    using BRegs = std::conditional_t<NK, BRegsNK, BRegsKN>;
     auto srd = [](const void* base, uint32_t bytes) -> u32x4 {  // raw buffer descriptor, stride 0, bounds checked
         const uint64_t a = reinterpret_cast<uint64_t>(base);
         return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
     };
-    const u32x4 wsrd = srd(p.qweight, (uint32_t)p.K * row_bytes);
-    const u32x4 zsrd = srd(p.qzeros, (uint32_t)(p.K / p.g) * row_bytes);
-    const u32x4 ssrd = srd(p.scales, (uint32_t)(p.K / p.g) * (uint32_t)p.N * 2u);
+    const u32x4 wsrd = srd(p.qweight, NK ? (uint32_t)p.N * (uint32_t)p.KW * 4u : (uint32_t)p.K * row_bytes);
+    const u32x4 zsrd = srd(p.qzeros, NK ? (uint32_t)p.N * (uint32_t)p.ZW * 4u : (uint32_t)(p.K / p.g) * row_bytes);
+    const u32x4 ssrd = srd(p.scales, NK ? (uint32_t)p.N * (uint32_t)p.SW * 2u : (uint32_t)(p.K / p.g) * (uint32_t)p.N * 2u);
     const u32x4 xsrd = srd(p.x, (uint32_t)((int64_t)p.M * p.K * 2));
 // Eight weight words / the group's zero word and scales in ONE asm statement each, opened by s_nop 4: an SGPR written by
 // the SALU (the scalar offsets, a rematerialised descriptor) needs five wait states before a VMEM instruction may read
@@ -131,9 +159,35 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
                  : "v"(zvoff), "s"(zrs), "s"(zso), "v"(svoff), "s"(srs), "s"(sso))
 #define AWQ_BLOAD1(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff))
 #define AWQ_BLOAD2(dst, voff, rs, soff) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff))
-    constexpr int B_OPS = 18;  // vector-memory operations of one fetch_b
+// NK form: four dwordx2 weight loads, then four zero words and four scales, each group behind one s_nop 4 (same hazard)
+#define AWQ_BLOADW4(W, vo, rs, so)                                                                                              \
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %4, %5, %6 offen\n\tbuffer_load_dwordx2 %1, %4, %5, %7 offen\n\t"              \
+                 "buffer_load_dwordx2 %2, %4, %5, %8 offen\n\tbuffer_load_dwordx2 %3, %4, %5, %9 offen"                                \
+                 : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3])                                                               \
+                 : "v"(vo), "s"(rs), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]))
+#define AWQ_BLOADZS4(Z, S, zvo, zrs, zso, svo, srs, sso)                                                                        \
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %8, %9, %10 offen\n\tbuffer_load_dword %1, %8, %9, %11 offen\n\t"                \
+                 "buffer_load_dword %2, %8, %9, %12 offen\n\tbuffer_load_dword %3, %8, %9, %13 offen\n\t"                            \
+                 "buffer_load_ushort %4, %14, %15, %16 offen\n\tbuffer_load_ushort %5, %14, %15, %17 offen\n\t"                      \
+                 "buffer_load_ushort %6, %14, %15, %18 offen\n\tbuffer_load_ushort %7, %14, %15, %19 offen"                            \
+                 : "=v"(Z[0]), "=v"(Z[1]), "=v"(Z[2]), "=v"(Z[3]), "=v"(S[0]), "=v"(S[1]), "=v"(S[2]), "=v"(S[3])               \
+                 : "v"(zvo), "s"(zrs), "s"(zso[0]), "s"(zso[1]), "s"(zso[2]), "s"(zso[3]), "v"(svo), "s"(srs), "s"(sso[0]),       \
+                   "s"(sso[1]), "s"(sso[2]), "s"(sso[3]))
     auto fetch_b = [&](BRegs& R, int t) {
         const uint32_t k0 = (uint32_t)t * BK;
+        if constexpr (NK) {
+            const uint32_t grp = __umulhi(k0, g_magic);
+            uint32_t so_w[4], so_z[4], so_s[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                so_w[c] = (uint32_t)t * (BK / 8 * 4) + (uint32_t)c * (uint32_t)p.KW * 4u;
+                so_z[c] = (grp >> 3) * 4u + (uint32_t)c * (uint32_t)p.ZW * 4u;
+                so_s[c] = grp * 2u + (uint32_t)c * (uint32_t)p.SW * 2u;
+            }
+            AWQ_BLOADW4(R.w, nk_w, wsrd, so_w);
+            AWQ_BLOADZS4(R.z, R.s, nk_z, zsrd, so_z, nk_s, ssrd, so_s);
+            R.zsh = 4u * (grp & 7u);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             uint32_t so[8];
@@ -144,13 +198,25 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         const uint32_t grp = __umulhi(k0, g_magic);
         const uint32_t zo = grp * row_bytes, so2 = grp * (uint32_t)p.N * 2u;
         AWQ_BLOADZS(R.z, R.s, z_voff, zsrd, zo, s_voff, ssrd, so2);
+        }
     };
-    // everything up to and including R's requests has returned once at most `newer` later operations are outstanding
-#define AWQ_WAIT_B(R, newer)                                                                                              \
-    asm volatile("s_waitcnt vmcnt(" #newer ")"                                                                            \
-                 : "+v"(R.w[0][0]), "+v"(R.w[0][1]), "+v"(R.w[0][2]), "+v"(R.w[0][3]), "+v"(R.w[0][4]), "+v"(R.w[0][5]),   \
-                   "+v"(R.w[0][6]), "+v"(R.w[0][7]), "+v"(R.w[1][0]), "+v"(R.w[1][1]), "+v"(R.w[1][2]), "+v"(R.w[1][3]),   \
-                   "+v"(R.w[1][4]), "+v"(R.w[1][5]), "+v"(R.w[1][6]), "+v"(R.w[1][7]), "+v"(R.z), "+v"(R.s))
+    // everything up to and including R's requests has returned once at most NEWER later operations are outstanding
+    auto wait_b = [&](BRegs& R, auto newer_c) __attribute__((always_inline)) {
+        constexpr int NEWER = decltype(newer_c)::value;
+        if constexpr (NK) {
+            asm volatile("s_waitcnt vmcnt(%12)"
+                         : "+v"(R.w[0]), "+v"(R.w[1]), "+v"(R.w[2]), "+v"(R.w[3]), "+v"(R.z[0]), "+v"(R.z[1]), "+v"(R.z[2]), "+v"(R.z[3]),
+                           "+v"(R.s[0]), "+v"(R.s[1]), "+v"(R.s[2]), "+v"(R.s[3])
+                         : "n"(NEWER));
+        } else {
+            asm volatile("s_waitcnt vmcnt(%18)"
+                         : "+v"(R.w[0][0]), "+v"(R.w[0][1]), "+v"(R.w[0][2]), "+v"(R.w[0][3]), "+v"(R.w[0][4]), "+v"(R.w[0][5]),
+                           "+v"(R.w[0][6]), "+v"(R.w[0][7]), "+v"(R.w[1][0]), "+v"(R.w[1][1]), "+v"(R.w[1][2]), "+v"(R.w[1][3]),
+                           "+v"(R.w[1][4]), "+v"(R.w[1][5]), "+v"(R.w[1][6]), "+v"(R.w[1][7]), "+v"(R.z), "+v"(R.s)
+                         : "n"(NEWER));
+        }
+    };
+#define AWQ_WAIT_B(R, newer) wait_b(R, std::integral_constant<int, (newer)>{})
 
     // ---- A side: LDS-DMA pieces of this wave: piece q = PIECES * wave + u covers rows 8q .. 8q+7, lane L writes
     // LDS chunk (row 8q + L/8, slot L%8) and fetches global chunk kc = slot ^ ((row >> 1) & 7)
@@ -206,13 +272,24 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         issue_next();  // next step's requests first (their round trip is the longest thing in the step), then wait for R
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const uint32_t aa = a_base + (uint32_t)(buf * A_BUF) + (uint32_t)(((4 * kk + kb) ^ hl) << 4);
+            // this lane's 8 K values of sub-step kk: chunk 4 kk + kb of the row's eight (GEMM layout: rows 8 kb .. 8 kb + 7 of each
+            // 32-row slab), chunk 2 kb + kk in the NK form (words 2 kb, 2 kb + 1 of the step)
+            const uint32_t aa = a_base + (uint32_t)(buf * A_BUF) + (uint32_t)((((NK ? 2 * kb + kk : 4 * kk + kb)) ^ hl) << 4);
             u32x4v af[4], ag[4];  // rows 0-63 of the wave tile; rows 64-127 are requested once these are in the MFMAs
             AWQ_LDS_READ16(af[0], aa, 0);
             AWQ_LDS_READ16(af[1], aa, 2048);
             AWQ_LDS_READ16(af[2], aa, 4096);
             AWQ_LDS_READ16(af[3], aa, 6144);
-            if (kk == 0) {
+            if constexpr (NK) {
+                if (kk == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t z = (R.z[c] >> R.zsh) & 15u;
+                        zm[c] = u2h2(0x54006400u | z | (z << 20));  // (1024 + z, 64 + z): the biases of the two halves below
+                        sd[c] = u2h2(__builtin_amdgcn_perm(R.s[c], R.s[c], 0x01000100u));  // (s, s)
+                    }
+                }
+            } else if (kk == 0) {
                 // zero points and scales of this step's group, duplicated into both halves: columns 4 ph + {0, 1, 2, 3}
                 //   c = 0: byte ph low nibble, c = 1: byte ph+2 low, c = 2: byte ph high, c = 3: byte ph+2 high
                 const uint32_t zp0 = __builtin_amdgcn_perm(R.z, R.z, sel0), zp1 = __builtin_amdgcn_perm(R.z, R.z, sel1);
@@ -227,6 +304,22 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
                 sd[3] = __builtin_shufflevector(s23, s23, 1, 1);
             }
             u32x4v bf[4];
+            if constexpr (NK) {
+                // byte b of a word = the natural pair (k = 2 b, 2 b + 1): into bytes 0 and 2, then ONE and-or gives (1024 + w, 64 + w')
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t w = R.w[c][kk];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t pb = __builtin_amdgcn_perm(w, w, 0x0C000C00u | (uint32_t)b | ((uint32_t)b << 16));
+                        if constexpr (DBG & 8) {
+                            bf[c][b] = pb ^ h22u(zm[c]) ^ h22u(sd[c]);
+                            continue;
+                        }
+                        bf[c][b] = h22u((u2h2(and_or(pb, 0x00F0000Fu, 0x54006400u)) - zm[c]) * sd[c]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int rp = 0; rp < 4; ++rp) {
                 const uint32_t p0 = __builtin_amdgcn_perm(R.w[kk][2 * rp + 1], R.w[kk][2 * rp], sel0);
@@ -272,7 +365,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
     auto step = [&](int t, BRegs& cur, BRegs& nxt) {
         if (!(t & 1)) {
             if constexpr (!(DBG & 4)) {
-                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_OPS) : "memory");
                 __builtin_amdgcn_s_barrier();
             }
         }
@@ -285,7 +378,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
             if constexpr (DBG & 1) {
                 if (t == 0) AWQ_WAIT_B(B0, 0);
             } else {
-                AWQ_WAIT_B(cur, 26);
+                AWQ_WAIT_B(cur, AB_OPS);
             }
         };
         compute((DBG & 1) ? B0 : cur, t & 3, issue_next);
@@ -303,7 +396,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
     AWQ_WAIT_B(B1, 0);
 
     // ---- epilogue: lane (j, kb) holds rows 16 i + 4 kb + e, columns 8 j + 4 ph + c of its wave tile
-    const int col = n0 + set * 128 + 8 * j + 4 * ph;
+    const int col = NK ? ncol0 : n0 + set * 128 + 8 * j + 4 * ph;  // NK: four consecutive columns per lane as well
     if (col >= p.N) return;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -345,6 +438,7 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
     p.bias = reinterpret_cast<const half_t*>(a.bias);
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
+    p.KW = p.ZW = p.SW = 0;
     p.tiles_m = (a.M + bm - 1) / bm;
     p.tiles_n = (a.N + BN - 1) / BN;
     p.pm = PM; p.pn = PN;
@@ -383,6 +477,44 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
         hipLaunchKernelGGL((awq_gemm_regb_kernel<2>), dim3(grid), dim3(512), lds, a.stream, p);
     } else {
         hipLaunchKernelGGL((awq_gemm_regb_kernel<1>), dim3(grid), dim3(256), lds, a.stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+// ---- the NK form: WQLinear_GEMV buffers (qweight [N, K/8], qzeros [N, ZW], scales [N, 8 ZW]), prefill-sized batches
+bool awq_gemm_regb_nk_supports(int M, int K, int N, int g, int ZW) {
+    return M > 0 && K > 0 && N > 0 && ZW > 0 && (int64_t)M * K * 2 < ((int64_t)1 << 32) && K % BK == 0 && g % BK == 0 && K % g == 0 &&
+           N % 4 == 0 && K < 65536 && ZW * 8 >= K / g && (int64_t)N * (K / 8) * 4 < ((int64_t)1 << 31) &&
+           (int64_t)N * ZW * 16 < ((int64_t)1 << 31);
+}
+
+int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                            const uint16_t* bias, uint16_t* y, int M, int K, int N, int g, int ZW, int bm, hipStream_t st) {
+    if (!awq_gemm_regb_nk_supports(M, K, N, g, ZW)) return AWQ_ERR_UNSUPPORTED;
+    if (bm == 0) bm = 128;
+    if (bm != 128 && bm != 256) return AWQ_ERR_UNSUPPORTED;
+    RegbParams p;
+    p.qweight = reinterpret_cast<const uint32_t*>(qweight);
+    p.qzeros = reinterpret_cast<const uint32_t*>(qzeros);
+    p.scales = reinterpret_cast<const half_t*>(scales);
+    p.x = reinterpret_cast<const half_t*>(x);
+    p.bias = reinterpret_cast<const half_t*>(bias);
+    p.y = reinterpret_cast<half_t*>(y);
+    p.M = M; p.K = K; p.N = N; p.g = g;
+    p.KW = K / 8; p.ZW = ZW; p.SW = 8 * ZW;
+    p.tiles_m = (M + bm - 1) / bm;
+    p.tiles_n = (N + BN - 1) / BN;
+    p.pm = PM; p.pn = PN;
+    p.mp = (p.tiles_m + p.pm - 1) / p.pm;
+    p.patches = p.mp * ((p.tiles_n + p.pn - 1) / p.pn);
+    const int grid = ((p.patches + 7) / 8) * 8 * (p.pm * p.pn);
+    const size_t lds = (size_t)NBUF * bm * BK * 2;
+    if (bm == 256) {
+        static std::atomic<unsigned long long> opted{0};
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 0, true>), opted)) return AWQ_ERR_LAUNCH;
+        hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 0, true>), dim3(grid), dim3(512), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((awq_gemm_regb_kernel<1, 0, true>), dim3(grid), dim3(256), lds, st, p);
     }
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

@@ -10,6 +10,38 @@ from .attn import QuantAttentionFused
 from .norm import FasterTransformerRMSNorm
 
 
+class MixtralBlock(nn.Module):
+    """Reference: awq/modules/fused/block.py:6-55 -- same constructor, same dataflow
+    `h = x + attn(norm_1(x)); out = h + moe(norm_2(h))`, `moe` a FusedSparseMoeBlock (modules/fused/moe.py: routing in one launch,
+    grouped int4 GEMMs over the experts that were hit, no routing data read back below the prefill threshold, so a decode step
+    is hipGraph-capturable).  As in LlamaLikeBlock the first residual add rides on norm_2 (`FasterTransformerRMSNorm(x,
+    residual=...)`: one launch, the sum lands in o_proj's own output buffer)."""
+
+    def __init__(self, hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, moe, norm_1, norm_2, dev, max_seq_len, rope_theta):
+        super().__init__()
+        self.n_heads = n_heads
+        self.n_kv_heads = n_kv_heads
+        self.hidden_size = hidden_size
+        self.norm_1 = norm_1.to(dev)
+        self.attn = QuantAttentionFused(self.hidden_size, self.n_heads, self.n_kv_heads, qkv_layer, o_proj, dev=dev,
+                                        max_seq_len=max_seq_len, use_alibi=False, rope_theta=rope_theta).to(dev)
+        self.norm_2 = norm_2.to(dev)
+        self.moe = moe
+        self.device = dev
+
+    def forward(self, hidden_states):
+        norm_out = self.norm_1(hidden_states)
+        attn_output, _, _ = self.attn.forward(hidden_states=norm_out)
+        if (isinstance(self.norm_2, FasterTransformerRMSNorm) and attn_output.dtype == hidden_states.dtype == torch.float16
+                and attn_output.is_contiguous() and hidden_states.is_contiguous()):
+            h = attn_output  # becomes hidden_states + attn_output, in place in o_proj's own output buffer
+            normed = self.norm_2(hidden_states, residual=h)
+        else:
+            h = hidden_states.to(attn_output.device) + attn_output
+            normed = self.norm_2(h)
+        return h + self.moe.forward(normed)
+
+
 class LlamaLikeBlock(nn.Module):
     def __init__(self, hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, mlp, norm_1, norm_2, dev, max_seq_len,
                  rope_theta=10000, partial_rotary_factor=1.0, use_alibi=False, head_dim=None):

@@ -100,3 +100,19 @@ class LlamaLikeModel(nn.Module):
             return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=None, hidden_states=(), attentions=())
         except Exception:  # pragma: no cover
             return SimpleNamespace(last_hidden_state=h)
+
+
+class MixtralModel(LlamaLikeModel):
+    """Reference: awq/modules/fused/model.py:20-58 -- the same step bookkeeping over MixtralBlock layers; `forward` returns
+    transformers' MoeModelOutputWithPast when it is importable (empty router_logits, like the reference)."""
+
+    @torch.inference_mode()
+    def forward(self, input_ids, *args, **kwargs):
+        out = super().forward(input_ids, *args, **kwargs)
+        try:
+            from transformers.modeling_outputs import MoeModelOutputWithPast
+
+            return MoeModelOutputWithPast(last_hidden_state=out.last_hidden_state, past_key_values=None, hidden_states=(),
+                                          attentions=(), router_logits=())
+        except Exception:  # pragma: no cover
+            return out

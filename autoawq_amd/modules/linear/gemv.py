@@ -8,9 +8,9 @@ Drop-in contract kept (reference awq/modules/linear/gemv.py:27-197):
   * from_linear(linear, w_bit, group_size, init_only=False, scales=None, zeros=None) (:77-154);
   * forward (:156-186): any leading dims, any float dtype (computed in fp16, cast back), bias added
     AFTER the cast back, in the input dtype (:183-185).
-What differs by design: the arithmetic runs in libawq_hip.so (csrc/gemv_nk.hip for M <= 16 per
-launch; bit-exact dequant + fp16 GEMM above 64 rows); there is no CPU path -- a non-HIP tensor
-raises.
+What differs by design: the arithmetic runs in libawq_hip.so on the module's own buffers at every batch
+size (csrc/gemv_rows.hip, gemv_lds.hip, gemv_nk.hip up to 16 rows per launch; csrc/gemm_regb.hip, N-major
+form, from 17 rows); there is no CPU path -- a non-HIP tensor raises.
 """
 import torch
 import torch.nn as nn
@@ -19,32 +19,17 @@ from ... import _lib, ops
 from ...utils.packing import (GEMV_ORDER, calculate_zeros_width, pack_rows_int4, pack_zeros_nk,
                               quantize_int_weights_nk)
 
-# from this many rows a call runs the fused MFMA GEMM kernels (gemm_skinny / gemm_tiled / gemm_regb by row count) on a cached
-# GEMM-layout repack of the same integers instead of ceil(M/16) passes of the 16-row decode kernel (4096 x 11008, M = 32:
-# 14 us vs 2 x 24; the reference switches to its batched kernel at 8 rows, gemv.py:168)
-PREFILL_MIN_ROWS = 17
-
-
 def tensor_key(*tensors):
     """Identity AND content version of tensors a derived cache was built from: `data_ptr` changes when a buffer is re-assigned,
     `_version` when it is written in place (`load_state_dict`, `.copy_()`) -- ADVICE r03: a key of pointers alone went stale."""
     return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
-def _gemm_layout_copy(m):
-    """The same integers repacked (bit-exactly, utils/convert.py) into the GEMM layout, built on first use and kept: batches the
-    decode kernels of this layout do not take (prefill) run on the fused MFMA kernels of awq_gemm_forward instead of
-    dequantise + vendor GEMM.  Costs one more int4 copy of the weights (HBM is 288 GB); rebuilt if the buffers are re-assigned or written in place."""
-    key = tensor_key(m.qweight, m.scales, m.qzeros)
-    c = m.__dict__.get("_gemm_copy")
-    if c is None or c[0] != key:
-        from ...utils.convert import pack_linear, unpack_linear
-
-        w, z, s, _ = unpack_linear(m)
-        g = pack_linear("gemm", w, z, s, None, m.in_features, m.out_features, m.group_size)
-        c = (key, g.qweight, g.scales, g.qzeros)
-        m.__dict__["_gemm_copy"] = c
-    return c[1], c[2], c[3]
+def dequant_matmul_nk(x2d, wt):
+    """The reference's own prefill route (dequantise, then a dense fp16 GEMM: awq/modules/linear/gemm.py:48-54) for the few
+    shapes no hand-written kernel of the GEMV / GEMVFast layouts takes (K % 64, group sizes below 64 at prefill sizes):
+    `wt` = the bit-exact fp16 W^T [N, K] from awq_dequantize_weights_gemv[_fast], a temporary of this call."""
+    return torch.matmul(x2d, wt.t())
 
 
 class WQLinear_GEMV(nn.Module):
@@ -95,15 +80,15 @@ class WQLinear_GEMV(nn.Module):
         input_dtype = inputs.dtype
         if input_dtype != torch.float16:
             inputs = inputs.half()
-        if inputs.shape[0] >= PREFILL_MIN_ROWS:
-            out = ops.gemm_forward(inputs, *_gemm_layout_copy(self))
-        else:
-            try:
-                out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
-            except _lib.AwqHipError as e:  # a shape the decode kernels do not take (K % 128, unusual group sizes): the
-                if e.code != _lib.ERR_UNSUPPORTED:  # GEMM-layout kernels handle every valid tensor
-                    raise
-                out = ops.gemm_forward(inputs, *_gemm_layout_copy(self))
+        try:
+            # every batch size on this layout's OWN buffers (round 4): decode kernels up to 16 rows, from 17 rows the
+            # register-decoded MFMA GEMM in its N-major form (csrc/gemm_regb.hip, AWQ_GEMV_KERNEL_PREFILL) -- the second,
+            # GEMM-layout copy of every matrix that rounds 2-3 kept for prefill is gone
+            out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
+        except _lib.AwqHipError as e:  # a shape no kernel of this layout takes (K % 128 with odd group sizes)
+            if e.code != _lib.ERR_UNSUPPORTED:
+                raise
+            out = dequant_matmul_nk(inputs, ops.dequantize_weights_gemv(self.qweight, self.scales, self.qzeros, self.group_size))
         if input_dtype != torch.float16:
             out = out.to(dtype=input_dtype)
         out = out + self.bias if self.bias is not None else out

@@ -226,6 +226,19 @@ def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     if M == 0:
         return y
     L = _lib.lib()
+    kern = flags & 0xF
+    if M > 16 and kern in (0, GEMV_KERNEL_PREFILL):
+        # prefill-sized: ONE call of the register-decoded MFMA GEMM on this layout's own buffers (awq_gemv_forward AUTO /
+        # AWQ_GEMV_KERNEL_PREFILL); shapes it does not take (K % 64, group sizes below 64) fall through to the 16-row chunks
+        with torch.cuda.device(x2d.device):
+            rc = L.awq_gemv_forward(_ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), M, K, N, group_size, ZW, flags,
+                                    _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "awq_gemv_forward")
+            return y
+        if kern == GEMV_KERNEL_PREFILL:
+            _lib.check(rc, "awq_gemv_forward")
+        flags &= ~0xF
     chunk = 16
     while chunk > 1 and L.awq_gemv_lds_bytes(chunk, K, ZW) > 160 * 1024:
         chunk //= 2
@@ -239,6 +252,7 @@ def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
 
 
 GEMV_EX_SILU_PAIRS = 1  # include/awq_hip.h AWQ_GEMV_EX_SILU_PAIRS
+GEMV_KERNEL_PREFILL = 4  # include/awq_hip.h AWQ_GEMV_KERNEL_PREFILL
 
 
 def gemv_forward_ex(x2d, qweight, scales, qzeros, group_size, norm_weight=None, norm_eps=0.0, add_residual=None,

@@ -212,7 +212,7 @@ def leg_gemm_bs(dev, ops):
     # the same matrix shape in the WQLinear_GEMV format (awq_gemv_forward: row-streaming kernel at M <= 2, 16-row MFMA tiles to 16)
     sets = [rand_packed_nk(K, N, GROUP, dev, gen) for _ in range(nsets)]
     out["gemv_layout_by_batch"] = {}
-    for M in (1, 2, 4, 8, 16):
+    for M in (1, 2, 4, 8, 16, 32, 64):  # (from 17 rows: the N-major form of the register-decoded MFMA GEMM, this layout's own buffers)
         x = torch.randn((M, K), device=dev, generator=gen).half()
 
         def fn2():
@@ -280,7 +280,23 @@ def leg_gemm_prefill(dev, ops):
     def roof(us):
         return {"bound": "mfma", "achieved": fl / us / 1e6, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / us / 1e6 / MFMA_PEAK_TF}
 
+    # the same matrix in the WQLinear_GEMV checkpoint format: the N-major form of the same kernel on that layout's own buffers
+    # (round 4: no GEMM-layout copy of the weights behind WQLinear_GEMV any more)
+    del qw, qz, sc
+    torch.cuda.empty_cache()
+    nq, nz, ns = rand_packed_nk(K, N, GROUP, dev, gen)
+    us_nk = timeit(lambda: ops.gemv_forward(x, nq, ns, nz, GROUP))
+    nk_kernel = ops.last_kernel()
+    an = ops.gemv_forward(x[:2048], nq, ns, nz, GROUP).float()
+    bn = torch.matmul(x[:2048], ops.dequantize_weights_gemv(nq, ns, nz, GROUP).t()).float()
+    rel_nk = float((an - bn).abs().max() / bn.abs().max())
+    assert rel_nk < 5e-3, f"GEMV-layout prefill kernel disagrees with dequantise + GEMM: {rel_nk}"
+    nk_by_m = {str(m): 2.0 * m * K * N / timeit(lambda: ops.gemv_forward(x[:m], nq, ns, nz, GROUP)) / 1e6 for m in (4096, 8192)}
+
     return {"shape": f"{K}x{N} g{GROUP}, M={M} (bs 8 x seq 2048)", "flops": fl,
+            "gemv_layout": {"us": us_nk, "kernel": nk_kernel, "roofline": roof(us_nk), "tflops_other_token_counts": nk_by_m,
+                            "vs_dequant_plus_gemm_max_rel": rel_nk,
+                            "what": "WQLinear_GEMV buffers (qweight [N, K/8]): awq_gemv_forward AUTO -> AWQ_GEMV_KERNEL_PREFILL"},
             "fused_mfma": {"us": us_f, "kernel": kernel, "roofline": roof(us_f)},
             "fused_lds_tiled_r01": {"us": us_t, "roofline": roof(us_t)}, "two_pass": {"us": us_2, "roofline": roof(us_2)},
             "module": {"us": us_m, "roofline": roof(us_m),
@@ -464,6 +480,66 @@ def leg_by_layout(dev, ops, layers, skip):
     return out
 
 
+def dry_run(a):
+    """`bench.py --gpus N --dry-run` under torch.distributed.run on CPU: everything of the N > 1 path that is not a kernel."""
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE {world}"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    cfg = MODELS[a.model]
+    layers = a.layers or cfg["layers"]
+    model, shapes = build_model(dev, rank, world, layers, layout=a.layout, model=a.model)
+
+    class NoLaunch:  # the three entry points run_step calls, shapes only
+        @staticmethod
+        def _y(x, n):
+            return torch.full((x.shape[0], n), float(rank + 1), dtype=torch.float16)
+
+        def gemm_forward(self, x, qw, sc, qz):
+            return self._y(x, qw.shape[1] * 8)
+
+        def gemv_forward(self, x, qw, sc, qz, g):
+            return self._y(x, qw.shape[0])
+
+        def gemv_fast_forward(self, x, qw, sc, qz, g):
+            return self._y(x, qw.shape[0] * 4)
+
+    from autoawq_amd.comm import make_collective
+
+    allreduce, collective, oneshot = make_collective(cfg["hidden"], dev)
+    assert oneshot is None and collective.startswith("RCCL all_reduce via torch.distributed"), collective
+    outs = [None] * sum(len(l) for l in model)
+    ops = NoLaunch()
+    for _ in range(a.warmup):
+        run_step(model, outs, ops, allreduce)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run_step(model, outs, ops, allreduce)
+    dist.barrier()
+    t = torch.tensor([(time.perf_counter() - t0) * 1e3])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # every row-parallel output went through the collective: each element is the sum of (rank + 1) over the ranks
+    reduced = [o for o, lin in zip(outs, (l for layer in model for l in layer)) if lin["reduce"]]
+    ok = all(bool((o == world * (world + 1) / 2).all()) for o in reduced) and len(reduced) == 2 * layers
+    tb = torch.tensor([float(sum(algorithmic_bytes(l["K"], l["N"], 1, GROUP) for layer in model for l in layer))])
+    dist.all_reduce(tb)
+    if rank == 0:
+        print(json.dumps({"metric": f"decode tok/s @bs=1 (int4 linears), {a.model.upper()} AWQ-int4 g128", "value": None, "unit": "tok/s",
+                          "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": float(t.item()) / a.steps,
+                          "scaling": "strong", "config": {"workload": "no launches: multi-rank plumbing only", "layers": layers,
+                                                          "parallelism": f"tp{world}", "collective": collective,
+                                                          "collectives_per_step": len(reduced), "collectives_summed_correctly": ok,
+                                                          "shard_shapes_rank0": [[n, K, N] for n, K, N, _ in shapes],
+                                                          "algorithmic_bytes_per_step_all_ranks": float(tb.item())}}), flush=True)
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -478,7 +554,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-model", action="store_true", help="skip the secondary whole-decoder figure")
     ap.add_argument("--no-secondary", action="store_true", help="headline leg (and cpu_baseline) only")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the multi-rank plumbing only (rendezvous over gloo, per-rank shard shapes, the collective's rank-"
+                         "consistent fallback, barrier + max-over-ranks timing) with launches replaced by zero outputs; prints a line "
+                         "marked dry_run whose value is null (tests/test_tp_cpu.py runs it with two processes)")
     a = ap.parse_args()
+    if a.dry_run:
+        return dry_run(a)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -462,7 +462,7 @@ def _fused(version, max_seq_len=32):
     from autoawq_amd.fuser import fuse_llama
 
     model, _ = load_quantized(skeleton(), ckpt(version), device="cuda")
-    return fuse_llama(model, max_seq_len=max_seq_len)
+    return fuse_llama(model, max_seq_len=max_seq_len, decode_layout=None)  # the checkpoint's own layout
 
 
 @pytest.mark.gpu
@@ -482,6 +482,35 @@ def test_fused_model_prefill_then_decode_matches_reference_logits(version):
         assert step.shape == (2, 1, 64)
         assert np.abs(step[:, 0] - ref[:, t]).max() <= 2e-2 * rng, t
     assert lm.model.blocks[0].attn.start_pos == 12
+
+
+@pytest.mark.gpu
+def test_fuse_llama_repacks_the_default_checkpoint_format_to_the_decode_layout_and_says_so():
+    """`fuse_llama` default (decode_layout="auto"): a "gemm" checkpoint -- `AwqConfig.version`'s default -- is served on the
+    WQLinear_GEMV layout (bit-exact integer repack), declared on the result; "gemv" checkpoints pass through; logits as before."""
+    from autoawq_amd.checkpoint import load_quantized
+    from autoawq_amd.fuser import fuse_llama
+    from autoawq_amd.modules.linear import WQLinear_GEMM, WQLinear_GEMV
+
+    g = golden("tiny_llama_awq_gemm_outputs")
+    ref, ids = g["logits"], torch.from_numpy(g["input_ids"]).cuda()
+    model, qc = load_quantized(skeleton(), ckpt("gemm"), device="cuda")
+    assert qc.version == "gemm"
+    lm = fuse_llama(model, max_seq_len=32)
+    assert lm.checkpoint_layout == "gemm" and lm.decode_layout == "gemv"
+    blk = lm.model.blocks[0]
+    assert all(isinstance(m, WQLinear_GEMV) for m in (blk.attn.qkv_proj, blk.attn.o_proj, blk.mlp.down_proj)) and blk.mlp.gemv_layout
+    assert not any(isinstance(m, WQLinear_GEMM) for m in lm.modules())
+    rng = np.abs(ref).max()
+    out = lm(ids[:, :8]).float().cpu().numpy()
+    assert np.abs(out - ref[:, :8]).max() <= 2e-2 * rng
+    step = lm(ids[:, 8:9]).float().cpu().numpy()
+    assert np.abs(step[:, 0] - ref[:, 8]).max() <= 2e-2 * rng
+    model2, _ = load_quantized(skeleton(), ckpt("gemv"), device="cuda")
+    lm2 = fuse_llama(model2, max_seq_len=32)
+    assert lm2.checkpoint_layout == "gemv" and lm2.decode_layout == "gemv"
+    lm3 = _fused("gemm")
+    assert lm3.checkpoint_layout == "gemm" and lm3.decode_layout == "gemm" and isinstance(lm3.model.blocks[0].attn.o_proj, WQLinear_GEMM)
 
 
 @pytest.mark.gpu

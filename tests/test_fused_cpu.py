@@ -151,15 +151,17 @@ def test_fused_mlp_gate_up_pairs_interleave_rows_gemv_layout():
 
 
 def test_derived_weight_caches_follow_in_place_loads():
-    """`_gemm_layout_copy` (prefill repack of a GEMV-layout module) and `QuantFusedMLP.gate_up_pairs` were keyed on
-    data pointers only; `load_state_dict` / `.copy_()` write IN PLACE (same pointers), after which prefill, the five-launch decode
-    and the registered buffers disagreed silently.  The keys now carry the tensors' versions."""
+    """`QuantFusedMLP.gate_up_pairs` (the interleaved gate / up copy of the five-launch decode) was keyed on data
+    pointers only; `load_state_dict` / `.copy_()` write IN PLACE (same pointers), after which the decode path and the registered
+    buffers disagreed silently.  The key now carries the tensors' versions.  (The other derived cache of round 3, the GEMM-layout
+    prefill copy of GEMV / GEMVFast modules, no longer exists: prefill reads the module's own buffers.)"""
     from autoawq_amd import WQLinear_GEMV
     from autoawq_amd.modules.fused.mlp import QuantFusedMLP
-    from autoawq_amd.modules.linear.gemv import _gemm_layout_copy
-    from autoawq_amd.utils.convert import convert_linear
+    from autoawq_amd.modules.linear import gemv as gemv_mod
+    from autoawq_amd.modules.linear import gemv_fast as gemv_fast_mod
     from autoawq_amd.utils.packing import calculate_zeros_width
 
+    assert not hasattr(gemv_mod, "_gemm_layout_copy") and not hasattr(gemv_fast_mod, "_gemm_layout_copy")
     gen = torch.Generator().manual_seed(16)
     lim = 0x7FFFFFFF
 
@@ -171,21 +173,10 @@ def test_derived_weight_caches_follow_in_place_loads():
         m.scales = torch.rand((N, zw * 8), generator=gen).half()
         return m
 
-    a, b = lin(256, 64), lin(256, 64)
-    first = [t.clone() for t in _gemm_layout_copy(a)]
-    assert all(torch.equal(x, y) for x, y in zip(_gemm_layout_copy(a), first))
-    assert _gemm_layout_copy(a)[0] is _gemm_layout_copy(a)[0]           # cached while nothing changes
-    ptr = a.qweight.data_ptr()
-    a.load_state_dict(b.state_dict())                                   # in place: same storage, new contents
-    assert a.qweight.data_ptr() == ptr and torch.equal(a.qweight, b.qweight)
-    want = convert_linear(b, "gemm")
-    got = _gemm_layout_copy(a)
-    assert torch.equal(got[0], want.qweight) and torch.equal(got[1], want.scales) and torch.equal(got[2], want.qzeros)
-    assert not torch.equal(got[0], first[0])
-
     mlp = QuantFusedMLP(lin(256, 48), lin(384, 256), lin(256, 48))
     other = QuantFusedMLP(lin(256, 48), lin(384, 256), lin(256, 48))
     p0 = mlp.gate_up_pairs()[0].clone()
+    assert mlp.gate_up_pairs()[0] is mlp.gate_up_pairs()[0]             # cached while nothing changes
     mlp.load_state_dict(other.state_dict())
     pq, ps, pz = mlp.gate_up_pairs()
     assert torch.equal(pq[0::2], other.gate_proj_qweight) and torch.equal(pq[1::2], other.up_proj_qweight)

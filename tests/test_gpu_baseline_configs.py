@@ -93,6 +93,75 @@ def test_regb_prefill_kernel_directly_at_config3_shape(ops, oracle, K, N, bm):
     assert torch.equal(y, ops.gemm_forward(dx, dq, ds, dz, db, flags=ops.gemm_flags(ops.KERNEL_REGB, nlog=bm))), "not reproducible"
 
 
+@pytest.mark.parametrize("K,N,M", [(4096, 11008, 16384), (11008, 4096, 4096), (4096, 4096, 17), (4096, 12288, 130), (1024, 200, 300),
+                                   (512, 64, 70), (3584, 8192, 257), (8192, 1280, 64)])
+@pytest.mark.parametrize("bm", [1, 2])
+def test_gemv_layout_prefill_kernel_vs_oracle(ops, oracle, K, N, M, bm):
+    """csrc/gemm_regb.hip in its N-MAJOR form (round 4: AWQ_GEMV_KERNEL_PREFILL, what WQLinear_GEMV runs from 17 rows) on the
+    GEMV layout's own buffers: config 3's shape in both orientations, ragged M / N (partial row and column tiles, N % 256 != 0,
+    N % 8 != 0 at N = 200 ... N % 4 == 0), the 70B shard shapes; sampled rows against the CPU oracle, every output against the
+    fp32 product of the bit-exact dequantised weights (awq_dequantize_weights_gemv); AUTO takes this kernel from 17 rows; one-hot
+    rows select rows of W; bitwise reproducible."""
+    from test_gpu_parity import gemv_case
+
+    qw, qz, sc, _ = gemv_case(K, N, 128, 1, seed=K + 5 * N + M)
+    gen = torch.Generator().manual_seed(K + M + bm)
+    x = torch.randn((M, K), generator=gen).half()
+    dq, ds, dz, dx = qw.cuda(), sc.cuda(), qz.cuda(), x.cuda()
+    fl = ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL, nlog=bm)
+    y = ops.gemv_forward(dx, dq, ds, dz, 128, flags=fl)
+    assert ops.last_kernel() == "gemm_regb_nk" and y.shape == (M, N)
+    ya = ops.gemv_forward(dx, dq, ds, dz, 128)
+    assert ops.last_kernel() == "gemm_regb_nk"          # AUTO: one call, this kernel
+    if bm == 1:
+        assert torch.equal(y, ya)
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), 128)     # [K, N] fp16, the reference's rounding
+    rows = torch.randperm(M, generator=gen)[:min(M, 96)].sort().values
+    rows[0], rows[-1] = 0, M - 1
+    y32, _ = oracle.matmul(x[rows].numpy(), W)
+    assert_product_close(y[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"gemv-layout prefill bm{bm} {K}x{N} M{M}")
+    Wt = ops.dequantize_weights_gemv(dq, ds, dz, 128)
+    assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
+    Wf = Wt.float().t().contiguous()
+    for m0 in range(0, M, 2048):
+        ref = dx[m0:m0 + 2048].float() @ Wf
+        err = (y[m0:m0 + 2048].float() - ref).abs()
+        tol = 2e-3 * ref.abs() + 2e-3 * ref.abs().mean()
+        assert bool((err <= tol).all()), (K, N, bm, m0, float(err.max()))
+    assert torch.equal(y, ops.gemv_forward(dx, dq, ds, dz, 128, flags=fl)), "not reproducible"
+    rowsel = min(M, 256)
+    e = torch.zeros((rowsel, K), dtype=torch.float16, device="cuda")
+    ks = (torch.arange(rowsel, device="cuda") * 61 + 17) % K
+    e[torch.arange(rowsel, device="cuda"), ks] = 1.0
+    if rowsel >= 17:
+        assert torch.equal(ops.gemv_forward(e, dq, ds, dz, 128, flags=fl), Wt.t()[ks]), "one-hot rows must select rows of W"
+
+
+def test_gemv_layout_prefill_kernel_group_sizes_and_refusals(ops, oracle):
+    """group sizes 64 and K (one group), and what the kernel refuses (group_size 32, K % 64): the wrapper then runs the 16-row
+    decode kernels in chunks, or the module its dequantise + GEMM route -- every valid tensor still has a forward."""
+    from autoawq_amd import _lib
+    from test_gpu_parity import gemv_case
+
+    for K, N, g, M in [(1024, 256, 64, 40), (2048, 512, 2048, 33), (1024, 72, 64, 20)]:
+        qw, qz, sc, x = gemv_case(K, N, g, M, seed=K + N + g)
+        y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g)
+        assert ops.last_kernel() == "gemm_regb_nk", (K, N, g)
+        W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+        y32, _ = oracle.matmul(x.numpy(), W)
+        assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"prefill g{g} {K}x{N} M{M}")
+    qw, qz, sc, x = gemv_case(512, 40, 32, 33, seed=9)
+    with pytest.raises(_lib.AwqHipError) as ei:
+        ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), 32, flags=ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL))
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
+    y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), 32)     # AUTO: falls through to the 16-row chunks
+    assert ops.last_kernel() == "gemv_nk"
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), 32)
+    y32, _ = oracle.matmul(x.numpy(), W)
+    assert_product_close(y.cpu().numpy().astype(np.float64), y32, "g32 falls through to the tile kernel",
+                         wsigma=oracle.weight_rounding_sigma(x.numpy(), W))
+
+
 # ------------------------------------------------------------------ the batched-decode configurations bench.py times
 
 @pytest.mark.parametrize("K,N", [(4096, 11008), (4096, 22016), (4096, 28672)])

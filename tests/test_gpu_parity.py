@@ -488,8 +488,9 @@ GEMV_KERNEL_TILE16, GEMV_KERNEL_ROWS = 1, 2  # AWQ_GEMV_KERNEL_* of include/awq_
 
 
 def gemv_rows_takes(M, K, g):
-    """AUTO dispatch of awq_gemv_forward (capi.hip): the row-streaming kernel at batch 1, and at batch 2 while K <= 6144"""
-    return g % 128 == 0 and K % g == 0 and K >= 128 and (M == 1 or (M == 2 and K <= 6144))
+    """AUTO dispatch of awq_gemv_forward (capi.hip awq_gemv_auto_kernel): the row-streaming kernel at batches 1 and 2, and at
+    batches 3 .. 4 while K <= 6144 (round 4; profiles/r03_gemv_rows_sweep.txt)"""
+    return g % 128 == 0 and K % g == 0 and K >= 128 and (M <= 2 or (M <= 4 and K <= 6144))
 
 
 @pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (11008, 4096, 128), (4096, 11008, 128), (1024, 72, 64),

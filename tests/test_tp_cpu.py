@@ -237,6 +237,31 @@ def test_oneshot_setup_failure_on_one_rank_is_seen_by_every_rank_world2_gloo():
         assert summed == [3.0] * 8
 
 
+def test_bench_two_rank_plumbing_dry_run():
+    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --layers 2 --dry-run`: the N > 1 code of
+    bench.py that is not a kernel -- rendezvous, per-rank TP shard shapes, the collective's rank-consistent fallback, the
+    barrier / max-over-ranks timing, the JSON contract -- runs here with two gloo processes."""
+    import json
+    import subprocess
+
+    port = 35500 + (os.getpid() % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for model, hidden, qkv_n in (("7b", 4096, 6144), ("70b", 8192, 5120)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "3",
+                            "--warmup", "1", "--dry-run", "--model", model], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+        assert len(line) == 1, r.stdout[-800:]
+        d = json.loads(line[0])
+        c = d["config"]
+        assert d["dry_run"] and d["value"] is None and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
+        assert c["parallelism"] == "tp2" and c["collectives_per_step"] == 4 and c["collectives_summed_correctly"]
+        assert c["collective"].startswith("RCCL all_reduce via torch.distributed")
+        assert c["shard_shapes_rank0"][0] == ["qkv", hidden, qkv_n] and c["shard_shapes_rank0"][1][2] == hidden
+        port += 7
+
+
 # ------------------------------------------------------------------ the modules' own collective path
 
 def _oracle_forward_gemm(self, x):

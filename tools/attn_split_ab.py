@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Decode attention: how many sequence splits?  Builds csrc/decoder.hip with other (blocks in flight, minimum rows per block)
-targets into tools/bin/ and times the whole 7B-shape decoder (tools/bench_decode_model.py, GEMV layout) with each library.
+"""Decode attention: how many sequence splits?  Builds csrc/decoder.hip with other (blocks in flight, rows per split beyond the
+single-split length of 256) targets into tools/bin/ and times the whole 7B-shape decoder (tools/bench_decode_model.py, GEMV layout) with each library.
     python tools/attn_split_ab.py --build-only   (here)      gpurun -- python tools/attn_split_ab.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "autoawq_amd", "csrc")
-VARIANTS = [(1024, 64), (512, 128), (256, 256), (256, 64)]
+VARIANTS = [(1024, 256), (1024, 128), (1024, 64), (2048, 64), (512, 128)]  # VARIANTS[0] = csrc/decoder.hip as built
 
 
 def so(v):
@@ -32,7 +32,7 @@ def child(i):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_decode_model
     r = bench_decode_model.run(contexts=(64, 512, 2048), steps=48, verbose=False, check=False, layout="gemv")
-    print(f"blocks {VARIANTS[i][0]:5d} min rows {VARIANTS[i][1]:4d}: " + "  ".join(f"ctx {c}: {1000.0 / ms:6.1f} tok/s" for c, ms in r.items()), flush=True)
+    print(f"blocks <= {VARIANTS[i][0]:5d}  rows per split {VARIANTS[i][1]:4d}: " + "  ".join(f"ctx {c}: {1000.0 / ms:6.1f} tok/s" for c, ms in r.items()), flush=True)
 
 
 if __name__ == "__main__":
