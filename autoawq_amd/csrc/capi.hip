@@ -352,6 +352,20 @@ int awq_grouped_gemm_forward_ex(const uint16_t* x, const int32_t* qweight, const
                                    (int)x_div, (int)max_blocks, K * NW, G * NW, G * N);
 }
 
+int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                             uint16_t* y, const int32_t* seg_offsets, int64_t P, int64_t num_experts, int64_t K, int64_t N,
+                             int64_t group_size, uint32_t flags, void* stream) {
+    int rc = check_gemm_layout(K, N, group_size);
+    if (rc) return rc;
+    if (P < 0 || P > INT32_MAX || num_experts < 1 || num_experts > 4096) return AWQ_ERR_BAD_SHAPE;
+    if (P == 0 || N == 0) return AWQ_OK;
+    if (!x || !qweight || !scales || !qzeros || !y || !seg_offsets) return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales) || !aligned16(qzeros) || !aligned16(y)) return AWQ_ERR_BAD_ALIGNMENT;
+    g_last_kernel = "gemm_regb_grouped";
+    return awq_launch_gemm_regb_grouped(x, qweight, scales, qzeros, y, seg_offsets, (int)P, (int)num_experts, (int)K, (int)N,
+                                        (int)group_size, AWQ_GEMM_FLAG_NLOG(flags) == 2 ? 256 : 0, static_cast<hipStream_t>(stream));
+}
+
 /* ---- GEMV layout ------------------------------------------------------------------------- */
 
 // Which kernel awq_gemv_forward's AUTO dispatch takes (host only, no launch): the row-streaming kernel at batches 1 and 2, and at

@@ -382,8 +382,10 @@ int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* 
     // the split must not depend on a length that only the device knows: size it for max_len
     const int len_for_split = len_dev ? max_len : seq_len + (fused ? 1 : 0);
     if (len_for_split < 1 || len_for_split > Tmax) return AWQ_ERR_BAD_SHAPE;
-    // Splits per KV head: about 256 rows each (AWQ_ATTN_ROWS), at most ~1024 blocks (AWQ_ATTN_BLOCKS) and 64 splits (the
-    // combine kernel's one-lane-per-split step).  ONE split up to 256 rows: no partials, no combine launch at all -- what a
+    // Splits per KV head: about 128 rows each (AWQ_ATTN_ROWS; A/B on the whole-model decode, profiles/r04_attention_split_ab.txt:
+    // 128 rows 769 / 712 / 663 tok/s at 64 / 512 / 2048 tokens of context, 256 rows 772 / 657 / 564, 64 rows 768 / 694 / 589),
+    // at most ~1024 blocks (AWQ_ATTN_BLOCKS) and 64 splits (the combine kernel's one-lane-per-split step).  ONE split up to
+    // AWQ_ATTN_SINGLE = 256 rows: no partials, no combine launch at all -- what a
     // short context pays for a 32-way split sized for the whole cache was 9.5 + 5 us per layer (profiles/r03_whole_model_gemv_
     // kernel_stats.txt); callers that know the context on the host (modules/fused/decode.py: one hipGraph per length bucket)
     // pass the bucket's bound as max_len.  (Both constants overridable in experiment builds: tools/attn_split_ab.py.)
@@ -391,7 +393,7 @@ int awq_launch_decode_attention(const uint16_t* q, uint16_t* k_cache, uint16_t* 
 #define AWQ_ATTN_BLOCKS 1024
 #endif
 #ifndef AWQ_ATTN_ROWS
-#define AWQ_ATTN_ROWS 256
+#define AWQ_ATTN_ROWS 128
 #endif
 #ifndef AWQ_ATTN_SINGLE
 #define AWQ_ATTN_SINGLE 256

@@ -66,6 +66,10 @@ struct RegbParams {
     int mp, patches;  // patches of pm x pn tiles: mp along M, `patches` in all
     int pm, pn;       // tile patch one XCD runs at a time (pm * pn = 32)
     int KW, ZW, SW;   // NK form: words per qweight row, zero words per row, scale halfs per row
+    // GROUPED form (MoE prefill): rows [seg[e], seg[e + 1]) of x / y belong to expert e, whose tensors sit e strides further
+    const int* seg;   // [E + 1] row offsets on the DEVICE (nothing about the routing is read back to the host)
+    int E;
+    long long w_stride, z_stride, s_stride;  // bytes between two experts' qweight / qzeros / scales
 };
 
 constexpr int BK = 64, NBUF = 4, BN = 256;
@@ -73,7 +77,9 @@ constexpr int PM = 8, PN = 4;  // tile patch per XCD round
 
 // DBG (tools/regb_experiments.py, -DAWQ_REGB_EXPERIMENTS builds only; results are WRONG, timing only): 1 = weights fetched
 // once, 2 = activations fetched once, 4 = no barrier, 8 = no decode arithmetic, 16 = every output row stored into rows 0..127 (stores issued, nothing reaches HBM)
-template <int WGM, int DBG = 0, bool NK = false>  // waves along M: BM = 128 * WGM; NK: the GEMV layout's buffers (header)
+// GROUPED: the M tiles are dealt over the experts of a sorted token list (device-side row offsets `seg`): virtual tile `mt` walks
+// expert 0's ceil(rows / BM) tiles, then expert 1's, ...; a block past the last expert's tiles exits.
+template <int WGM, int DBG = 0, bool NK = false, bool GROUPED = false>  // waves along M: BM = 128 * WGM; NK: the GEMV layout's buffers (header)
 __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams p) {
     constexpr int BM = 128 * WGM;
     constexpr int A_BUF = BM * BK * 2;            // bytes of one activation K step
@@ -97,7 +103,24 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         nt = (patch / p.mp) * p.pn + local / p.pm;
         if (mt >= p.tiles_m || nt >= p.tiles_n) return;
     }
-    const int m0 = mt * BM, n0 = nt * BN;
+    int m0 = mt * BM, m_hi = p.M;
+    const int n0 = nt * BN;
+    if constexpr (GROUPED) {
+        int e = 0, vt = mt, lo = 0, hi = 0;
+        for (; e < p.E; ++e) {  // (scalar loads: E + 1 words, uniform)
+            lo = p.seg[e];
+            hi = p.seg[e + 1];
+            const int te = (hi - lo + BM - 1) / BM;
+            if (vt < te) break;
+            vt -= te;
+        }
+        if (e >= p.E) return;
+        m0 = lo + vt * BM;
+        m_hi = hi;
+        p.qweight = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.qweight) + (long long)e * p.w_stride);
+        p.qzeros = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.qzeros) + (long long)e * p.z_stride);
+        p.scales = reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(p.scales) + (long long)e * p.s_stride);
+    }
     const int NW = p.N >> 3;
     const int T = p.K / BK;
 
@@ -228,7 +251,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         const int q = PIECES * wave + u;
         const int row = 8 * q + (lane >> 3), slot = lane & 7;
         const int kc = slot ^ ((row >> 1) & 7);
-        const int grow = min(m0 + row, p.M - 1);
+        const int grow = min(m0 + row, m_hi - 1);
         a_voff[u] = (uint32_t)(((int64_t)grow * p.K + 8 * kc) * 2);
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic segment
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = m0 + wm * 128 + 16 * i + 4 * kb + e;
-            if (row < p.M) {
+            if (row < m_hi) {
                 half4_t o;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[c] = (half_t)(acc[i][c][e] + b4[c]);
@@ -439,6 +462,7 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
     p.y = reinterpret_cast<half_t*>(a.y);
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
     p.KW = p.ZW = p.SW = 0;
+    p.seg = nullptr; p.E = 0; p.w_stride = p.z_stride = p.s_stride = 0;
     p.tiles_m = (a.M + bm - 1) / bm;
     p.tiles_n = (a.N + BN - 1) / BN;
     p.pm = PM; p.pn = PN;
@@ -502,6 +526,7 @@ int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uin
     p.y = reinterpret_cast<half_t*>(y);
     p.M = M; p.K = K; p.N = N; p.g = g;
     p.KW = K / 8; p.ZW = ZW; p.SW = 8 * ZW;
+    p.seg = nullptr; p.E = 0; p.w_stride = p.z_stride = p.s_stride = 0;
     p.tiles_m = (M + bm - 1) / bm;
     p.tiles_n = (N + BN - 1) / BN;
     p.pm = PM; p.pn = PN;
@@ -515,6 +540,43 @@ int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uin
         hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 0, true>), dim3(grid), dim3(512), lds, st, p);
     } else {
         hipLaunchKernelGGL((awq_gemm_regb_kernel<1, 0, true>), dim3(grid), dim3(256), lds, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+// ---- the GROUPED form (MoE prefill, GEMM-layout expert stacks): x / y rows sorted by expert, seg [E + 1] on the device.
+// max_tiles: M tiles the launch provides = ceil(P / bm) + E covers every split of P rows over E experts.
+int awq_launch_gemm_regb_grouped(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                                 uint16_t* y, const int32_t* seg, int P, int E, int K, int N, int g, int bm, hipStream_t st) {
+    if (!awq_gemm_regb_supports(P, K, N, g) || E < 1 || !seg) return AWQ_ERR_UNSUPPORTED;
+    if (bm == 0) bm = 128;
+    if (bm != 128 && bm != 256) return AWQ_ERR_UNSUPPORTED;
+    RegbParams p;
+    p.qweight = reinterpret_cast<const uint32_t*>(qweight);
+    p.qzeros = reinterpret_cast<const uint32_t*>(qzeros);
+    p.scales = reinterpret_cast<const half_t*>(scales);
+    p.x = reinterpret_cast<const half_t*>(x);
+    p.bias = nullptr;
+    p.y = reinterpret_cast<half_t*>(y);
+    p.M = P; p.K = K; p.N = N; p.g = g;
+    p.KW = p.ZW = p.SW = 0;
+    p.seg = seg; p.E = E;
+    p.w_stride = (long long)K * (N / 8) * 4;
+    p.z_stride = (long long)(K / g) * (N / 8) * 4;
+    p.s_stride = (long long)(K / g) * N * 2;
+    p.tiles_m = (P + bm - 1) / bm + E;
+    p.tiles_n = (N + BN - 1) / BN;
+    p.pm = PM; p.pn = PN;
+    p.mp = (p.tiles_m + p.pm - 1) / p.pm;
+    p.patches = p.mp * ((p.tiles_n + p.pn - 1) / p.pn);
+    const int grid = ((p.patches + 7) / 8) * 8 * (p.pm * p.pn);
+    const size_t lds = (size_t)NBUF * bm * BK * 2;
+    if (bm == 256) {
+        static std::atomic<unsigned long long> opted{0};
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 0, false, true>), opted)) return AWQ_ERR_LAUNCH;
+        hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 0, false, true>), dim3(grid), dim3(512), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((awq_gemm_regb_kernel<1, 0, false, true>), dim3(grid), dim3(256), lds, st, p);
     }
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

@@ -47,39 +47,51 @@ PREFILL_MIN_PAIRS = 384
 
 
 def _apply_moe_prefill(w1, w2, x, gating_output, topk, renormalize):
-    """Prefill-sized token counts: the pairs are sorted by expert, every expert that was hit runs ITS rows through the fused
-    MFMA GEMM kernels (awq_gemm_forward AUTO: gemm_skinny / gemm_tiled / gemm_regb by row count) for w1|w3 and w2 instead of
-    ceil(rows / 16) passes of the decode kernel, then the routing weight is applied per pair and the top-k slots are summed
-    exactly like the decode path (`[T, topk, H]` fp16, sum over dim 1).  Reads the per-expert row counts back to the host
-    (one synchronisation; prefill is not graph-captured)."""
+    """Prefill-sized token counts (round 4): the pairs are sorted by expert ON THE DEVICE, and each projection is ONE launch of
+    the register-decoded MFMA GEMM whose row tiles are dealt over the experts from the device-side row offsets
+    (awq_grouped_gemm_prefill) -- w1|w3 over all experts, silu * mul, w2 over all experts -- then the routing weight is
+    applied per pair and the top-k slots are summed exactly like the decode path (`[T, topk, H]` fp16, sum over dim 1).
+    Nothing is read back to the host (round 3 read the per-expert row counts and launched one GEMM per expert and
+    projection: 16 launches of ~112 blocks each for Mixtral, and no hipGraph capture)."""
     T, H = x.shape
     E = w1.qweight.shape[0]
     topk_weights, topk_ids = fused_topk(gating_output, topk, renormalize)
     flat_e = topk_ids.reshape(-1).long()
     order = torch.argsort(flat_e, stable=True)
-    counts = torch.bincount(flat_e, minlength=E).cpu().tolist()
+    counts = torch.zeros(E, dtype=torch.int32, device=x.device).scatter_add_(0, flat_e, torch.ones_like(flat_e, dtype=torch.int32))
+    seg = torch.zeros(E + 1, dtype=torch.int32, device=x.device)
+    seg[1:] = torch.cumsum(counts, 0)
     xs = x.index_select(0, order // topk)                      # [T * topk, H] rows grouped by expert
-    ys = torch.empty_like(xs)
-    off = 0
-    for e, n in enumerate(counts):
-        if n == 0:
-            continue
-        gate_up = ops.gemm_forward(xs[off:off + n], w1.qweight[e], w1.scales[e], w1.qzeros[e])
-        if n <= 16:
-            ys[off:off + n] = ops.gemm_forward(gate_up, w2.qweight[e], w2.scales[e], w2.qzeros[e], flags=ops.X_GATED_SILU)
-        else:
-            ys[off:off + n] = ops.gemm_forward(ops.silu_and_mul(gate_up), w2.qweight[e], w2.scales[e], w2.qzeros[e])
-        off += n
+    try:
+        gate_up = ops.grouped_gemm_prefill(xs, w1.qweight, w1.scales, w1.qzeros, seg)
+        ys = ops.grouped_gemm_prefill(ops.silu_and_mul(gate_up), w2.qweight, w2.scales, w2.qzeros, seg)
+    except ops._lib.AwqHipError as e:  # shapes the register-decoded kernel does not take (K % 64, group sizes below 64)
+        if getattr(e, "code", 0) != -3 or torch.cuda.is_current_stream_capturing():
+            raise
+        ys = _per_expert_gemms(w1, w2, xs, counts)
     w_sorted = topk_weights.reshape(-1).index_select(0, order).to(torch.float32)
     out = torch.empty((T * topk, H), dtype=torch.float16, device=x.device)
     out.index_copy_(0, order, (ys.float() * w_sorted[:, None]).half())
     return out.view(T, topk, H).sum(dim=1)
 
 
+def _per_expert_gemms(w1, w2, xs, counts):
+    """Fallback of the prefill path for odd shapes: one awq_gemm_forward per expert and projection (reads the counts back)."""
+    ys = torch.empty((xs.shape[0], w2.qweight.shape[2] * 8), dtype=torch.float16, device=xs.device)
+    off = 0
+    for e, n in enumerate(counts.cpu().tolist()):
+        if n == 0:
+            continue
+        gate_up = ops.gemm_forward(xs[off:off + n], w1.qweight[e], w1.scales[e], w1.qzeros[e])
+        ys[off:off + n] = ops.gemm_forward(ops.silu_and_mul(gate_up), w2.qweight[e], w2.scales[e], w2.qzeros[e])
+        off += n
+    return ys
+
+
 def apply_moe_weights(w1: Dict[str, torch.Tensor], w2: Dict[str, torch.Tensor], x: torch.Tensor,
                       gating_output: torch.Tensor, topk: int, renormalize: bool) -> torch.Tensor:
     num_experts = w1.qweight.shape[0]
-    if x.shape[0] * topk >= PREFILL_MIN_PAIRS and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if x.shape[0] * topk >= PREFILL_MIN_PAIRS and x.is_cuda:
         in_dtype = x.dtype
         out = _apply_moe_prefill(w1, w2, x.half() if in_dtype != torch.float16 else x, gating_output, topk, renormalize)
         return out.to(in_dtype) if in_dtype != torch.float16 else out

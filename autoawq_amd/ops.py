@@ -210,6 +210,27 @@ def gemm_forward(x2d, qweight, scales, qzeros, bias=None, flags=0):
     return y
 
 
+def grouped_gemm_prefill(x_sorted, qweight, scales, qzeros, seg_offsets, flags=0):
+    """MoE prefill (awq_grouped_gemm_prefill): x_sorted [P, K] fp16 = the (token, expert) pairs' rows sorted by expert,
+    seg_offsets [E + 1] int32 on the device, qweight [E, K, N/8] / scales [E, K/g, N] / qzeros [E, K/g, N/8] the stacked
+    GEMM-layout experts -> y [P, N].  No routing data is read back: capturable."""
+    _require_gpu(x_sorted, qweight, scales, qzeros, seg_offsets)
+    if x_sorted.dtype != torch.float16 or seg_offsets.dtype != torch.int32:
+        raise _lib.AwqHipError("grouped_gemm_prefill expects fp16 activations and int32 offsets")
+    x_sorted, qweight, scales, qzeros = x_sorted.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    P, K = x_sorted.shape
+    E, N, G = qweight.shape[0], qweight.shape[2] * 8, qzeros.shape[1]
+    if qweight.shape[1] != K or scales.shape != (E, G, N) or qzeros.shape != (E, G, N // 8) or seg_offsets.numel() != E + 1 or K % G:
+        raise _lib.AwqHipError(f"grouped_gemm_prefill: shape mismatch x{tuple(x_sorted.shape)} qweight{tuple(qweight.shape)} "
+                               f"scales{tuple(scales.shape)} qzeros{tuple(qzeros.shape)} seg{tuple(seg_offsets.shape)}")
+    y = torch.empty((P, N), dtype=torch.float16, device=x_sorted.device)
+    with torch.cuda.device(x_sorted.device):
+        rc = _lib.lib().awq_grouped_gemm_prefill(_ptr(x_sorted), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y),
+                                                 _ptr(seg_offsets.contiguous()), P, E, K, N, K // G, flags, _stream())
+    _lib.check(rc, "awq_grouped_gemm_prefill")
+    return y
+
+
 def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     """GEMV layout (qweight [N, K/8], qzeros [N, ZW], scales [N, 8*ZW]): y [M, N] fp16 = x2d @ W^T
     (awq_gemv_forward).  M is processed in chunks that fit the kernel (<= 16 rows and the LDS)."""

@@ -311,7 +311,7 @@ def leg_moe_prefill(dev):
     import bench_moe
 
     r = bench_moe.run_prefill(dev=dev, verbose=False)
-    r["what"] = "Mixtral-8x7B-shape fused MoE MLP at 512 tokens (1024 pairs): one fused MFMA GEMM per expert and projection (modules/fused/moe.py)"
+    r["what"] = "Mixtral-8x7B-shape fused MoE MLP at 512 tokens (1024 pairs): ONE grouped launch of the register-decoded MFMA GEMM per projection, row tiles dealt over the experts from device-side offsets (awq_grouped_gemm_prefill, modules/fused/moe.py)"
     return r
 
 

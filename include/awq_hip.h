@@ -160,6 +160,17 @@ AWQ_EXPORT int awq_grouped_gemm_forward_ex(const uint16_t* x, const int32_t* qwe
                                         int64_t block_rows, int64_t max_blocks, int64_t num_experts, int64_t K, int64_t N,
                                         int64_t group_size, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* MoE PREFILL (round 4; awq/modules/fused/moe.py:45-91 at prefill-sized token counts): x [P, K] fp16 holds the (token, expert)
+ * pairs' activation rows SORTED BY EXPERT, seg_offsets [E + 1] int32 ON THE DEVICE the row range of each expert
+ * (seg[e] .. seg[e + 1]); qweight / scales / qzeros are the stacked GEMM-layout expert tensors [E, K, N/8] / [E, K/g, N] /
+ * [E, K/g, N/8].  y [P, N] fp16 row r = x row r through ITS expert's matrix.  One launch of the register-decoded MFMA GEMM
+ * (csrc/gemm_regb.hip) whose M tiles are dealt over the experts from the device-side offsets: nothing about the routing is
+ * read back to the host, so the whole MoE block is hipGraph-capturable at every token count.  K % 64 == 0,
+ * group_size % 64 == 0, N % 8 == 0.  flags: AWQ_GEMM_FLAG_NLOG = 2 -> 256-row tiles. */
+AWQ_EXPORT int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                                        uint16_t* y, const int32_t* seg_offsets, int64_t P, int64_t num_experts, int64_t K,
+                                        int64_t N, int64_t group_size, uint32_t flags, void* stream);
+
 /* ---- GEMV layout: qweight [N, K/8] i32 (ordinal nibbles), qzeros [N, ZW] i32, scales [N, 8*ZW] f16
  *      (awq/modules/linear/gemv.py:45-69; ZW = calculate_zeros_width, gemv.py:12-24) -------------- */
 

@@ -862,9 +862,11 @@ def test_moe_activation_folded_into_w2_is_bit_identical(ops, T):
 
 
 def test_moe_prefill_path_vs_oracle_and_vs_the_block_path(ops, oracle):
-    """T = 512 tokens, top-2 of 8 experts (1024 pairs, ~128 rows per expert): apply_moe_weights sorts the pairs by expert and
-    runs one fused GEMM per expert and projection (modules/fused/moe.py::_apply_moe_prefill).  Against the CPU oracle on a
-    sample of tokens and against the 16-row-block grouped kernel on all of them."""
+    """T = 512 tokens, top-2 of 8 experts (1024 pairs, ~128 rows per expert): apply_moe_weights sorts the pairs by expert on the
+    device and runs ONE grouped launch of the register-decoded MFMA GEMM per projection (awq_grouped_gemm_prefill,
+    modules/fused/moe.py::_apply_moe_prefill; round 3: one GEMM per expert and a host read-back).  Against the CPU oracle on a
+    sample of tokens, against the 16-row-block grouped kernel on all of them, against one awq_gemm_forward per expert for the
+    kernel alone (ragged and EMPTY experts included), and captured into a hipGraph (nothing is read back)."""
     from autoawq_amd.modules.fused import moe
 
     T, E, H, I, g, topk = 512, 8, 512, 768, 128, 2
@@ -881,6 +883,33 @@ def test_moe_prefill_path_vs_oracle_and_vs_the_block_path(ops, oracle):
     logits = torch.randn((T, E), generator=gen)
     assert T * topk >= moe.PREFILL_MIN_PAIRS
     got = moe.apply_moe_weights(ws, w2, x.cuda(), logits.cuda(), topk, True)
+    assert ops.last_kernel() != "none"
+    # the grouped kernel alone: rows sorted by expert with a ragged split (one expert empty, one with a single row, one with
+    # 257 rows = three 128-row tiles) == one awq_gemm_forward per expert on its rows, bit for bit
+    counts = torch.tensor([0, 1, 257, 100, 129, 128, 17, 300], dtype=torch.int32)
+    seg = torch.zeros(E + 1, dtype=torch.int32)
+    seg[1:] = torch.cumsum(counts, 0)
+    P = int(seg[-1])
+    xs = torch.randn((P, H), generator=gen).half().cuda()
+    for bm in (1, 2):
+        yg = ops.grouped_gemm_prefill(xs, ws.qweight, ws.scales, ws.qzeros, seg.cuda(), flags=ops.gemm_flags(nlog=bm))
+        assert ops.last_kernel() == "gemm_regb_grouped" and yg.shape == (P, 2 * I)
+        for e in range(E):
+            lo, hi = int(seg[e]), int(seg[e + 1])
+            if hi > lo:
+                ref = ops.gemm_forward(xs[lo:hi], ws.qweight[e], ws.scales[e], ws.qzeros[e], flags=ops.gemm_flags(ops.KERNEL_REGB, nlog=bm))
+                assert torch.equal(yg[lo:hi], ref), (bm, e)
+    s_ = torch.cuda.Stream()
+    with torch.cuda.stream(s_):
+        xc, lc = x.cuda(), logits.cuda()
+        moe.apply_moe_weights(ws, w2, xc, lc, topk, True)
+        s_.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s_):
+            captured = moe.apply_moe_weights(ws, w2, xc, lc, topk, True)
+        gr.replay()
+        s_.synchronize()
+    assert torch.equal(captured, got), "the captured MoE prefill block must replay to the same result"
     saved = moe.PREFILL_MIN_PAIRS
     try:
         moe.PREFILL_MIN_PAIRS = 1 << 30

@@ -86,9 +86,10 @@ def run(dev=None, verbose=True, layers=2, reps=20):
 
 
 def run_prefill(T=512, dev=None, verbose=True, reps=5):
-    """The same block at a prefill-sized token count (T x top-2 = 1024 pairs, ~128 rows per expert): the per-expert fused-GEMM
-    path of apply_moe_weights vs the 16-row-block grouped kernel it replaces there; MFMA TFLOP/s (2 * pairs * (K N) flops of
-    both projections)."""
+    """The same block at a prefill-sized token count (T x top-2 = 1024 pairs, ~128 rows per expert): the grouped prefill path of
+    apply_moe_weights (round 4: ONE launch of the register-decoded MFMA GEMM per projection, tiles dealt over the experts from
+    device-side offsets) vs round 3's one-GEMM-per-expert loop (host read-back) and the 16-row-block grouped decode kernel;
+    MFMA TFLOP/s (2 * pairs * (K N) flops of both projections)."""
     from autoawq_amd.modules.fused import moe
 
     dev = dev or torch.device("cuda")
@@ -126,12 +127,24 @@ def run_prefill(T=512, dev=None, verbose=True, reps=5):
     finally:
         moe.PREFILL_MIN_PAIRS = saved
     rel = float((yp.float() - yb.float()).abs().max() / yb.float().abs().max())
+
+    def per_expert():  # round 3's path, for the A/B
+        tw, ti = moe.fused_topk(logits, topk, True)
+        flat = ti.reshape(-1).long()
+        order = torch.argsort(flat, stable=True)
+        counts = torch.bincount(flat, minlength=E).int()
+        ys = moe._per_expert_gemms(w1, w2, x.index_select(0, order // topk), counts)
+        out = torch.empty((T * topk, H), dtype=torch.float16, device=dev)
+        out.index_copy_(0, order, (ys.float() * tw.reshape(-1).index_select(0, order).float()[:, None]).half())
+        return out.view(T, topk, H).sum(dim=1)
+
+    us_e, _ = timeit(per_expert)
     if verbose:
-        print(f"Mixtral-8x7B-shape MoE MLP, T={T}, top-{topk}: per-expert fused GEMMs {us_p:.0f} us ({fl / us_p / 1e6:.0f} TF), "
-              f"16-row-block grouped kernel {us_b:.0f} us ({fl / us_b / 1e6:.0f} TF); max rel diff {rel:.1e}")
-    return {"tokens": T, "per_expert_fused_gemm_us": us_p, "block16_grouped_us": us_b, "flops": fl,
+        print(f"Mixtral-8x7B-shape MoE MLP, T={T}, top-{topk}: grouped prefill GEMMs {us_p:.0f} us ({fl / us_p / 1e6:.0f} TF), "
+              f"one GEMM per expert (r03) {us_e:.0f} us, 16-row-block grouped kernel {us_b:.0f} us ({fl / us_b / 1e6:.0f} TF); max rel diff {rel:.1e}")
+    return {"tokens": T, "grouped_prefill_us": us_p, "per_expert_fused_gemm_us_r03": us_e, "block16_grouped_us": us_b, "flops": fl,
             "roofline": {"bound": "mfma", "achieved": fl / us_p / 1e6, "peak": 2500.0, "unit": "TFLOP/s", "frac": fl / us_p / 1e6 / 2500.0},
-            "paths_max_rel_diff": rel, "note": "eager timing (the per-expert path reads the row counts back: one host sync per block)"}
+            "paths_max_rel_diff": rel, "note": "eager timing; the grouped path reads nothing back (hipGraph-capturable), round 3's per-expert path synchronises once per block"}
 
 
 def run_ep(world, dev=None, layers=2, reps=20, verbose=True):
