@@ -375,8 +375,7 @@ int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweight, const ui
 int awq_gemv_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0 || K % group_size || K % 8 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return -1;
     const int m = (int)M, k = (int)K, n = (int)N, g = (int)group_size;
-    if (M > 16)  // prefill-sized: the register-decoded GEMM on this layout's own buffers (any zeros width >= the groups)
-        return awq_gemm_regb_nk_supports(m, k, n, g, (k / g + 7) / 8) ? (int)AWQ_GEMV_KERNEL_PREFILL : -1;
+    if (M > 16) return -1;  // one call serves 16 rows (the host wrapper chunks); AWQ_GEMV_KERNEL_PREFILL is explicit only (header)
     // round 4: batch 2 at every K and batches 3 .. 4 while K <= 6144 also run the row-streaming kernel -- it is ahead of the
     // 16-row tile kernel there on all four 7B shapes (profiles/r03_gemv_rows_sweep.txt: M = 2 4.65 / 7.05 / 10.77 / 8.57 us vs
     // 6.18 / 9.96 / 16.65 / 10.73; M = 4 at K = 4096 5.79 / 9.79 / 14.39 vs 6.59 / 10.40 / 18.29; at K = 11008 12.25 vs 11.79)
@@ -395,7 +394,7 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     if (!x || !qweight || !scales || !qzeros || !y) return AWQ_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales)) return AWQ_ERR_BAD_ALIGNMENT;
     const uint32_t kern = AWQ_GEMM_FLAG_KERNEL(flags);
-    if (kern == AWQ_GEMV_KERNEL_PREFILL || (kern == AWQ_GEMV_KERNEL_AUTO && M > 16)) {
+    if (kern == AWQ_GEMV_KERNEL_PREFILL) {
         if (!aligned16(y)) return AWQ_ERR_BAD_ALIGNMENT;
         g_last_kernel = "gemm_regb_nk";
         return awq_launch_gemm_regb_nk(x, qweight, scales, qzeros, nullptr, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,

@@ -9,8 +9,9 @@ Drop-in contract kept (reference awq/modules/linear/gemv.py:27-197):
   * forward (:156-186): any leading dims, any float dtype (computed in fp16, cast back), bias added
     AFTER the cast back, in the input dtype (:183-185).
 What differs by design: the arithmetic runs in libawq_hip.so on the module's own buffers at every batch
-size (csrc/gemv_rows.hip, gemv_lds.hip, gemv_nk.hip up to 16 rows per launch; csrc/gemm_regb.hip, N-major
-form, from 17 rows); there is no CPU path -- a non-HIP tensor raises.
+size (csrc/gemv_rows.hip, gemv_lds.hip, gemv_nk.hip up to 16 rows per launch; from 17 rows the bit-exact
+dequantise kernel + a dense fp16 GEMM, or -- opt-in -- csrc/gemm_regb.hip in its N-major form); there is no
+CPU path -- a non-HIP tensor raises.
 """
 import torch
 import torch.nn as nn
@@ -32,7 +33,12 @@ def dequant_matmul_nk(x2d, wt):
     return torch.matmul(x2d, wt.t())
 
 
+PREFILL_MIN_ROWS = 17  # the decode kernels serve 16 rows per launch (the reference switches to its batched kernel at 8: gemv.py:168)
+
+
 class WQLinear_GEMV(nn.Module):
+    PREFILL_IMPL = "two_pass"  # | "fused" (see forward)
+
     def __init__(self, w_bit, group_size, in_features, out_features, bias, dev):
         super().__init__()
         if w_bit not in [4]:
@@ -80,14 +86,28 @@ class WQLinear_GEMV(nn.Module):
         input_dtype = inputs.dtype
         if input_dtype != torch.float16:
             inputs = inputs.half()
-        try:
-            # every batch size on this layout's OWN buffers (round 4): decode kernels up to 16 rows, from 17 rows the
-            # register-decoded MFMA GEMM in its N-major form (csrc/gemm_regb.hip, AWQ_GEMV_KERNEL_PREFILL) -- the second,
-            # GEMM-layout copy of every matrix that rounds 2-3 kept for prefill is gone
-            out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
-        except _lib.AwqHipError as e:  # a shape no kernel of this layout takes (K % 128 with odd group sizes)
-            if e.code != _lib.ERR_UNSUPPORTED:
-                raise
+        # Every batch size on this layout's OWN buffers (round 4: the second, GEMM-layout copy of every matrix that rounds 2-3
+        # kept for prefill is gone).  Up to 16 rows: the decode kernels.  From 17 rows: PREFILL_IMPL --
+        #   "two_pass" (default)  dequantise (hand-written kernel, bit-exact) into a temporary + a dense fp16 GEMM: the reference's
+        #                         own prefill route (gemm.py:48-54); 0.42 of the MFMA peak at M = 16384, ~45 us at M = 32;
+        #   "fused"               the register-decoded MFMA GEMM in its N-major form (AWQ_GEMV_KERNEL_PREFILL): no temporary, but
+        #                         0.29 of the peak at M = 16384 and latency-bound below ~2000 rows (profiles/r04_bench_*.json).
+        out = None
+        rows = inputs.shape[0]
+        if rows >= PREFILL_MIN_ROWS and self.PREFILL_IMPL == "fused":
+            try:
+                out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size,
+                                       flags=ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL))
+            except _lib.AwqHipError as e:  # K % 64, group sizes below 64
+                if e.code != _lib.ERR_UNSUPPORTED:
+                    raise
+        if out is None and rows < PREFILL_MIN_ROWS:
+            try:
+                out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
+            except _lib.AwqHipError as e:  # a shape no decode kernel of this layout takes (K % 128 with odd group sizes)
+                if e.code != _lib.ERR_UNSUPPORTED:
+                    raise
+        if out is None:
             out = dequant_matmul_nk(inputs, ops.dequantize_weights_gemv(self.qweight, self.scales, self.qzeros, self.group_size))
         if input_dtype != torch.float16:
             out = out.to(dtype=input_dtype)

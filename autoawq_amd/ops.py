@@ -247,19 +247,14 @@ def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     if M == 0:
         return y
     L = _lib.lib()
-    kern = flags & 0xF
-    if M > 16 and kern in (0, GEMV_KERNEL_PREFILL):
-        # prefill-sized: ONE call of the register-decoded MFMA GEMM on this layout's own buffers (awq_gemv_forward AUTO /
-        # AWQ_GEMV_KERNEL_PREFILL); shapes it does not take (K % 64, group sizes below 64) fall through to the 16-row chunks
+    if (flags & 0xF) == GEMV_KERNEL_PREFILL:
+        # explicit only: ONE call of the register-decoded MFMA GEMM on this layout's own buffers (any M); AUTO keeps the
+        # 16-row chunks of the decode kernels (include/awq_hip.h: the kernel is latency-bound below ~2000 rows)
         with torch.cuda.device(x2d.device):
             rc = L.awq_gemv_forward(_ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), M, K, N, group_size, ZW, flags,
                                     _stream())
-        if rc != _lib.ERR_UNSUPPORTED:
-            _lib.check(rc, "awq_gemv_forward")
-            return y
-        if kern == GEMV_KERNEL_PREFILL:
-            _lib.check(rc, "awq_gemv_forward")
-        flags &= ~0xF
+        _lib.check(rc, "awq_gemv_forward")
+        return y
     chunk = 16
     while chunk > 1 and L.awq_gemv_lds_bytes(chunk, K, ZW) > 160 * 1024:
         chunk //= 2

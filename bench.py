@@ -212,7 +212,7 @@ def leg_gemm_bs(dev, ops):
     # the same matrix shape in the WQLinear_GEMV format (awq_gemv_forward: row-streaming kernel at M <= 2, 16-row MFMA tiles to 16)
     sets = [rand_packed_nk(K, N, GROUP, dev, gen) for _ in range(nsets)]
     out["gemv_layout_by_batch"] = {}
-    for M in (1, 2, 4, 8, 16, 32, 64):  # (from 17 rows: the N-major form of the register-decoded MFMA GEMM, this layout's own buffers)
+    for M in (1, 2, 4, 8, 16, 32, 64):  # (from 17 rows: 16-row chunks of the decode kernels -- the layout's own buffers, no GEMM-layout copy)
         x = torch.randn((M, K), device=dev, generator=gen).half()
 
         def fn2():
@@ -285,18 +285,23 @@ def leg_gemm_prefill(dev, ops):
     del qw, qz, sc
     torch.cuda.empty_cache()
     nq, nz, ns = rand_packed_nk(K, N, GROUP, dev, gen)
-    us_nk = timeit(lambda: ops.gemv_forward(x, nq, ns, nz, GROUP))
+    pre = ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL)
+    us_nk = timeit(lambda: ops.gemv_forward(x, nq, ns, nz, GROUP, flags=pre))
     nk_kernel = ops.last_kernel()
-    an = ops.gemv_forward(x[:2048], nq, ns, nz, GROUP).float()
+    us_nk2 = timeit(lambda: torch.matmul(x, ops.dequantize_weights_gemv(nq, ns, nz, GROUP).t()))
+    an = ops.gemv_forward(x[:2048], nq, ns, nz, GROUP, flags=pre).float()
     bn = torch.matmul(x[:2048], ops.dequantize_weights_gemv(nq, ns, nz, GROUP).t()).float()
     rel_nk = float((an - bn).abs().max() / bn.abs().max())
     assert rel_nk < 5e-3, f"GEMV-layout prefill kernel disagrees with dequantise + GEMM: {rel_nk}"
-    nk_by_m = {str(m): 2.0 * m * K * N / timeit(lambda: ops.gemv_forward(x[:m], nq, ns, nz, GROUP)) / 1e6 for m in (4096, 8192)}
+    nk_by_m = {str(m): 2.0 * m * K * N / timeit(lambda: ops.gemv_forward(x[:m], nq, ns, nz, GROUP, flags=pre)) / 1e6 for m in (4096, 8192)}
 
     return {"shape": f"{K}x{N} g{GROUP}, M={M} (bs 8 x seq 2048)", "flops": fl,
-            "gemv_layout": {"us": us_nk, "kernel": nk_kernel, "roofline": roof(us_nk), "tflops_other_token_counts": nk_by_m,
-                            "vs_dequant_plus_gemm_max_rel": rel_nk,
-                            "what": "WQLinear_GEMV buffers (qweight [N, K/8]): awq_gemv_forward AUTO -> AWQ_GEMV_KERNEL_PREFILL"},
+            "gemv_layout": {"fused_nk": {"us": us_nk, "kernel": nk_kernel, "roofline": roof(us_nk), "tflops_other_token_counts": nk_by_m,
+                                         "vs_dequant_plus_gemm_max_rel": rel_nk},
+                            "two_pass": {"us": us_nk2, "roofline": roof(us_nk2)},
+                            "what": "WQLinear_GEMV buffers (qweight [N, K/8]), no second copy of the weights: the module's default route "
+                                    "(awq_dequantize_weights_gemv into a temporary + a dense fp16 GEMM) and the opt-in fused kernel "
+                                    "(AWQ_GEMV_KERNEL_PREFILL: gemm_regb.hip, N-major form)"},
             "fused_mfma": {"us": us_f, "kernel": kernel, "roofline": roof(us_f)},
             "fused_lds_tiled_r01": {"us": us_t, "roofline": roof(us_t)}, "two_pass": {"us": us_2, "roofline": roof(us_2)},
             "module": {"us": us_m, "roofline": roof(us_m),

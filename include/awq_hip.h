@@ -178,8 +178,7 @@ AWQ_EXPORT int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweigh
  * awq_ext.gemmv2_forward_cuda(..., group_size, split_k_iters) (awq/modules/linear/gemv.py:168-180).
  * y [M, N] fp16 = x [M, K] fp16 @ dequant(qweight)^T, fp32 accumulation; decode kernels: 1 <= M <= 16 per call and
  * awq_gemv_lds_bytes(M, K, ZW) <= 160 KiB (the host wrapper chunks larger M where the prefill kernel refuses); no bias (the
- * reference adds it afterwards, gemv.py:185).  AUTO: from 17 rows the prefill kernel (AWQ_GEMV_KERNEL_PREFILL: any M in one
- * call, the checkpoint's own buffers -- no second copy of the weights in another layout); M <= 2 (and M <= 4 for K <= 6144)
+ * reference adds it afterwards, gemv.py:185).  AUTO (M <= 16): M <= 2 (and M <= 4 for K <= 6144)
  * takes the row-streaming kernel
  * (gemv_rows.hip: a wave instruction reads 1 KiB of one row, activations in registers, no cross-CU exchange; needs
  * group_size % 128 == 0 and K <= 65536); 5 <= M with N >= 8192 and M K <= 32768 the LDS-streaming MFMA kernel (gemv_lds.hip:
@@ -191,8 +190,10 @@ AWQ_EXPORT int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweigh
 #define AWQ_GEMV_KERNEL_TILE16 1u /* 16 rows per block through v_mfma_f32_16x16x32_f16, M <= 16 */
 #define AWQ_GEMV_KERNEL_ROWS 2u   /* row-streaming kernel (1 KiB of one row per wave instruction, activations in registers), M <= 4 */
 #define AWQ_GEMV_KERNEL_LDS 3u    /* weights through LDS by DMA into MFMA 16x16x32, 2 <= M <= 16 with M K <= 32768; _SPLITK: waves per tile */
-#define AWQ_GEMV_KERNEL_PREFILL 4u /* M >= 17 in ONE call: the register-decoded MFMA GEMM on this layout's own buffers (gemm_regb.hip, NK
-                                     form; K % 64 == 0, group_size % 64 == 0, N % 4 == 0); _NLOG = 2: 256-row tiles */
+#define AWQ_GEMV_KERNEL_PREFILL 4u /* any M in ONE call: the register-decoded MFMA GEMM on this layout's own buffers (gemm_regb.hip, NK
+                                     form; K % 64 == 0, group_size % 64 == 0, N % 4 == 0); _NLOG = 2: 256-row tiles.  EXPLICIT only:
+                                     measured 0.29 of the MFMA peak at M = 16384 (dequantise + dense GEMM: 0.42) and latency-bound
+                                     below ~2000 rows (190 us at M = 32 for 4096 x 11008), so AUTO does not take it */
 /* Which AWQ_GEMV_KERNEL_* the AUTO dispatch of awq_gemv_forward takes for this shape (host only; -1: none takes it).  A pure
  * function of its arguments -- what awq_hip_last_kernel (a per-thread diagnostic) reports after the call. */
 AWQ_EXPORT int awq_gemv_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size);

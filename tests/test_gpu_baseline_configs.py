@@ -97,11 +97,12 @@ def test_regb_prefill_kernel_directly_at_config3_shape(ops, oracle, K, N, bm):
                                    (512, 64, 70), (3584, 8192, 257), (8192, 1280, 64)])
 @pytest.mark.parametrize("bm", [1, 2])
 def test_gemv_layout_prefill_kernel_vs_oracle(ops, oracle, K, N, M, bm):
-    """csrc/gemm_regb.hip in its N-MAJOR form (round 4: AWQ_GEMV_KERNEL_PREFILL, what WQLinear_GEMV runs from 17 rows) on the
+    """csrc/gemm_regb.hip in its N-MAJOR form (round 4: AWQ_GEMV_KERNEL_PREFILL, explicit; WQLinear_GEMV.PREFILL_IMPL = "fused") on the
     GEMV layout's own buffers: config 3's shape in both orientations, ragged M / N (partial row and column tiles, N % 256 != 0,
     N % 8 != 0 at N = 200 ... N % 4 == 0), the 70B shard shapes; sampled rows against the CPU oracle, every output against the
-    fp32 product of the bit-exact dequantised weights (awq_dequantize_weights_gemv); AUTO takes this kernel from 17 rows; one-hot
-    rows select rows of W; bitwise reproducible."""
+    fp32 product of the bit-exact dequantised weights (awq_dequantize_weights_gemv); AUTO stays on the 16-row chunks of the
+    decode kernels; one-hot rows select rows of W; bitwise reproducible; the module's two routes (default: dequantise + dense
+    GEMM; "fused": this kernel) agree with the oracle."""
     from test_gpu_parity import gemv_case
 
     qw, qz, sc, _ = gemv_case(K, N, 128, 1, seed=K + 5 * N + M)
@@ -111,10 +112,10 @@ def test_gemv_layout_prefill_kernel_vs_oracle(ops, oracle, K, N, M, bm):
     fl = ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL, nlog=bm)
     y = ops.gemv_forward(dx, dq, ds, dz, 128, flags=fl)
     assert ops.last_kernel() == "gemm_regb_nk" and y.shape == (M, N)
-    ya = ops.gemv_forward(dx, dq, ds, dz, 128)
-    assert ops.last_kernel() == "gemm_regb_nk"          # AUTO: one call, this kernel
-    if bm == 1:
-        assert torch.equal(y, ya)
+    if M <= 300 and bm == 1:
+        ya = ops.gemv_forward(dx, dq, ds, dz, 128)      # AUTO: the decode kernels, 16 rows per launch
+        assert ops.last_kernel() in ("gemv_nk", "gemv_lds", "gemv_rows")
+        assert float((ya.float() - y.float()).abs().max()) <= 2e-2 * float(y.float().abs().max())
     W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), 128)     # [K, N] fp16, the reference's rounding
     rows = torch.randperm(M, generator=gen)[:min(M, 96)].sort().values
     rows[0], rows[-1] = 0, M - 1
@@ -135,6 +136,14 @@ def test_gemv_layout_prefill_kernel_vs_oracle(ops, oracle, K, N, M, bm):
     e[torch.arange(rowsel, device="cuda"), ks] = 1.0
     if rowsel >= 17:
         assert torch.equal(ops.gemv_forward(e, dq, ds, dz, 128, flags=fl), Wt.t()[ks]), "one-hot rows must select rows of W"
+    if bm == 1 and M <= 4096:
+        from autoawq_amd import WQLinear_GEMV
+
+        mod = WQLinear_GEMV(4, 128, K, N, False, "cuda")
+        mod.qweight, mod.qzeros, mod.scales = dq, dz, ds
+        assert_product_close(mod(dx)[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module two-pass {K}x{N} M{M}")
+        mod.PREFILL_IMPL = "fused"
+        assert torch.equal(mod(dx), y) and ops.last_kernel() == "gemm_regb_nk"
 
 
 def test_gemv_layout_prefill_kernel_group_sizes_and_refusals(ops, oracle):
@@ -143,9 +152,10 @@ def test_gemv_layout_prefill_kernel_group_sizes_and_refusals(ops, oracle):
     from autoawq_amd import _lib
     from test_gpu_parity import gemv_case
 
+    pre = ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL)
     for K, N, g, M in [(1024, 256, 64, 40), (2048, 512, 2048, 33), (1024, 72, 64, 20)]:
         qw, qz, sc, x = gemv_case(K, N, g, M, seed=K + N + g)
-        y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g)
+        y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=pre)
         assert ops.last_kernel() == "gemm_regb_nk", (K, N, g)
         W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
         y32, _ = oracle.matmul(x.numpy(), W)
@@ -154,7 +164,7 @@ def test_gemv_layout_prefill_kernel_group_sizes_and_refusals(ops, oracle):
     with pytest.raises(_lib.AwqHipError) as ei:
         ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), 32, flags=ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL))
     assert ei.value.code == _lib.ERR_UNSUPPORTED
-    y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), 32)     # AUTO: falls through to the 16-row chunks
+    y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), 32)     # AUTO: the 16-row chunks
     assert ops.last_kernel() == "gemv_nk"
     W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), 32)
     y32, _ = oracle.matmul(x.numpy(), W)
