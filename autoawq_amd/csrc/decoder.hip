@@ -14,6 +14,32 @@
 
 namespace {
 
+// Cross-lane moves INSIDE a 16-lane row as DPP operands (a few cycles) instead of __shfl_xor (ds_bpermute: an LDS-crossbar round
+// trip of ~100 cycles each, and the attention inner loop made four of them per score, dependent on each other).
+template <int CTRL>
+AWQ_DEV float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a row, in every lane: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8
+#ifndef AWQ_ATTN_NO_DPP
+#define AWQ_ATTN_NO_DPP 0  // experiment builds: 1 = the __shfl_xor butterflies of rounds 1-3
+#endif
+// (dpp: uniform.  A/B on the whole decoder, profiles/r04_attention_split_ab.txt: the DPP form gains 1.5-3 % in single-split launches --
+// short contexts, where the kernel is a latency chain on 32 blocks -- and LOSES 6-10 % at 2048 tokens of context, where the
+// launch is memory-bound and the faster consumption only puts more requests in flight; so the launch shape picks the form.)
+AWQ_DEV float row16_sum(float s, bool dpp) {
+    if (AWQ_ATTN_NO_DPP || !dpp) {
+#pragma unroll
+        for (int x = 8; x > 0; x >>= 1) s += __shfl_xor(s, x, 64);
+        return s;
+    }
+    s += dpp_f<0xB1>(s);
+    s += dpp_f<0x4E>(s);
+    s += dpp_f<0x124>(s);
+    s += dpp_f<0x128>(s);
+    return s;
+}
+
 AWQ_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -110,7 +136,10 @@ __global__ __launch_bounds__(128) void awq_rope_kv_append_kernel(const half_t* _
 // grid (splits, Hkv, B), 256 threads.  A block owns one KV head, the G = Hq/Hkv query heads that
 // share it and a contiguous chunk of the sequence.  Lane (r = lane >> 4, c = lane & 15) reads the
 // 16 bytes [8c, 8c+8) of cache row t0 + 4*(wave + 4*i) + r: a wave instruction covers four whole
-// 256-byte rows (D = 128).  Scores by 16-lane butterfly, online softmax per lane group, P*V into
+// 256-byte rows (D = 128).  (Round 4 tried HEAD-major caches [B, Hkv, Tmax, D] -- four consecutive rows of a head = 1 KiB of contiguous
+// memory per instruction, on the theory that the 2.1 TB/s this kernel reaches at 2048 tokens is the rate of scattered 256-byte
+// pieces: no gain at 64 / 512 tokens, -1.5 % at 2048 and -6 % at 200 (one block then reads 50 KB from one region); reverted,
+// profiles/r04_attention_split_ab.txt.  The kernel is bound by its per-block latency chain, not by the access granularity.)  Scores by 16-lane butterfly, online softmax per lane group, P*V into
 // 8 fp32 accumulators per query head; lane groups, waves and finally the splits are merged with
 // the usual (max, sum, acc) rule.  Partial results of a split go to `part` [B, Hq, splits, D + 2]
 // fp32 and a second tiny kernel finishes; with one split the block writes fp16 directly.
@@ -136,6 +165,29 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
     const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 4, c = lane & 15;
+    // A launch with ONE split starts at row 0 whatever the length is: its first row sets are requested HERE, before the length,
+    // the rotation tables and the query have made their own round trips (at 64 tokens of context the kernel is nothing but a chain
+    // of dependent round trips on 32 blocks; rows at or past the length are requested too -- they exist, the cache is Tmax rows --
+    // and never used: `live` below).  Later row sets and launches with several splits request inside the loop as before.
+    constexpr int U = 4;  // row sets requested before any is consumed: 8 loads of 16 bytes in flight per lane
+    const int64_t rowstride = (int64_t)Hkv * D;
+    const half_t* kb = kc + ((int64_t)b * Tmax * Hkv + hk) * D + 8 * c;
+    const half_t* vb = vc + ((int64_t)b * Tmax * Hkv + hk) * D + 8 * c;
+#ifndef AWQ_ATTN_NO_EARLY
+#define AWQ_ATTN_NO_EARLY 0  // experiment builds: 1 = request every row set inside the loop (round 3's order)
+#endif
+    const bool early = gridDim.x == 1 && !AWQ_ATTN_NO_EARLY;
+    half8_t kv0[U], vv0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int t = 4 * wave + 16 * u + r;
+        kv0[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        vv0[u] = kv0[u];
+        if (early && t < Tmax) {
+            kv0[u] = *reinterpret_cast<const half8_t*>(kb + (int64_t)t * rowstride);
+            vv0[u] = *reinterpret_cast<const half8_t*>(vb + (int64_t)t * rowstride);
+        }
+    }
     // device-side lengths are clamped to the cache (see awq_rope_kv_append_kernel): never a row >= Tmax
     const int T = max(1, min((len_dev ? *len_dev : seq_len) + (FUSED ? 1 : 0), Tmax));
     const int pos = T - 1;  // FUSED: the new token's position
@@ -160,7 +212,7 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
             half8_t o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float mine = (float)x[e], other = __shfl_xor(mine, 8, 64);  // dims d and d +- 64
+                const float mine = (float)x[e], other = AWQ_ATTN_NO_DPP ? __shfl_xor(mine, 8, 64) : dpp_f<0x128>(mine);  // row_ror:8 = lane c ^ 8 of the row: dims d and d +- 64
                 o[e] = (c < 8) ? (half_t)(mine * cs[e] - other * sn[e]) : (half_t)(other * sn[e] + mine * cs[e]);
             }
             return o;
@@ -197,23 +249,25 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
     }
-    const int64_t rowstride = (int64_t)Hkv * D;
-    const half_t* kb = kc + ((int64_t)b * Tmax * Hkv + hk) * D + 8 * c;
-    const half_t* vb = vc + ((int64_t)b * Tmax * Hkv + hk) * D + 8 * c;
-    constexpr int U = 4;  // row sets requested before any is consumed: 8 loads of 16 bytes in flight per lane
     for (int tb = t0 + 4 * wave; tb < t1; tb += 16 * U) {  // wave-uniform trip count
         half8_t kv[U], vv[U];
+        const bool first = early && tb == 4 * wave;  // (uniform) these row sets were requested at the top of the kernel
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = tb + 16 * u + r;
-            kv[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            vv[u] = kv[u];
+            kv[u] = kv0[u];
+            vv[u] = vv0[u];
+            if (!first) {
+                kv[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                vv[u] = kv[u];
+                if (t < t1 && !(FUSED && t == pos)) {
+                    kv[u] = *reinterpret_cast<const half8_t*>(kb + (int64_t)t * rowstride);
+                    vv[u] = *reinterpret_cast<const half8_t*>(vb + (int64_t)t * rowstride);
+                }
+            }
             if (FUSED && t == pos) {  // the new token: from the qkv row, not from the cache
                 kv[u] = k_new;
                 vv[u] = v_new;
-            } else if (t < t1) {
-                kv[u] = *reinterpret_cast<const half8_t*>(kb + (int64_t)t * rowstride);
-                vv[u] = *reinterpret_cast<const half8_t*>(vb + (int64_t)t * rowstride);
             }
         }
 #pragma unroll
@@ -224,8 +278,7 @@ __global__ __launch_bounds__(256) void awq_decode_attn_kernel(const half_t* __re
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += qf[g][e] * (float)kv[u][e];
-#pragma unroll
-                for (int x = 8; x > 0; x >>= 1) s += __shfl_xor(s, x, 64);  // sum over the 16 lanes of the row
+                s = row16_sum(s, early);  // sum over the 16 lanes of the row
                 if constexpr (EXTRA) {
                     if (inv_cap > 0.f) s = softcap * tanhf(s * inv_cap);
                     s += slope[g] * (float)(tb + 16 * u + r - pos);

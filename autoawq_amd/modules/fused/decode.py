@@ -84,6 +84,7 @@ class GraphedDecoder:
         return logits
 
     # ---- one token ------------------------------------------------------------------------------------------------------
+    @torch.inference_mode()
     def _capture(self, bound):
         for b in self.blocks:
             b.attn.use_device_positions(self.pos, self.len)
@@ -129,6 +130,7 @@ class GraphedDecoder:
         self._sync_host_state()
         return logits
 
+    @torch.inference_mode()
     def replay(self):
         """The current bucket's graph once more on the decoder's stream with the ids already in place (benchmarks: no host
         copies in the timed region).  Advances the position like `step`."""
