@@ -382,9 +382,12 @@ def leg_whole_model(dev):
     wg = bench_decode_model.run(contexts=(64, 2048), steps=48, dev=dev, verbose=False, check=True, layout="gemm")
     return {"unit": "tok/s", "layout": "gemv", "context_64": 1000.0 / wm[64], "context_2048": 1000.0 / wm[2048],
             "gemm_layout": {"context_64": 1000.0 / wg[64], "context_2048": 1000.0 / wg[2048]},
-            "what": "synthetic 7B-shape fused decoder (32 blocks + lm_head), one hipGraph per token, five launches per block "
-                    "(qkv with the norm in its prologue, RoPE + append + attention, o_proj + residual, gate|up with norm in and "
-                    "silu * mul out, down + residual); logits checked against the unfused module path before timing",
+            "what": "synthetic 7B-shape fused decoder (32 blocks + lm_head) through modules/fused/decode.py::GraphedDecoder: one hipGraph "
+                    "replay per token, one captured step per context-length bucket (256 / 1024 / 4096 ... rows; the attention launch is "
+                    "sized for the bucket), five launches per block (qkv with the norm in its prologue, RoPE + append + attention, "
+                    "o_proj + residual, gate|up with norm in and silu * mul out, down + residual); logits of the replayed graph "
+                    "checked against the unfused module path before timing (HIP vs HIP: a consistency check, the parity tests "
+                    "against the reference's logits are tests/test_decoder.py)",
             "published_reference": {"value": 198.848, "context": 64, "hardware": "RTX 4090", "source": "README.md:207 (BASELINE.md)"},
             "vs_published_ctx64": (1000.0 / wm[64]) / 198.848}
 
