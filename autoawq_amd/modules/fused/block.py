@@ -167,3 +167,144 @@ class LlamaLikeBlock(nn.Module):
         attn_output, _, _ = self.attn.forward(hidden_states=norm_out)
         normed = self.norm_2(attn_output, residual=h)
         return self.mlp.forward(normed), h, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The other block families of awq/modules/fused/block.py (round 4): the same constructors and dataflows over this package's
+# QuantAttentionFused (whose feature surface -- ALiBi, logit soft-capping, q / k norms, custom attention shapes -- round 3 built and
+# pinned).  They run the plain module path (separate norm / attention / MLP launches); the five-launch folded decode path is
+# LlamaLikeBlock's.  Not built: CohereBlock (block.py:264-320) -- it asks for the INTERLEAVED rotary form (`is_neox=False`), which
+# awq_rope_kv_append does not implement -- and Phi-3's `rope_scaling` (long-rope factors): both raise instead of computing
+# something else.
+
+def _add(a, b):
+    return a.to(b.device) + b
+
+
+class QwenBlock(nn.Module):
+    """awq/modules/fused/block.py:122-188 (Qwen2 / Qwen3: q_norm / k_norm on the heads, optional separate head_dim)."""
+
+    def __init__(self, hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, mlp, norm_1, norm_2, dev, max_seq_len,
+                 rope_theta=10000, partial_rotary_factor=1.0, use_alibi=False, head_dim=None, q_norm=None, k_norm=None):
+        super().__init__()
+        self.n_heads, self.n_kv_heads, self.hidden_size = n_heads, n_kv_heads, hidden_size
+        self.head_dim = head_dim if head_dim else hidden_size // n_heads
+        self.norm_1 = norm_1.to(dev)
+        self.attn = QuantAttentionFused(hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, dev=dev, max_seq_len=max_seq_len,
+                                        use_alibi=use_alibi, rope_theta=rope_theta, partial_rotary_factor=partial_rotary_factor,
+                                        head_dim=head_dim, q_norm=q_norm, k_norm=k_norm).to(dev)
+        self.norm_2 = norm_2.to(dev)
+        self.mlp = mlp.to(dev)
+        self.device = dev
+
+    def forward(self, hidden_states):
+        attn_output, _, _ = self.attn.forward(hidden_states=self.norm_1(hidden_states))
+        h = _add(hidden_states, attn_output)
+        return h + self.mlp.forward(self.norm_2(h))
+
+
+class Gemma2LikeBlock(nn.Module):
+    """awq/modules/fused/block.py:190-262 (Gemma-2: a norm before AND after attention and MLP, logit soft-capping)."""
+
+    def __init__(self, hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, mlp, norm_1, norm_2, norm_3, norm_4, dev, max_seq_len,
+                 rope_theta=10000, partial_rotary_factor=1.0, use_alibi=False, head_dim=None, attn_logit_softcapping=None):
+        super().__init__()
+        self.n_heads, self.n_kv_heads, self.hidden_size = n_heads, n_kv_heads, hidden_size
+        self.head_dim = head_dim if head_dim else hidden_size // n_heads
+        self.norm_1 = norm_1.to(dev)
+        self.attn = QuantAttentionFused(hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, dev=dev, max_seq_len=max_seq_len,
+                                        use_alibi=use_alibi, rope_theta=rope_theta, partial_rotary_factor=partial_rotary_factor,
+                                        head_dim=head_dim, attn_logit_softcapping=attn_logit_softcapping or 0.0).to(dev)
+        self.norm_2 = norm_2.to(dev)
+        self.norm_3 = norm_3.to(dev)
+        self.mlp = mlp.to(dev)
+        self.norm_4 = norm_4.to(dev)
+        self.device = dev
+
+    def forward(self, hidden_states):
+        attn_output, _, _ = self.attn.forward(hidden_states=self.norm_1(hidden_states))
+        h = _add(hidden_states, self.norm_2(attn_output))
+        return h + self.norm_4(self.mlp(self.norm_3(h)))
+
+
+class Phi3Block(nn.Module):
+    """awq/modules/fused/block.py:489-544 (Phi-3: the checkpoint's qkv_proj is already fused, the MLP's gate_up_proj too)."""
+
+    def __init__(self, hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, mlp, norm_1, norm_2, dev, max_seq_len,
+                 rope_theta=10000, rope_scaling=None, use_alibi=False, head_dim=None):
+        super().__init__()
+        if rope_scaling is not None:
+            raise NotImplementedError("Phi3Block: rope_scaling (long-rope factors) is not implemented by awq_rope_kv_append")
+        self.n_heads, self.n_kv_heads, self.hidden_size = n_heads, n_kv_heads, hidden_size
+        self.head_dim = head_dim if head_dim else hidden_size // n_heads
+        self.norm_1 = norm_1.to(dev)
+        self.attn = QuantAttentionFused(hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, dev=dev, max_seq_len=max_seq_len,
+                                        use_alibi=use_alibi, rope_theta=rope_theta, head_dim=head_dim).to(dev)
+        self.norm_2 = norm_2.to(dev)
+        self.mlp = mlp.to(dev)
+        self.device = dev
+
+    def forward(self, hidden_states):
+        attn_output, _, _ = self.attn.forward(hidden_states=self.norm_1(hidden_states))
+        h = _add(hidden_states, attn_output)
+        return h + self.mlp.forward(self.norm_2(h))
+
+
+class MPTBlock(nn.Module):
+    """awq/modules/fused/block.py:322-368 (MPT: multi-head attention with ALiBi, no rotation; LayerNorms; `ffn`)."""
+
+    def __init__(self, hidden_size, n_heads, qkv_layer, o_proj, mpt_mlp, norm_1, norm_2, dev, max_seq_len):
+        super().__init__()
+        self.n_heads, self.n_kv_heads, self.hidden_size = n_heads, 0, hidden_size
+        self.norm_1 = norm_1
+        self.attn = QuantAttentionFused(hidden_size, n_heads, 0, qkv_layer, o_proj, dev=dev, max_seq_len=max_seq_len, use_alibi=True).to(dev)
+        self.norm_2 = norm_2
+        self.ffn = mpt_mlp.to(dev)
+        self.device = dev
+
+    def forward(self, hidden_states):
+        attn_output, _, _ = self.attn.forward(hidden_states=self.norm_1(hidden_states))
+        h = _add(hidden_states, attn_output)
+        return h + self.ffn.forward(self.norm_2(h))
+
+
+class FalconDecoderLayer(nn.Module):
+    """awq/modules/fused/block.py:371-487 (Falcon: attention and MLP in PARALLEL on the block input; new architecture: 8 KV heads and a
+    LayerNorm per branch; old architecture: multi-query attention, one shared LayerNorm, custom attention shapes)."""
+
+    def __init__(self, hidden_size, n_heads, qkv_layer, o_proj, mlp, dev, max_seq_len, input_layernorm=None, ln_attn=None, ln_mlp=None,
+                 new_decoder_arch=True):
+        super().__init__()
+        self.n_heads, self.hidden_size, self.new_decoder_arch = n_heads, hidden_size, new_decoder_arch
+        self.n_kv_heads = 8 if new_decoder_arch else 0
+        head_dim = hidden_size // n_heads
+        shapes = None
+        if not new_decoder_arch:  # one shared K / V head behind the query heads of the fused row (block.py:428-460)
+            shapes = {"xqkv_view": (n_heads + 2, head_dim),
+                      "xq_slice": lambda xqkv: xqkv[:, :, :-2], "xk_slice": lambda xqkv: xqkv[:, :, [-2]], "xv_slice": lambda xqkv: xqkv[:, :, [-1]],
+                      "xq_view": (n_heads, head_dim), "xk_view": (1, head_dim), "xv_view": (1, head_dim), "xk_reshape": (1, head_dim // 8, 8),
+                      "single_xq_view": (n_heads, head_dim), "single_xk_view": (1, head_dim), "single_xv_view": (1, head_dim)}
+        self.attention_shapes = shapes
+        self.attn = QuantAttentionFused(hidden_size, n_heads, self.n_kv_heads if new_decoder_arch else 1, qkv_layer, o_proj, dev=dev,
+                                        max_seq_len=max_seq_len, use_alibi=False, attention_shapes=shapes).to(dev)
+        if new_decoder_arch:
+            self.ln_attn, self.ln_mlp = ln_attn, ln_mlp
+        else:
+            self.input_layernorm = input_layernorm
+        self.mlp = mlp
+        self.device = dev
+
+    def forward(self, hidden_states):
+        if self.new_decoder_arch:
+            attn_in, mlp_in = self.ln_attn(hidden_states), self.ln_mlp(hidden_states)
+        else:
+            attn_in = mlp_in = self.input_layernorm(hidden_states)
+        attn_output, _, _ = self.attn.forward(hidden_states=attn_in)
+        return _add(hidden_states, attn_output) + self.mlp.forward(mlp_in)
+
+
+class CohereBlock(nn.Module):
+    """awq/modules/fused/block.py:264-320 is NOT built: it needs the interleaved rotary form (`is_neox=False`)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("CohereBlock needs interleaved RoPE (is_neox=False), which awq_rope_kv_append does not implement")
