@@ -70,7 +70,8 @@ class OneShotAllReduce:
         self._fp = (ctypes.c_void_p * world)(*[t.data_ptr() for t in flags])
         self.device = state.device
         self._calls = 0
-        self._err_host = torch.zeros(4, dtype=torch.int32).pin_memory() if state.is_cuda else None
+        with torch.inference_mode(False):  # (a persistent buffer: never an inference tensor, whatever mode the constructor runs in)
+            self._err_host = torch.zeros(4, dtype=torch.int32).pin_memory() if state.is_cuda else None
         self._err_event = None
 
     # ---- construction -----------------------------------------------------------------------------------------------

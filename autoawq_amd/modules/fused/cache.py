@@ -23,10 +23,11 @@ class WindowedCache:
         self._alloc(int(cache_batch_size), heads, int(head_dim), device)
 
     def _alloc(self, batch, heads, head_dim, device, keep=None):
-        kv = torch.zeros((2, batch, self.max_seq_len, heads, head_dim), dtype=torch.float16, device=device)
-        if keep is not None:
-            n = min(batch, keep.shape[1])
-            kv[:, :n] = keep[:, :n].to(device)
+        with torch.inference_mode(False):  # a persistent buffer written in place from any context: never an inference tensor
+            kv = torch.zeros((2, batch, self.max_seq_len, heads, head_dim), dtype=torch.float16, device=device)
+            if keep is not None:
+                n = min(batch, keep.shape[1])
+                kv[:, :n] = keep[:, :n].to(device)
         self.kv = kv
         self.k, self.v = kv[0], kv[1]
 

@@ -42,9 +42,10 @@ class GraphedDecoder:
         if bounds[-1] < self.max_seq_len:
             bounds.append(self.max_seq_len)
         self.bounds = bounds
-        self.pos = torch.zeros(1, dtype=torch.int32, device=self.device)   # start position of the step
-        self.len = torch.ones(1, dtype=torch.int32, device=self.device)    # cache rows after its append
-        self.tok = torch.zeros((self.batch, 1), dtype=torch.int64, device=self.device)
+        with torch.inference_mode(False):  # persistent buffers written in place from any context: never inference tensors
+            self.pos = torch.zeros(1, dtype=torch.int32, device=self.device)   # start position of the step
+            self.len = torch.ones(1, dtype=torch.int32, device=self.device)    # cache rows after its append
+            self.tok = torch.zeros((self.batch, 1), dtype=torch.int64, device=self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.graphs = {}  # bucket bound -> (graph, logits)
         self.position = 0

@@ -39,7 +39,9 @@ class QuantFusedMLP(nn.Module):
         `state_dict()` use) are views into it, so loading into them, or reading them, touches the same memory."""
         dim = 0 if self.gemv_layout else 1  # GEMV layout stacks output rows, GEMM layout columns
         self._pairs = None
-        fused = tuple(torch.cat([g, u], dim=dim).contiguous() for g, u in ((gq, uq), (gs, us), (gz, uz)))
+        with torch.inference_mode(False):  # (the registered buffers become views of these: never inference tensors, so that a
+            # later load_state_dict -- an in-place copy from an ordinary context -- works even if a forward under inference mode re-fused them)
+            fused = tuple(torch.cat([g, u], dim=dim).contiguous() for g, u in ((gq, uq), (gs, us), (gz, uz)))
         self._fused = fused
         for name, f, g in (("qweight", fused[0], gq), ("scales", fused[1], gs), ("qzeros", fused[2], gz)):
             n = g.shape[dim]

@@ -58,9 +58,13 @@ class _Workspace:
     that finds the copy complete inspects it, re-initialises the workspace and raises."""
 
     def __init__(self, device, nbytes):
-        self.buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        # (created OUTSIDE inference mode whatever the caller's mode is: a workspace first needed inside `torch.inference_mode()` --
+        #  the fused model's forward -- would otherwise hold inference tensors, and the read-back below, issued later from an
+        #  ordinary context, would raise "Inplace update to inference tensor outside InferenceMode")
+        with torch.inference_mode(False):
+            self.buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.calls = 0
-        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.event = None
         self.init()
 

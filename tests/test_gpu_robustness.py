@@ -113,3 +113,27 @@ def test_error_word_is_noticed(ops):
     ref = ops.gemm_forward(*c)
     assert torch.equal(ref, ops.gemm_forward(*c))
     ops.check_workspaces()
+
+
+def test_workspace_first_created_inside_inference_mode_is_usable_outside():
+    """The fused model's forward runs under `torch.inference_mode()`; a split-K workspace first created there used to hold
+    inference tensors, and its error-word read-back -- every 64th call, here from an ordinary context -- raised (found by the
+    round-4 suite once a test that decodes under inference mode ran before the others)."""
+    from autoawq_amd import ops
+
+    gen = torch.Generator().manual_seed(3)
+    lim = 0x7FFFFFFF
+    K, N = 512, 256
+    qw = torch.randint(-lim - 1, lim, (K, N // 8), dtype=torch.int32, generator=gen).cuda()
+    qz = torch.randint(-lim - 1, lim, (K // 128, N // 8), dtype=torch.int32, generator=gen).cuda()
+    sc = (torch.rand((K // 128, N), generator=gen) * 0.02 + 0.005).half().cuda()
+    x = torch.randn((1, K), generator=gen).half().cuda()
+    s = torch.cuda.Stream()   # a stream nobody has used: its workspace does not exist yet
+    with torch.cuda.stream(s):
+        with torch.inference_mode():
+            first = ops.gemm_forward(x, qw, sc, qz).clone()
+        for _ in range(3 * 64 + 5):   # crosses the read-back interval several times, outside inference mode
+            y = ops.gemm_forward(x, qw, sc, qz)
+        s.synchronize()
+    assert torch.equal(y, first)
+    ops.check_workspaces()
