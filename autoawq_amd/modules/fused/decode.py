@@ -91,8 +91,9 @@ class GraphedDecoder:
             b.attn.use_device_positions(self.pos, self.len)
             b.attn.decode_len_bound = bound
         keep = (self.pos.clone(), self.len.clone())
+        caller = torch.cuda.current_stream(self.device)  # (taken BEFORE entering the decoder's stream: the ids were copied on it)
         with torch.cuda.stream(self.stream):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self.stream.wait_stream(caller)
             # (the warm-up step runs the kernels for real -- it appends a row at the current position, which the first replay
             #  writes again with the real token -- and builds every lazily cached buffer OUTSIDE the capture)
             self.lm(self.tok)
@@ -104,8 +105,9 @@ class GraphedDecoder:
                 self.pos.add_(1)
                 self.len.add_(1)
             self.stream.synchronize()
-        self.pos.copy_(keep[0])
-        self.len.copy_(keep[1])
+            self.pos.copy_(keep[0])
+            self.len.copy_(keep[1])
+        caller.wait_stream(self.stream)
         self._sync_host_state()
         self.graphs[bound] = (graph, logits)
         return self.graphs[bound]
@@ -123,10 +125,11 @@ class GraphedDecoder:
         if entry is None:
             entry = self._capture(bound)
         graph, logits = entry
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)   # the ids were copied on the caller's stream
         with torch.cuda.stream(self.stream):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             graph.replay()
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        caller.wait_stream(self.stream)   # ... and the caller reads the logits
         self.position += 1
         self._sync_host_state()
         return logits
