@@ -41,10 +41,20 @@ def guard_stats():
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
     config.addinivalue_line("markers", "guard_skip: not run under the guard-band allocator (AWQ_GUARD_ALLOC)")
+    config.addinivalue_line("markers", "gpu_fault: provokes a GPU memory fault on purpose in a child process (AWQ_RUN_FAULT_SELFCHECK=1 selects it)")
     install_guard_allocator()
 
 
 def pytest_collection_modifyitems(config, items):
+    # `gpu_fault` tests provoke a GPU memory fault ON PURPOSE (the guard-band allocator's self-check).  The fault only kills the child
+    # process that provokes it -- it did so cleanly on every box of round 4 (profiles/r04_final_195ff05/guard/selfcheck_*.log) -- but
+    # a fault is not something to put in front of every later test of a shared box by default: they are DESELECTED unless
+    # AWQ_RUN_FAULT_SELFCHECK=1 (tools/guard_run.sh runs the same self-check as a script in its evidence runs).
+    if os.environ.get("AWQ_RUN_FAULT_SELFCHECK", "") != "1":
+        drop = [it for it in items if "gpu_fault" in it.keywords]
+        if drop:
+            config.hook.pytest_deselected(items=drop)
+            items[:] = [it for it in items if "gpu_fault" not in it.keywords]
     if os.environ.get("AWQ_GUARD_ALLOC", "") in ("end", "start"):
         skip = pytest.mark.skip(reason="not under the guard-band allocator")
         for it in items:

@@ -30,9 +30,12 @@ def _lib_built():
     return build.build()
 
 
+@pytest.mark.gpu_fault
 @pytest.mark.parametrize("mode", ["end", "start"])
 def test_guard_allocator_faults_on_an_access_outside_an_allocation(mode):
-    """The checker itself: a read 8 KiB outside a guarded allocation must kill the child (else the runs below prove nothing)."""
+    """The checker itself: a read 8 KiB outside a guarded allocation must kill the child (else the runs below prove nothing).
+    Provokes a real GPU memory fault: selected only with AWQ_RUN_FAULT_SELFCHECK=1 (tests/conftest.py); the evidence runs of
+    tools/guard_run.sh perform the same self-check (profiles/r04_final_195ff05/guard/selfcheck_end.log: "Memory access fault")."""
     _lib_built()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard_selfcheck.py")], env=_env(mode), cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
