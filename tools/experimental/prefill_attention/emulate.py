@@ -1,0 +1,295 @@
+"""CPU desk-check of prefill_attn.hip's index algebra (runs here, no GPU): a numpy model of ONE block that follows the kernel's
+expressions line by line -- the thread -> (row, chunk) staging maps, both LDS swizzles, the v_perm transposition of V, the
+fragment addresses, the k-slot order shared by P and V^T, the lane -> (query, d) ownership of the accumulators, the output
+addresses -- on top of the v_mfma_f32_16x16x32_f16 operand layout the GEMM kernels of csrc/ are built on (and validated on
+the GPU with): A lane (j, kb) = row j, k 8 kb + i; B lane (j, kb) = column j, k 8 kb + i; C lane (j, kb), e = row 4 kb + e,
+column j.  What it cannot check: instruction semantics, hazards, timing.
+
+    python tools/experimental/prefill_attention/emulate.py          # exit status 0 = every case within tolerance"""
+import sys
+
+import numpy as np
+
+HD, BQ, BKV = 128, 128, 64
+LANES = np.arange(64)
+J, KB = LANES & 15, LANES >> 4
+
+
+def mfma16(a, b, c):
+    """a, b [64 lanes, 8] (fp16 values as float32), c [64, 4] -> c + A B in the layout above"""
+    A = np.zeros((16, 32), np.float32)
+    B = np.zeros((32, 16), np.float32)
+    for i in range(8):
+        A[J, 8 * KB + i] = a[:, i]
+        B[8 * KB + i, J] = b[:, i]
+    C = A @ B
+    out = c.copy()
+    for e in range(4):
+        out[:, e] += C[4 * KB + e, J]
+    return out
+
+
+def perm(a, b, sel):
+    """v_perm_b32 on uint32 arrays: selector byte 0-3 -> byte of b (second operand), 4-7 -> byte of a"""
+    out = np.zeros_like(a)
+    for byte in range(4):
+        s = (sel >> (8 * byte)) & 0xFF
+        src = b if s < 4 else a
+        out |= ((src >> np.uint32(8 * (s & 3))) & np.uint32(0xFF)) << np.uint32(8 * byte)
+    return out
+
+
+def run_block(q, kc, vc, b, h, kvh, qb, start, S, scale, softcap=0.0, slope_h=0.0):
+    """q [B, S, Hq, 128] fp16, kc / vc [Bc, Tmax, Hkv, 128] fp16 -> {(row, d): value} of the block's stores"""
+    mods = softcap > 0 or slope_h != 0.0
+    kv_len = start + S
+    q0 = qb * BQ
+    lds = np.zeros(2 * (BKV * HD * 2 + HD * BKV * 2), np.uint8)
+    K_TILE = BKV * HD * 2
+    V_TILE = HD * BKV * 2
+    tid = np.arange(256)
+    sc, sr = tid & 15, tid >> 4
+
+    def krow16(row, chunk):  # 16 bytes of cache row `row`, d = 8 chunk ..: zeros past kv_len (descriptor bound)
+        out = np.zeros((len(row), 8), np.float16)
+        ok = row < kv_len
+        out[ok] = kc[b, row[ok], kvh].reshape(-1, 16, 8)[np.arange(ok.sum()), chunk[ok]]
+        return out
+
+    def vrow16(row, chunk):
+        out = np.zeros((len(row), 8), np.float16)
+        ok = row < kv_len
+        out[ok] = vc[b, row[ok], kvh].reshape(-1, 16, 8)[np.arange(ok.sum()), chunk[ok]]
+        return out
+
+    def stage_tile(buf, kv0):
+        base = buf * (K_TILE + V_TILE)
+        for i in range(4):  # write_k
+            r = sr + 16 * i
+            data = krow16(kv0 + r, sc).view(np.uint8).reshape(256, 16)
+            addr = base + r * 256 + 16 * (sc ^ (r & 15))
+            for t in range(256):
+                lds[addr[t]:addr[t] + 16] = data[t]
+        vreg = [vrow16(kv0 + 4 * sr + i, sc).view(np.uint32).reshape(256, 4) for i in range(4)]  # write_v
+        for i in range(8):
+            sel = 0x07060302 if (i & 1) else 0x05040100
+            t0 = perm(vreg[1][:, i >> 1], vreg[0][:, i >> 1], sel)
+            t1 = perm(vreg[3][:, i >> 1], vreg[2][:, i >> 1], sel)
+            d = 8 * sc + i
+            g = (d ^ (d >> 3)) & 15
+            addr = base + K_TILE + d * 128 + 8 * (sr ^ g)
+            both = np.stack([t0, t1], axis=1).astype(np.uint32).view(np.uint8).reshape(256, 8)
+            for t in range(256):
+                lds[addr[t]:addr[t] + 8] = both[t]
+
+    stores = {}
+    for wave in range(4):
+        pass
+    # Q fragments per wave
+    last_row = min(q0 + BQ, S) - 1
+    ntiles = (start + last_row) // BKV + 1
+    state = []
+    for wave in range(4):
+        qw0 = q0 + 32 * wave
+        qf = np.zeros((2, 4, 64, 8), np.float32)
+        for qt in range(2):
+            row = qw0 + 16 * qt + J
+            for ks in range(4):
+                for ln in range(64):
+                    if row[ln] < S:
+                        d0 = 32 * ks + 8 * KB[ln]
+                        qf[qt, ks, ln] = q[b, row[ln], h, d0:d0 + 8].astype(np.float32)
+        state.append(dict(qw0=qw0, qf=qf, oacc=np.zeros((2, 8, 64, 4), np.float32), m=np.full((2, 64), -np.inf, np.float32),
+                          l=np.zeros((2, 64), np.float32)))
+    stage_tile(0, 0)
+    for it in range(ntiles):
+        buf, kv0 = it & 1, it * BKV
+        base = buf * (K_TILE + V_TILE)
+        for wave in range(4):
+            st = state[wave]
+            qw0 = st["qw0"]
+            sacc = np.zeros((2, 4, 64, 4), np.float32)
+            for t in range(4):
+                for ks in range(4):
+                    addr = base + (16 * t + J) * 256 + 16 * ((4 * ks + KB) ^ J)
+                    kf = np.stack([lds[a:a + 16].view(np.float16).astype(np.float32) for a in addr])
+                    for qt in range(2):
+                        sacc[qt, t] = mfma16(kf, st["qf"][qt, ks], sacc[qt, t])
+            qpos = np.stack([start + qw0 + 16 * qt + J for qt in range(2)])
+            kvidx = np.zeros((4, 64, 4), np.int64)
+            for t in range(4):
+                for e in range(4):
+                    kvidx[t, :, e] = kv0 + 16 * t + 4 * KB + e
+            if mods:
+                for qt in range(2):
+                    sv = sacc[qt] * np.float32(scale)
+                    if softcap > 0:
+                        sv = np.float32(softcap) * np.tanh(sv / np.float32(softcap))
+                    sacc[qt] = sv * np.float32(1.44269504088896) + np.float32(slope_h * 1.44269504088896) * (kvidx - qpos[qt][None, :, None]).astype(np.float32)
+            if kv0 + BKV - 1 > start + qw0:
+                for qt in range(2):
+                    sacc[qt][kvidx > qpos[qt][None, :, None]] = -np.inf
+            sc2 = np.float32(1.0 if mods else scale * 1.44269504088896)
+            pf = np.zeros((2, 2, 64, 8), np.float32)
+            for qt in range(2):
+                mloc = sacc[qt].transpose(1, 0, 2).reshape(64, 16).max(axis=1)
+                mloc = np.maximum(mloc, mloc[LANES ^ 16])
+                mloc = np.maximum(mloc, mloc[LANES ^ 32])
+                m_new = np.maximum(st["m"][qt], mloc * sc2)
+                alpha = np.exp2(st["m"][qt] - m_new)
+                st["m"][qt] = m_new
+                pr = np.exp2(sacc[qt] * sc2 - m_new[None, :, None])  # [t, lane, e]
+                st["l"][qt] = st["l"][qt] * alpha + pr.sum(axis=(0, 2))
+                st["oacc"][qt] *= alpha[None, :, None]
+                prh = pr.astype(np.float16).astype(np.float32)
+                for u in range(2):
+                    pf[qt, u, :, 0:4] = prh[2 * u]
+                    pf[qt, u, :, 4:8] = prh[2 * u + 1]
+            for dt in range(8):
+                lane_x = 8 * (KB ^ J ^ (J >> 3))
+                row = base + K_TILE + (16 * dt + J) * 128
+                for u in range(2):
+                    lo = row + (lane_x ^ (8 * ((8 * u) ^ (2 * dt))))
+                    hi = row + (lane_x ^ (8 * ((8 * u + 4) ^ (2 * dt))))
+                    vf = np.stack([np.concatenate([lds[a:a + 8].view(np.float16), lds[c:c + 8].view(np.float16)]).astype(np.float32)
+                                   for a, c in zip(lo, hi)])
+                    for qt in range(2):
+                        st["oacc"][qt, dt] = mfma16(vf, pf[qt, u], st["oacc"][qt, dt])
+        stage_tile(buf ^ 1, kv0 + BKV)
+    for wave in range(4):
+        st = state[wave]
+        for qt in range(2):
+            l = st["l"][qt]
+            l = l + l[LANES ^ 16]
+            l = l + l[LANES ^ 32]
+            for ln in range(64):
+                row = st["qw0"] + 16 * qt + J[ln]
+                if row >= S:
+                    continue
+                for dt in range(8):
+                    for e in range(4):
+                        stores[(row, 16 * dt + 4 * KB[ln] + e)] = st["oacc"][qt, dt, ln, e] / l[ln]
+    return stores
+
+
+def reference(q, kc, vc, b, h, kvh, start, S, scale, softcap, slope_h):
+    kv_len = start + S
+    qq = q[b, :, h].astype(np.float64)
+    kk = kc[b, :kv_len, kvh].astype(np.float64)
+    vv = vc[b, :kv_len, kvh].astype(np.float64)
+    s = qq @ kk.T * scale
+    if softcap > 0:
+        s = softcap * np.tanh(s / softcap)
+    qpos = start + np.arange(S)[:, None]
+    kpos = np.arange(kv_len)[None, :]
+    s = s + slope_h * (kpos - qpos)
+    s[kpos > qpos] = -np.inf
+    p = np.exp(s - s.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    return p @ vv
+
+
+def check_block_map():
+    """the kernel's blockIdx -> (batch, kv head, query head, row block) map covers every work item exactly once"""
+    bad = 0
+    for B, Hq, Hkv, S in [(1, 32, 32, 2048), (2, 32, 8, 300), (3, 8, 1, 128), (1, 28, 4, 1000), (5, 16, 2, 129)]:
+        qblocks = (S + BQ - 1) // BQ
+        per_group = qblocks * (Hq // Hkv)
+        groups = B * Hkv
+        grid = 8 * ((groups + 7) // 8) * per_group
+        seen = {}
+        for bid in range(grid):
+            xcd, slot = bid & 7, bid >> 3
+            group = xcd + 8 * (slot // per_group)
+            if group >= groups:
+                continue
+            within = slot % per_group
+            b, kvh = group // Hkv, group % Hkv
+            hq_per = Hq // Hkv
+            qb = qblocks - 1 - within // hq_per
+            h = kvh * hq_per + within % hq_per
+            key = (b, h, qb)
+            assert h // hq_per == kvh
+            seen[key] = seen.get(key, 0) + 1
+        ok = len(seen) == B * Hq * qblocks and all(v == 1 for v in seen.values())
+        bad += not ok
+        print(f"block map B={B} Hq={Hq} Hkv={Hkv} S={S}: {len(seen)} items over {grid} blocks {'ok' if ok else 'WRONG'}")
+    return bad
+
+
+def check_bank_conflicts():
+    """LDS conflict degree of every read / write of the kernel under the lane-group and bank rules of MI355X_MICROARCH.md (LDS
+    table): 1 = conflict-free.  Reported, not asserted (a conflict costs time, not correctness)."""
+    def ways(addr, nbytes, groups, banks):
+        worst = 1
+        for g in groups:
+            per_bank = {}
+            for ln in g:
+                for w in range(nbytes // 4):
+                    a = int(addr[ln]) + 4 * w
+                    per_bank.setdefault((a // 4) % banks, set()).add(a // 4)
+            worst = max(worst, max(len(v) for v in per_bank.values()))
+        return worst
+
+    r = lambda *spans: [l for a, b in spans for l in range(a, b + 1)]
+    g_b128 = [r((0, 3), (12, 15), (20, 27)), r((4, 11), (16, 19), (28, 31)), r((32, 35), (44, 47), (52, 59)), r((36, 43), (48, 51), (60, 63))]
+    g_half = [list(range(0, 32)), list(range(32, 64))]
+    g_16 = [list(range(16 * i, 16 * i + 16)) for i in range(4)]
+    g_8 = [list(range(8 * i, 8 * i + 8)) for i in range(8)]
+    out = {}
+    out["K fragment read (ds_read_b128)"] = max(ways((16 * t + J) * 256 + 16 * ((4 * ks + KB) ^ J), 16, g_b128, 64)
+                                                for t in range(4) for ks in range(4))
+    lane_x = 8 * (KB ^ J ^ (J >> 3))
+    out["V^T fragment read (ds_read_b64)"] = max(ways((16 * dt + J) * 128 + (lane_x ^ (8 * ((8 * u + 4 * hl) ^ (2 * dt)))), 8, g_half, 64)
+                                                 for dt in range(8) for u in range(2) for hl in range(2))
+    for wave in range(4):
+        tid = 64 * wave + LANES
+        sc, sr = tid & 15, tid >> 4
+        kw = max(ways((sr + 16 * i) * 256 + 16 * (sc ^ ((sr + 16 * i) & 15)), 16, g_8, 32) for i in range(4))
+        vw = 1
+        for i in range(8):
+            d = 8 * sc + i
+            vw = max(vw, ways(d * 128 + 8 * (sr ^ ((d ^ (d >> 3)) & 15)), 8, g_16, 32))
+        out[f"K tile write, wave {wave} (ds_write_b128)"] = kw
+        out[f"V^T tile write, wave {wave} (ds_write_b64)"] = vw
+    for k, v in out.items():
+        print(f"LDS conflict degree, {k}: {v}")
+
+
+def main():
+    rng = np.random.default_rng(0)
+    bad = check_block_map()
+    check_bank_conflicts()
+    cases = [  # (S, start, Hq, Hkv, softcap, slope)
+        (128, 0, 2, 1, 0.0, 0.0),
+        (200, 0, 2, 2, 0.0, 0.0),
+        (70, 100, 2, 1, 0.0, 0.0),
+        (130, 60, 1, 1, 30.0, 0.0),
+        (96, 33, 2, 1, 0.0, 0.0625),
+    ]
+    for S, start, Hq, Hkv, softcap, slope in cases:
+        Tmax = start + S + 37
+        q = rng.standard_normal((1, S, Hq, HD)).astype(np.float16)
+        kc = rng.standard_normal((1, Tmax, Hkv, HD)).astype(np.float16)
+        vc = rng.standard_normal((1, Tmax, Hkv, HD)).astype(np.float16)
+        kc[:, start + S:] = np.nan  # rows past the context must never be read as data
+        vc[:, start + S:] = np.nan
+        scale = HD ** -0.5
+        for h in range(Hq):
+            kvh = h // (Hq // Hkv)
+            ref = reference(q, kc, vc, 0, h, kvh, start, S, scale, softcap, slope)
+            got = np.full((S, HD), np.nan)
+            for qb in range((S + BQ - 1) // BQ):
+                for (row, d), val in run_block(q, kc, vc, 0, h, kvh, qb, start, S, scale, softcap, slope).items():
+                    assert np.isnan(got[row, d]), "an output element stored twice"
+                    got[row, d] = val
+            err = np.abs(got - ref).max()
+            ok = bool(np.isfinite(got).all()) and err < 4e-3
+            bad += not ok
+            print(f"S={S} start={start} Hq={Hq} Hkv={Hkv} cap={softcap} slope={slope} head {h}: max err {err:.3g} {'ok' if ok else 'MISMATCH'}")
+    print("FAILED" if bad else "ALL OK")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
