@@ -5,6 +5,11 @@
 // is the natural K pair: v_perm_b32 + ONE v_and_or (mask 0x00F0000F, exponents 2^10 | 2^6), (t - (bias + z)) * s exact; the A
 // side reads chunk 2 kb + kk.  Purpose: batches of 17 ... 64 rows on WQLinear_GEMV without a GEMM-layout copy of the weights
 // (today: 16-row chunks of the decode kernels, 47 / 93 us at 4096 x 11008 for M = 32 / 64; the GEMM-layout form: 14 / 18 us).
+// MODE 2 ("wide", K % 256 == 0): the same N-major form with 256-wide steps -- lane (j, kb) reads 32 contiguous bytes (words 8 kb ..
+// 8 kb + 7 of the step: two dwordx4) of each of its four weight rows, so a row's 128 bytes are one full line per wave
+// instruction pair instead of four 32-byte visits (what held csrc/gemm_regb.hip's N-major form at 0.29 of the MFMA peak:
+// profiles/r04_pmc_mfma_prefill.txt); MFMA sub-step w of the step uses word w against x chunk w of 64-wide step 4 ws + kb
+// (a lane-dependent LDS step offset); 16 instead of 48 vector-memory operations per 256 k; two steps in flight.
 // Next round: run tools/experimental/gemm_skinny_nk/probe.py on the GPU; if it is green, merge the flag into csrc/gemm_skinny.hip
 // and route awq_gemv_forward (17 <= M <= 64) to it.
 //
@@ -85,17 +90,26 @@ struct SkinnyParams {
                  : "=v"(Z[0]), "=v"(Z[1]), "=v"(Z[2]), "=v"(Z[3]), "=v"(S[0]), "=v"(S[1]), "=v"(S[2]), "=v"(S[3])               \
                  : "v"(zvo), "s"(zrs), "s"(zso[0]), "s"(zso[1]), "s"(zso[2]), "s"(zso[3]), "v"(svo), "s"(srs), "s"(sso[0]),       \
                    "s"(sso[1]), "s"(sso[2]), "s"(sso[3]))
+#define AWQ_SK_BLOADW8(W, vo, rs, so)                                                                                           \
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %8, %9, %10 offen\n\tbuffer_load_dwordx4 %1, %8, %9, %10 offen offset:16\n\t"   \
+                 "buffer_load_dwordx4 %2, %8, %9, %11 offen\n\tbuffer_load_dwordx4 %3, %8, %9, %11 offen offset:16\n\t"             \
+                 "buffer_load_dwordx4 %4, %8, %9, %12 offen\n\tbuffer_load_dwordx4 %5, %8, %9, %12 offen offset:16\n\t"             \
+                 "buffer_load_dwordx4 %6, %8, %9, %13 offen\n\tbuffer_load_dwordx4 %7, %8, %9, %13 offen offset:16"                  \
+                 : "=v"(W[0][0]), "=v"(W[0][1]), "=v"(W[1][0]), "=v"(W[1][1]), "=v"(W[2][0]), "=v"(W[2][1]), "=v"(W[3][0]),     \
+                   "=v"(W[3][1])                                                                                                \
+                 : "v"(vo), "s"(rs), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]))
 #define AWQ_SK_DMA16(ldsaddr, voff, rs, soff)                                                                  \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsaddr), "v"(voff), \
                  "s"(rs), "s"(soff)                                                                             \
                  : "m0")
 #define AWQ_SK_LDS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
-template <int MI, bool NK>  // 16-row tiles per block: BM = 16 * MI (32 | 64); NK: the GEMV layout's buffers (header)
+template <int MI, int MODE>  // 16-row tiles per block: BM = 16 * MI (32 | 64); MODE 0: GEMM layout, 1 / 2: the GEMV layout's buffers (header)
 __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p) {
+    constexpr bool WIDE = MODE == 2, NK = MODE == 1, NMAJOR = MODE != 0;
     constexpr int BM = 16 * MI;
     constexpr int A_STEP = BM * 128;  // bytes of one 64-wide activation step in LDS
     constexpr int PER = MI * 4;       // 16-byte accumulator chunks per lane
-    constexpr int B_OPS = NK ? 12 : 18;  // vector-memory operations of one weight fetch
+    constexpr int B_OPS = WIDE ? 16 : NK ? 12 : 18;  // vector-memory operations of one weight fetch
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [sps][BM][8 chunks]; later the K-half fold area
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -107,17 +121,18 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
     const int NW = p.N >> 3;
     const int T = p.K >> 6;
     const int st0 = slice * p.sps, nst = min(p.sps, T - st0);  // this block's 64-row steps: [st0, st0 + nst)
-    const int half0 = (nst + 1) >> 1;                          // the first K half takes the odd step
-    const int w0 = kh ? half0 : 0, w1 = kh ? nst : half0;       // this wave's steps, relative to st0
+    const int nunits = WIDE ? nst >> 2 : nst;                  // WIDE: units of four steps (the launcher keeps st0 and nst multiples of 4)
+    const int half0 = (nunits + 1) >> 1;                       // the first K half takes the odd unit
+    const int w0 = kh ? half0 : 0, w1 = kh ? nunits : half0;    // this wave's units, relative to st0
 
     auto srd = [](const void* base, uint32_t bytes) -> u32x4 {
         const uint64_t a = reinterpret_cast<uint64_t>(base);
         return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
     };
     const uint32_t row_bytes = (uint32_t)NW * 4u;
-    const u32x4 wsrd = srd(p.qweight, NK ? (uint32_t)p.N * (uint32_t)p.KW * 4u : (uint32_t)p.K * row_bytes);
-    const u32x4 zsrd = srd(p.qzeros, NK ? (uint32_t)p.N * (uint32_t)p.ZW * 4u : (uint32_t)(p.K / p.g) * row_bytes);
-    const u32x4 ssrd = srd(p.scales, NK ? (uint32_t)p.N * (uint32_t)p.SW * 2u : (uint32_t)(p.K / p.g) * (uint32_t)p.N * 2u);
+    const u32x4 wsrd = srd(p.qweight, NMAJOR ? (uint32_t)p.N * (uint32_t)p.KW * 4u : (uint32_t)p.K * row_bytes);
+    const u32x4 zsrd = srd(p.qzeros, NMAJOR ? (uint32_t)p.N * (uint32_t)p.ZW * 4u : (uint32_t)(p.K / p.g) * row_bytes);
+    const u32x4 ssrd = srd(p.scales, NMAJOR ? (uint32_t)p.N * (uint32_t)p.SW * 2u : (uint32_t)(p.K / p.g) * (uint32_t)p.N * 2u);
     const u32x4 xsrd = srd(p.x, (uint32_t)((int64_t)p.M * p.K * 2));
 
     // ---- activations of the whole K slice -> LDS, once (piece q: step q / (BM/8), rows 8 (q % (BM/8)) .. + 7)
@@ -144,9 +159,9 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
     // NK form: ONE lane offset per tensor (the row of column ncol0), the row of column c through the scalar offset; rows past N
     // lie outside the descriptors (bounds-checked loads return 0) and are never stored
     const int ncol0 = n0 + cw * 64 + 4 * j;
-    const uint32_t nk_w = NK ? (uint32_t)ncol0 * (uint32_t)p.KW * 4u + 8u * (uint32_t)kb : 0u;
-    const uint32_t nk_z = NK ? (uint32_t)ncol0 * (uint32_t)p.ZW * 4u : 0u;
-    const uint32_t nk_s = NK ? (uint32_t)ncol0 * (uint32_t)p.SW * 2u : 0u;
+    const uint32_t nk_w = NMAJOR ? (uint32_t)ncol0 * (uint32_t)p.KW * 4u + (WIDE ? 32u : 8u) * (uint32_t)kb : 0u;
+    const uint32_t nk_z = NMAJOR ? (uint32_t)ncol0 * (uint32_t)p.ZW * 4u : 0u;
+    const uint32_t nk_s = NMAJOR ? (uint32_t)ncol0 * (uint32_t)p.SW * 2u : 0u;
     struct BRegsKN {
         uint32_t w[2][8];
         uint32_t z;
@@ -158,10 +173,22 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
         uint32_t s[4];   // the scale of (column c, group) in bits 0-15
         uint32_t zsh;    // 4 * (group & 7), uniform
     };
-    using BRegs = std::conditional_t<NK, BRegsNK, BRegsKN>;
+    struct BRegsWide {
+        u32x4 w[4][2];   // column c: words 8 kb .. 8 kb + 7 of this 256-wide step (k = 64 kb + 8 word + i)
+        uint32_t z[4];   // the zero word of (column c, this LANE's group)
+        uint32_t s[4];   // the scale of (column c, this lane's group) in bits 0-15
+        uint32_t zsh;    // 4 * (group & 7), per lane
+    };
+    using BRegs = std::conditional_t<WIDE, BRegsWide, std::conditional_t<NK, BRegsNK, BRegsKN>>;
     auto wait_b = [&](BRegs& R, auto newer_c) __attribute__((always_inline)) {
         constexpr int NEWER = decltype(newer_c)::value;
-        if constexpr (NK) {
+        if constexpr (WIDE) {
+            asm volatile("s_waitcnt vmcnt(%16)"
+                         : "+v"(R.w[0][0]), "+v"(R.w[0][1]), "+v"(R.w[1][0]), "+v"(R.w[1][1]), "+v"(R.w[2][0]), "+v"(R.w[2][1]),
+                           "+v"(R.w[3][0]), "+v"(R.w[3][1]), "+v"(R.z[0]), "+v"(R.z[1]), "+v"(R.z[2]), "+v"(R.z[3]), "+v"(R.s[0]),
+                           "+v"(R.s[1]), "+v"(R.s[2]), "+v"(R.s[3])
+                         : "n"(NEWER));
+        } else if constexpr (NK) {
             asm volatile("s_waitcnt vmcnt(%12)"
                          : "+v"(R.w[0]), "+v"(R.w[1]), "+v"(R.w[2]), "+v"(R.w[3]), "+v"(R.z[0]), "+v"(R.z[1]), "+v"(R.z[2]), "+v"(R.z[3]),
                            "+v"(R.s[0]), "+v"(R.s[1]), "+v"(R.s[2]), "+v"(R.s[3])
@@ -176,6 +203,21 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
     };
 #define AWQ_SK_WAIT_B(R, newer) wait_b(R, std::integral_constant<int, (newer)>{})
     auto fetch_b = [&](BRegs& R, int st) {  // st relative to st0; past the wave's range: the last step again (static counts)
+        if constexpr (WIDE) {  // st = unit index: k of the unit, this lane's 64-wide part of it and its group
+            const uint32_t K0 = (uint32_t)st0 * 64u + (uint32_t)min(st, max(w1 - 1, w0)) * 256u;
+            const uint32_t grp = __umulhi(K0 + 64u * (uint32_t)kb, p.g_magic);
+            uint32_t so_w[4], so_z[4], so_s[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                so_w[c] = (K0 >> 1) + (uint32_t)c * (uint32_t)p.KW * 4u;
+                so_z[c] = (uint32_t)c * (uint32_t)p.ZW * 4u;
+                so_s[c] = (uint32_t)c * (uint32_t)p.SW * 2u;
+            }
+            AWQ_SK_BLOADW8(R.w, nk_w, wsrd, so_w);
+            const uint32_t zvo = nk_z + (grp >> 3) * 4u, svo = nk_s + grp * 2u;
+            AWQ_SK_BLOADZS4(R.z, R.s, zvo, zsrd, so_z, svo, ssrd, so_s);
+            R.zsh = 4u * (grp & 7u);
+        } else {
         const uint32_t k0 = (uint32_t)(st0 + min(st, max(w1 - 1, w0))) * 64u;
         if constexpr (NK) {
             const uint32_t grp = __umulhi(k0, p.g_magic);
@@ -202,12 +244,13 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
         const uint32_t zo = grp * row_bytes, so2 = grp * (uint32_t)p.N * 2u;
         AWQ_SK_BLOADZS(R.z, R.s, z_voff, zsrd, zo, s_voff, ssrd, so2);
         }
+        }
     };
     BRegs B0, B1, B2;
     fetch_b(B0, w0);
     fetch_b(B1, w0 + 1);
-    fetch_b(B2, w0 + 2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * B_OPS) : "memory");  // everything older than the three weight fetches: the DMA pieces
+    if constexpr (!WIDE) fetch_b(B2, w0 + 2);  // (WIDE: two units of 256 in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WIDE ? 2 : 3) * B_OPS) : "memory");  // everything older than the three weight fetches: the DMA pieces
     __builtin_amdgcn_s_barrier();
 
     float4_t acc[MI][4];
@@ -222,6 +265,42 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
 
     auto compute = [&](BRegs& R, int st) {
         half2_t zm[4], sd[4];
+        if constexpr (WIDE) {  // st = unit index; sub-step w: word w of every column against x chunk w of 64-wide step 4 st + kb
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t z = (R.z[c] >> R.zsh) & 15u;
+                zm[c] = u2h2(0x54006400u | z | (z << 20));
+                sd[c] = u2h2(__builtin_amdgcn_perm(R.s[c], R.s[c], 0x01000100u));
+            }
+            const uint32_t a_unit = a_base + (uint32_t)((4 * st + kb) * A_STEP);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const uint32_t aa = a_unit + (uint32_t)((w ^ hl) << 4);
+                u32x4v af[MI];
+                AWQ_SK_LDS_READ16(af[0], aa, 0);
+                AWQ_SK_LDS_READ16(af[1], aa, 2048);
+                if constexpr (MI > 2) {
+                    AWQ_SK_LDS_READ16(af[2], aa, 4096);
+                    AWQ_SK_LDS_READ16(af[3], aa, 6144);
+                }
+                u32x4v bf[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t word = R.w[c][w >> 2][w & 3];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t pb = __builtin_amdgcn_perm(word, word, 0x0C000C00u | (uint32_t)b | ((uint32_t)b << 16));
+                        bf[c][b] = h22u((u2h2(and_or(pb, 0x00F0000Fu, 0x54006400u)) - zm[c]) * sd[c]);
+                    }
+                }
+                if constexpr (MI > 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[i][c] = mfma16(af[i], bf[c], acc[i][c]);
+            }
+        } else {
         if constexpr (NK) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -279,11 +358,22 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[i][c] = mfma16(af[i], bf[c], acc[i][c]);
         }
+        }
     };
 
     // ---- K loop, no barrier: wait for a step's words (the two younger fetches stay in flight), multiply, refill
     int st = w0;
-    for (; st + 3 <= w1; st += 3) {
+    if constexpr (WIDE) {
+        for (; st + 2 <= w1; st += 2) {
+            AWQ_SK_WAIT_B(B0, B_OPS); compute(B0, st);     fetch_b(B0, st + 2);
+            AWQ_SK_WAIT_B(B1, B_OPS); compute(B1, st + 1); fetch_b(B1, st + 3);
+        }
+        AWQ_SK_WAIT_B(B0, 0);  // (names both register sets: see the comment below)
+        AWQ_SK_WAIT_B(B1, 0);
+        if (st < w1) compute(B0, st);
+        st = w1;
+    }
+    for (; !WIDE && st + 3 <= w1; st += 3) {
         AWQ_SK_WAIT_B(B0, 2 * B_OPS); compute(B0, st);     fetch_b(B0, st + 3);
         AWQ_SK_WAIT_B(B1, 2 * B_OPS); compute(B1, st + 1); fetch_b(B1, st + 4);
         AWQ_SK_WAIT_B(B2, 2 * B_OPS); compute(B2, st + 2); fetch_b(B2, st + 5);
@@ -292,11 +382,13 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
     // requested, so it would hand them to the temporaries of the steps below while the loads are still in flight -- and a
     // late load then overwrites a live value.  One wait that NAMES all three register sets keeps them allocated until
     // everything has landed; the (at most two) remaining steps then need no wait of their own.
-    AWQ_SK_WAIT_B(B0, 0);
-    AWQ_SK_WAIT_B(B1, 0);
-    AWQ_SK_WAIT_B(B2, 0);
-    if (st < w1) compute(B0, st);
-    if (st + 1 < w1) compute(B1, st + 1);
+    if constexpr (!WIDE) {
+        AWQ_SK_WAIT_B(B0, 0);
+        AWQ_SK_WAIT_B(B1, 0);
+        AWQ_SK_WAIT_B(B2, 0);
+        if (st < w1) compute(B0, st);
+        if (st + 1 < w1) compute(B1, st + 1);
+    }
 
     // ---- fold the two K halves through LDS (the activation area is dead once every wave is past its K loop)
     __syncthreads();
@@ -389,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
     }
 
     // ---- epilogue: lane (j, kb) holds rows 16 i + 4 kb + e, columns 8 j + 4 ph + c of its wave's 128 columns
-    const int col = NK ? ncol0 : n0 + set * 128 + 8 * j + 4 * ph;  // NK: four consecutive columns per lane as well
+    const int col = NMAJOR ? ncol0 : n0 + set * 128 + 8 * j + 4 * ph;  // NK: four consecutive columns per lane as well
     if (col >= p.N) return;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -414,11 +506,11 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
     }
 }
 
-template <int MI, bool NK>
+template <int MI, int MODE>
 int launch_skinny(const SkinnyParams& p, dim3 grid, size_t lds, hipStream_t st) {
     static std::atomic<unsigned long long> opted{0};
-    (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_skinny_kernel<MI, NK>), opted);
-    hipLaunchKernelGGL((awq_gemm_skinny_kernel<MI, NK>), grid, dim3(512), lds, st, p);
+    (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_skinny_kernel<MI, MODE>), opted);
+    hipLaunchKernelGGL((awq_gemm_skinny_kernel<MI, MODE>), grid, dim3(512), lds, st, p);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
@@ -426,7 +518,8 @@ int launch_skinny(const SkinnyParams& p, dim3 grid, size_t lds, hipStream_t st) 
 
 // The experimental entry point (tools/experimental/gemm_skinny_nk/probe.py): x [M, K] fp16, GEMV-layout buffers, y [M, N];
 // workspace = a split-K workspace of libawq_hip.so (awq_gemm_workspace_bytes / _init: control words + sentinel-filled exchange).
-// nk = 0 runs the ORIGINAL form on GEMM-layout buffers (a check that the copy of the kernel still is the kernel).
+// nk = 0 runs the ORIGINAL form on GEMM-layout buffers (a check that the copy of the kernel still is the kernel), 1 the N-major
+// form with 64-wide steps, 2 the wide form (K % 256 == 0).
 extern "C" __attribute__((visibility("default"))) int awq_exp_gemm_skinny(const uint16_t* x, const int32_t* qweight, const uint16_t* scales,
                                                                           const int32_t* qzeros, uint16_t* y, int M, int K, int N, int g, int ZW,
                                                                           int nk, int splitk, void* workspace, size_t workspace_bytes,
@@ -436,6 +529,7 @@ extern "C" __attribute__((visibility("default"))) int awq_exp_gemm_skinny(const 
           awq_magic_u32((uint32_t)g, (uint32_t)K + 64u, &magic)))
         return AWQ_ERR_UNSUPPORTED;
     if ((int64_t)(M > 32 ? 4 : 2) * ((N + 255) / 256) > 256) return AWQ_ERR_UNSUPPORTED;
+    if (nk < 0 || nk > 2 || (nk == 2 && K % 256)) return AWQ_ERR_UNSUPPORTED;
     const int MI = M <= 32 ? 2 : 4, BM = 16 * MI, R = MI >= 4 ? 4 : 2;
     const int tiles = (N + 255) / 256, T = K / 64;
     const size_t tile_bytes = (size_t)4 * MI * 4 * 1024;
@@ -449,10 +543,15 @@ extern "C" __attribute__((visibility("default"))) int awq_exp_gemm_skinny(const 
     int sps = (T + S - 1) / S;
     const int sps_max = (128 * 1024) / (BM * 128);
     if (sps > sps_max) sps = sps_max;
+    if (nk == 2) {  // whole units of four steps per slice (sps_max is a multiple of 4)
+        sps = (sps + 3) & ~3;
+        if (sps > sps_max) sps = sps_max;
+    }
     S = (T + sps - 1) / sps;
     if (S > 1 && S < R) {
         if (T / 2 >= R) {
             sps = (T + R - 1) / R;
+            if (nk == 2) sps = (sps + 3) & ~3;
             S = (T + sps - 1) / sps;
         }
         if (S < R) {
@@ -482,6 +581,7 @@ extern "C" __attribute__((visibility("default"))) int awq_exp_gemm_skinny(const 
     if (S > 1 && R * tiles > 256 * (lds <= 80 * 1024 ? 2 : 1)) return AWQ_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles, (unsigned)S, 1u);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (nk) return MI == 2 ? launch_skinny<2, true>(p, grid, lds, st) : launch_skinny<4, true>(p, grid, lds, st);
-    return MI == 2 ? launch_skinny<2, false>(p, grid, lds, st) : launch_skinny<4, false>(p, grid, lds, st);
+    if (nk == 2) return MI == 2 ? launch_skinny<2, 2>(p, grid, lds, st) : launch_skinny<4, 2>(p, grid, lds, st);
+    if (nk == 1) return MI == 2 ? launch_skinny<2, 1>(p, grid, lds, st) : launch_skinny<4, 1>(p, grid, lds, st);
+    return MI == 2 ? launch_skinny<2, 0>(p, grid, lds, st) : launch_skinny<4, 0>(p, grid, lds, st);
 }

@@ -53,12 +53,12 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     bad = 0
 
-    def run(x, qw, sc, qz, g, splitk=0):
+    def run(x, qw, sc, qz, g, splitk=0, mode=1):
         M, K = x.shape
         N = qw.shape[0]
         y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
         ws = ops.workspace(dev, 64 << 20)
-        rc = fn(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), y.data_ptr(), M, K, N, g, qz.shape[1], 1, splitk,
+        rc = fn(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), y.data_ptr(), M, K, N, g, qz.shape[1], mode, splitk,
                 ws.data_ptr(), ws.numel(), stream)
         return rc, y
 
@@ -67,12 +67,12 @@ def main():
     for K, N, g in shapes:
         qw, qz, sc = random_gemv_layer(K, N, g, dev, seed=K + N + g)
         wt = ops.dequantize_weights_gemv(qw, sc, qz, g).float()  # [N, K], bit-exact vs the oracle (tests/test_gpu_parity.py)
-        for M in (9, 16, 17, 31, 32, 33, 48, 64):
-            for splitk in (0, 1):
+        for M, splitk, mode in [(M, sk, md) for M in (9, 16, 17, 31, 32, 33, 48, 64) for sk in (0, 1) for md in (1, 2)]:
+            if True:
                 x = (torch.randn((M, K), generator=torch.Generator().manual_seed(M), dtype=torch.float32) * 0.5).to(torch.float16).to(dev)
-                rc, y = run(x, qw, sc, qz, g, splitk)
+                rc, y = run(x, qw, sc, qz, g, splitk, mode)
                 if rc != 0:
-                    print(f"K={K} N={N} g={g} M={M} splitk={splitk}: rc={rc} (declined)")
+                    print(f"K={K} N={N} g={g} M={M} splitk={splitk} mode={mode}: rc={rc} (declined)")
                     continue
                 ref = x.float() @ wt.t()
                 # fp32 accumulation of exact fp16 products, one rounding to fp16 at the end: half an ulp of the result + slack
@@ -80,10 +80,10 @@ def main():
                 tol = ref.abs() * 2.0**-10 + 2e-2
                 ok = bool((err <= tol).all()) and bool(torch.isfinite(y).all())
                 bad += not ok
-                print(f"K={K} N={N} g={g} M={M} splitk={splitk}: max err {float(err.max()):.4g} "
+                print(f"K={K} N={N} g={g} M={M} splitk={splitk} mode={mode}: max err {float(err.max()):.4g} "
                       f"(max |ref| {float(ref.abs().max()):.4g}) {'ok' if ok else 'MISMATCH'}")
                 # run-to-run: the combine order is fixed, two launches must agree bit for bit
-                rc2, y2 = run(x, qw, sc, qz, g, splitk)
+                rc2, y2 = run(x, qw, sc, qz, g, splitk, mode)
                 if rc2 == 0 and not torch.equal(y, y2):
                     bad += 1
                     print("   NOT reproducible run to run")
@@ -95,7 +95,8 @@ def main():
     qw, qz, sc = random_gemv_layer(K, N, g, dev, seed=1)
     for M in (17, 32, 64):
         x = torch.randn((M, K), dtype=torch.float16, device=dev)
-        for name, call in (("skinny_nk", lambda: run(x, qw, sc, qz, g)),
+        for name, call in (("skinny_nk (64-wide steps)", lambda: run(x, qw, sc, qz, g, 0, 1)),
+                           ("skinny_nk wide (256-wide steps)", lambda: run(x, qw, sc, qz, g, 0, 2)),
                            ("today (16-row chunks)", lambda: ops.gemv_forward(x, qw, sc, qz, g))):
             for _ in range(20):
                 call()
