@@ -89,25 +89,33 @@ def main():
                     print("   NOT reproducible run to run")
     ops.check_workspaces()
 
-    # timing, the shape of bench.py's gemm_bs leg
-    from autoawq_amd.modules.linear import WQLinear_GEMV
+    # timing inside a hipGraph (bench.graph_time), the shape of bench.py's gemm_bs leg; cold weights: 16 distinct matrices per replay
+    import bench
     K, N, g = 4096, 11008, 128
-    qw, qz, sc = random_gemv_layer(K, N, g, dev, seed=1)
-    for M in (17, 32, 64):
+    mats = [random_gemv_layer(K, N, g, dev, seed=100 + i) for i in range(16)]
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        ws = ops.workspace(dev, 64 << 20)
+    for M in (16, 17, 32, 64):
         x = torch.randn((M, K), dtype=torch.float16, device=dev)
-        for name, call in (("skinny_nk (64-wide steps)", lambda: run(x, qw, sc, qz, g, 0, 1)),
-                           ("skinny_nk wide (256-wide steps)", lambda: run(x, qw, sc, qz, g, 0, 2)),
-                           ("today (16-row chunks)", lambda: ops.gemv_forward(x, qw, sc, qz, g))):
-            for _ in range(20):
-                call()
-            torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(200):
-                call()
-            b.record()
-            torch.cuda.synchronize()
-            print(f"M={M} {name}: {a.elapsed_time(b) * 5:.1f} us")
+        y = torch.empty((M, N), dtype=torch.float16, device=dev)
+
+        def exp(mode):
+            def f():
+                cur = torch.cuda.current_stream().cuda_stream
+                for qw, qz, sc in mats:
+                    rc = fn(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), y.data_ptr(), M, K, N, g, qz.shape[1], mode, 0,
+                            ws.data_ptr(), ws.numel(), cur)
+                    assert rc == 0, rc
+            return f
+
+        def today():
+            for qw, qz, sc in mats:
+                ops.gemv_forward(x, qw, sc, qz, g)
+
+        for name, f in (("skinny_nk (64-wide steps)", exp(1)), ("skinny_nk wide (256-wide steps)", exp(2)), ("today (gemv_forward)", today)):
+            us = bench.graph_time(f, st, reps=20, min_seconds=0.2) / len(mats)
+            print(f"M={M} {name}: {us:.1f} us per matrix ({bench.algorithmic_bytes(K, N, M, g) / us / 1e3:.0f} GB/s algorithmic)")
     print("FAILED" if bad else "ALL OK")
     return 1 if bad else 0
 
