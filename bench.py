@@ -627,6 +627,8 @@ def main():
                     print(f"[bench] {capture_note}", file=sys.stderr)
                 graph = None
         step = graph.replay if graph is not None else (lambda: run_step(model, outs, ops, allreduce))
+        if dist is not None:
+            dist.barrier()  # ranks leave the capture together: the one-shot all-reduce waits a bounded time (~1 s) for a peer
         for _ in range(a.warmup):
             step()
         stream.synchronize()
