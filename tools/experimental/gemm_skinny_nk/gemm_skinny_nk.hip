@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
                 const uint32_t aa = a_unit + (uint32_t)((w ^ hl) << 4);
                 u32x4v af[MI];
                 AWQ_SK_LDS_READ16(af[0], aa, 0);
-                AWQ_SK_LDS_READ16(af[1], aa, 2048);
+                if constexpr (MI > 1) AWQ_SK_LDS_READ16(af[1], aa, 2048);
                 if constexpr (MI > 2) {
                     AWQ_SK_LDS_READ16(af[2], aa, 4096);
                     AWQ_SK_LDS_READ16(af[3], aa, 6144);
@@ -294,7 +294,8 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
                     }
                 }
                 if constexpr (MI > 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]));
+                else if constexpr (MI > 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]));
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
             const uint32_t aa = a_base + (uint32_t)(st * A_STEP) + (uint32_t)((((NK ? 2 * kb + kk : 4 * kk + kb)) ^ hl) << 4);
             u32x4v af[MI];
             AWQ_SK_LDS_READ16(af[0], aa, 0);
-            AWQ_SK_LDS_READ16(af[1], aa, 2048);
+            if constexpr (MI > 1) AWQ_SK_LDS_READ16(af[1], aa, 2048);
             if constexpr (MI > 2) {
                 AWQ_SK_LDS_READ16(af[2], aa, 4096);
                 AWQ_SK_LDS_READ16(af[3], aa, 6144);
@@ -352,7 +353,8 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
                 bf[3][rp] = h22u((u2h2(and_or(p1, 0x00F000F0u, 0x54005400u)) - zm[3]) * sd[3]);
             }
             if constexpr (MI > 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]));
+            else if constexpr (MI > 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
     if (S > 1) {
         constexpr uint32_t SENT = 0xFFFFFFFFu, QNAN = 0x7FC00000u;
         constexpr uint32_t TILE_BYTES = 4u * PER * 1024u;
-        constexpr int R = MI >= 4 ? 4 : 2;  // launcher guarantees S >= R
+        constexpr int R = MI >= 4 ? 4 : MI >= 2 ? 2 : 1;  // launcher guarantees S >= R (MI = 1, experimental: one reducer)
         const rsrc_t slres = mk_rsrc(p.slabs, (uint32_t)S * (uint32_t)tiles * TILE_BYTES);
         const uint32_t lane_off = (uint32_t)cw * (PER * 1024u) + (uint32_t)lane * 16u;
         const int ridx = slice - (S - R);  // >= 0: a reducer
@@ -489,10 +491,10 @@ __global__ __launch_bounds__(512, 2) void awq_gemm_skinny_kernel(SkinnyParams p)
 #pragma unroll
         for (int c = 0; c < 4; ++c) b4[c] = (float)bv[c];
     }
-    const int ridx = S > 1 ? slice - (S - (MI >= 4 ? 4 : 2)) : -1;
+    const int ridx = S > 1 ? slice - (S - (MI >= 4 ? 4 : MI >= 2 ? 2 : 1)) : -1;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        if (S > 1 && (i % (MI >= 4 ? 4 : 2)) != ridx) continue;  // another reducer writes this row tile
+        if (S > 1 && (i % (MI >= 4 ? 4 : MI >= 2 ? 2 : 1)) != ridx) continue;  // another reducer writes this row tile
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = 16 * i + 4 * kb + e;
@@ -525,16 +527,18 @@ extern "C" __attribute__((visibility("default"))) int awq_exp_gemm_skinny(const 
                                                                           int nk, int splitk, void* workspace, size_t workspace_bytes,
                                                                           void* stream) {
     uint32_t magic;
-    if (!(M >= 9 && M <= 64 && K >= 128 && K % 64 == 0 && g % 64 == 0 && K % g == 0 && N % 8 == 0 && K < 65536 &&
+    if (!(M >= 1 && M <= 64 && K >= 128 && K % 64 == 0 && g % 64 == 0 && K % g == 0 && N % 8 == 0 && K < 65536 &&
           awq_magic_u32((uint32_t)g, (uint32_t)K + 64u, &magic)))
         return AWQ_ERR_UNSUPPORTED;
     if ((int64_t)(M > 32 ? 4 : 2) * ((N + 255) / 256) > 256) return AWQ_ERR_UNSUPPORTED;
     if (nk < 0 || nk > 2 || (nk == 2 && K % 256)) return AWQ_ERR_UNSUPPORTED;
-    const int MI = M <= 32 ? 2 : 4, BM = 16 * MI, R = MI >= 4 ? 4 : 2;
+    // (MI = 1 -- one 16-row tile, batches up to 16 -- exists in this experimental copy only, for the N-major forms)
+    const int MI = (M <= 16 && nk) ? 1 : M <= 32 ? 2 : 4, BM = 16 * MI, R = MI >= 4 ? 4 : MI >= 2 ? 2 : 1;
     const int tiles = (N + 255) / 256, T = K / 64;
     const size_t tile_bytes = (size_t)4 * MI * 4 * 1024;
     int S = splitk > 0 ? splitk : (tiles >= 32 ? 4 : K / 512);
     if (splitk <= 0) {
+        if (MI == 1) S = (512 + tiles - 1) / tiles;  // a 16-row block is light: at least ~512 blocks
         if (S < 4) S = 4;
         if (S > 16) S = 16;
     }
@@ -581,7 +585,7 @@ extern "C" __attribute__((visibility("default"))) int awq_exp_gemm_skinny(const 
     if (S > 1 && R * tiles > 256 * (lds <= 80 * 1024 ? 2 : 1)) return AWQ_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles, (unsigned)S, 1u);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (nk == 2) return MI == 2 ? launch_skinny<2, 2>(p, grid, lds, st) : launch_skinny<4, 2>(p, grid, lds, st);
-    if (nk == 1) return MI == 2 ? launch_skinny<2, 1>(p, grid, lds, st) : launch_skinny<4, 1>(p, grid, lds, st);
+    if (nk == 2) return MI == 1 ? launch_skinny<1, 2>(p, grid, lds, st) : MI == 2 ? launch_skinny<2, 2>(p, grid, lds, st) : launch_skinny<4, 2>(p, grid, lds, st);
+    if (nk == 1) return MI == 1 ? launch_skinny<1, 1>(p, grid, lds, st) : MI == 2 ? launch_skinny<2, 1>(p, grid, lds, st) : launch_skinny<4, 1>(p, grid, lds, st);
     return MI == 2 ? launch_skinny<2, 0>(p, grid, lds, st) : launch_skinny<4, 0>(p, grid, lds, st);
 }

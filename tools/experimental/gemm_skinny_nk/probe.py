@@ -67,7 +67,7 @@ def main():
     for K, N, g in shapes:
         qw, qz, sc = random_gemv_layer(K, N, g, dev, seed=K + N + g)
         wt = ops.dequantize_weights_gemv(qw, sc, qz, g).float()  # [N, K], bit-exact vs the oracle (tests/test_gpu_parity.py)
-        for M, splitk, mode in [(M, sk, md) for M in (9, 16, 17, 31, 32, 33, 48, 64) for sk in (0, 1) for md in (1, 2)]:
+        for M, splitk, mode in [(M, sk, md) for M in (1, 5, 8, 9, 16, 17, 31, 32, 33, 48, 64) for sk in (0, 1) for md in (1, 2)]:
             if True:
                 x = (torch.randn((M, K), generator=torch.Generator().manual_seed(M), dtype=torch.float32) * 0.5).to(torch.float16).to(dev)
                 rc, y = run(x, qw, sc, qz, g, splitk, mode)
@@ -96,7 +96,7 @@ def main():
     st = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(st):
         ws = ops.workspace(dev, 64 << 20)
-    for M in (16, 17, 32, 64):
+    for M in (8, 16, 17, 32, 64):  # (M <= 16: the experimental one-tile instantiation; today = gemv_lds / gemv_nk)
         x = torch.randn((M, K), dtype=torch.float16, device=dev)
         y = torch.empty((M, N), dtype=torch.float16, device=dev)
 
