@@ -6,7 +6,7 @@
 //
 // Shapes: q / out [B, S, Hq, 128] fp16 (after RoPE), caches [Bc, Tmax, Hkv, 128] fp16 already holding rows 0 .. start + S - 1;
 // query row s sees cache rows <= start + s.  One block = 128 query rows of one head, four waves of 32 rows; the KV rows are
-// walked in tiles of 64 through LDS (two buffers, one barrier per tile, the next tile's global loads issued before the math).
+// walked in tiles of 64 through LDS (two buffers, one barrier per tile, global loads requested a whole iteration ahead).
 //
 // MFMA mapping (v_mfma_f32_16x16x32_f16: A lane (j, kb) = row j, k 8 kb .. 8 kb + 7; B the same with column j; C lane (j, kb),
 // e = row 4 kb + e, column j -- the layouts every GEMM kernel of csrc/ uses):
@@ -98,19 +98,20 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
     // ---- tile staging: K thread (row tid / 16 + 16 i, chunk tid % 16); V thread (rows 4 (tid / 16) + r, d block tid % 16)
     const int sc = tid & 15, sr = tid >> 4;
     const uint32_t kv_col = (uint32_t)kvh * (HD * 2u) + 16u * (uint32_t)sc;
-    // ONE register set stages both tensors: K of the next tile is in flight under S^T = K Q^T, V under the softmax and O += P V
-    // (the other LDS buffer is free for the whole iteration: every wave left it at the previous barrier)
-    u32x4v stage[4];
+    // Two register sets, each requested a whole iteration before it is written to LDS: at the top of iteration `it` the K rows of
+    // tile it + 1 (requested at the top of it - 1) go to the other LDS buffer -- free since the previous barrier -- and tile it + 2 is
+    // requested; the V rows likewise after S^T = K Q^T.
+    u32x4v kst[4], vst[4];
     auto load_k = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            stage[i] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+            kst[i] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(
                                                       kres, (uint32_t)(kv0 + sr + 16 * i) * kv_row_bytes + kv_col, 0, 0));
     };
     auto load_v = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            stage[i] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+            vst[i] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(
                                                       vres, (uint32_t)(kv0 + 4 * sr + i) * kv_row_bytes + kv_col, 0, 0));
     };
     // (LDS addresses are recomputed from lane coordinates made opaque once per iteration: left loop-invariant, the compiler
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = sr + 16 * i;
-            *reinterpret_cast<u32x4v*>(ks_ + r * 256 + 16 * (sc ^ (r & 15))) = stage[i];
+            *reinterpret_cast<u32x4v*>(ks_ + r * 256 + 16 * (sc ^ (r & 15))) = kst[i];
         }
     };
     auto write_v = [&](int buf, int sc, int sr) {
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
         for (int i = 0; i < 8; ++i) {  // d = 8 sc + i: the four KV rows 4 sr .. 4 sr + 3 of that column, one 8-byte chunk
             const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;
             u32x2 t;
-            t[0] = __builtin_amdgcn_perm(stage[1][i >> 1], stage[0][i >> 1], sel);
-            t[1] = __builtin_amdgcn_perm(stage[3][i >> 1], stage[2][i >> 1], sel);
+            t[0] = __builtin_amdgcn_perm(vst[1][i >> 1], vst[0][i >> 1], sel);
+            t[1] = __builtin_amdgcn_perm(vst[3][i >> 1], vst[2][i >> 1], sel);
             const int d = 8 * sc + i;
             const int g = (d ^ (d >> 3)) & 15;
             *reinterpret_cast<u32x2*>(vt_ + d * 128 + 8 * (sr ^ g)) = t;
@@ -158,9 +159,11 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
     const int ntiles = (p.start + last_row) / BKV + 1;
 
     load_k(0);
-    write_k(0, sc, sr);
     load_v(0);
+    write_k(0, sc, sr);
     write_v(0, sc, sr);
+    load_k(BKV);
+    load_v(BKV);
     __syncthreads();
 
     // The iteration is straight-line on purpose (no "is there a next tile", no "does this wave see the tile"): the tile after the
@@ -168,11 +171,12 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
     // rows do not see is all -inf to it (p = 0).  Conditional staging made the compiler keep two copies of the staging registers.
     for (int it = 0; it < ntiles; ++it) {
         const int buf = it & 1, kv0 = it * BKV;
-        load_k(kv0 + BKV);
         const char* ks_ = smem + buf * (K_TILE + V_TILE);
         const char* vt_ = ks_ + K_TILE;
         int jo = j, kbo = kb, sco = sc, sro = sr;
         asm volatile("" : "+v"(jo), "+v"(kbo), "+v"(sco), "+v"(sro));
+        write_k(buf ^ 1, sco, sro);   // tile it + 1, requested an iteration ago
+        load_k(kv0 + 2 * BKV);
 
         // ---- S^T = K Q^T
         float4_t sacc[2][4];
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
             }
             __builtin_amdgcn_sched_barrier(0);  // keeps the LDS reads of later KV sub-tiles from being hoisted (register budget)
         }
-        write_k(buf ^ 1, sco, sro);
-        load_v(kv0 + BKV);
+        write_v(buf ^ 1, sco, sro);
+        load_v(kv0 + 2 * BKV);
 
         // ---- online softmax in the log2 domain; lane (j, kb) holds KV rows kv0 + 16 t + 4 kb + e of query 16 qt + j
         if constexpr (MODS) {  // scores -> log2 units with the cap and the position bias applied (sc2 = 1 below)
@@ -269,7 +273,6 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        write_v(buf ^ 1, sco, sro);
         __syncthreads();
     }
 
