@@ -1,4 +1,4 @@
-"""EXPERIMENTAL (round 4, never run on a GPU yet): builds gemm_skinny_nk.hip into tools/bin/libskinny_nk.so and checks it on
+"""EXPERIMENTAL (round 4, never run on a GPU yet): builds csrc/gemm_skinny.hip + gemm_skinny_nk.patch into tools/bin/libskinny_nk.so and checks it on
 an MI355X against the product's own bit-exact dequantisation of the same GEMV-layout buffers + a dense fp32 matmul, then times
 it beside what WQLinear_GEMV does today for 17 ... 64 rows (16-row chunks of the decode kernels).
 
@@ -19,10 +19,15 @@ OUT = os.path.join(ROOT, "tools", "bin", "libskinny_nk.so")
 
 
 def build():
+    """csrc/gemm_skinny.hip + gemm_skinny_nk.patch -> tools/bin/gemm_skinny_nk.hip -> tools/bin/libskinny_nk.so (the experimental
+    kernel is kept as a patch against the product kernel it extends, not as a second copy of it)"""
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    src = os.path.join(HERE, "gemm_skinny_nk.hip")
-    if os.path.exists(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(src):
+    base = os.path.join(ROOT, "autoawq_amd", "csrc", "gemm_skinny.hip")
+    patch = os.path.join(HERE, "gemm_skinny_nk.patch")
+    src = os.path.join(os.path.dirname(OUT), "gemm_skinny_nk.hip")
+    if os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(base), os.path.getmtime(patch)):
         return
+    subprocess.check_call(["patch", "--quiet", "-o", src, base, patch])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                            "-fno-slp-vectorize", "-Wno-unused-function", "-Wno-inline-asm", "-DAWQ_BUILDING_LIB",
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "autoawq_amd", "csrc"), "-shared", "-o", OUT, src])
