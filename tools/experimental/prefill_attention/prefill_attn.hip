@@ -102,6 +102,32 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
     // tile it + 1 (requested at the top of it - 1) go to the other LDS buffer -- free since the previous barrier -- and tile it + 2 is
     // requested; the V rows likewise after S^T = K Q^T.
     u32x4v kst[4], vst[4];
+#ifdef AWQ_PATTN_ASM_LOADS
+    // Variant for an A/B on the GPU (-DAWQ_PATTN_ASM_LOADS): the staging loads as inline asm with hand-counted waits, like the GEMM
+    // kernels of csrc/ (vector-memory operations retire in order: "four newer requests may be pending" is exact).  hipcc's own
+    // bookkeeping ends the loop's first wait at vmcnt(0), i.e. it also waits for the V rows requested half an iteration ago.
+    auto srd4 = [](const void* base, uint32_t bytes) -> u32x4 {
+        const uint64_t a = reinterpret_cast<uint64_t>(base);
+        return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+    };
+    const u32x4 ksrd = srd4(p.k + (size_t)b * p.Tmax * p.Hkv * HD, (uint32_t)kv_len * kv_row_bytes);
+    const u32x4 vsrd = srd4(p.v + (size_t)b * p.Tmax * p.Hkv * HD, (uint32_t)kv_len * kv_row_bytes);
+#define PATTN_LOAD4(R, o0, o1, o2, o3, rs)                                                                                          \
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %8, 0 offen\n\tbuffer_load_dwordx4 %1, %5, %8, 0 offen\n\t"                 \
+                 "buffer_load_dwordx4 %2, %6, %8, 0 offen\n\tbuffer_load_dwordx4 %3, %7, %8, 0 offen"                                 \
+                 : "=v"(R[0]), "=v"(R[1]), "=v"(R[2]), "=v"(R[3])                                                                  \
+                 : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rs))
+#define PATTN_WAIT4(R, newer) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]) : "n"(newer))
+    auto load_k = [&](int kv0) {
+        const uint32_t o = (uint32_t)(kv0 + sr) * kv_row_bytes + kv_col, d = 16u * kv_row_bytes;
+        PATTN_LOAD4(kst, o, o + d, o + 2 * d, o + 3 * d, ksrd);
+    };
+    auto load_v = [&](int kv0) {
+        const uint32_t o = (uint32_t)(kv0 + 4 * sr) * kv_row_bytes + kv_col, d = kv_row_bytes;
+        PATTN_LOAD4(vst, o, o + d, o + 2 * d, o + 3 * d, vsrd);
+    };
+#else
+#define PATTN_WAIT4(R, newer) ((void)0)
     auto load_k = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -114,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
             vst[i] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(
                                                       vres, (uint32_t)(kv0 + 4 * sr + i) * kv_row_bytes + kv_col, 0, 0));
     };
+#endif
     // (LDS addresses are recomputed from lane coordinates made opaque once per iteration: left loop-invariant, the compiler
     //  keeps all ~50 of them in registers across the tile loop and spills the accumulators instead)
     auto write_k = [&](int buf, int sc, int sr) {
@@ -160,6 +187,16 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
 
     load_k(0);
     load_v(0);
+    PATTN_WAIT4(kst, 0);
+    PATTN_WAIT4(vst, 0);
+#ifdef AWQ_PATTN_ASM_LOADS
+    // the compiler's own wait for the Q fragments has to happen HERE: left pending, its bookkeeping carries them into the loop and
+    // puts a vmcnt(0) in front of the first MFMAs of every iteration -- behind the K rows just requested
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
+#endif
     write_k(0, sc, sr);
     write_v(0, sc, sr);
     load_k(BKV);
@@ -175,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
         const char* vt_ = ks_ + K_TILE;
         int jo = j, kbo = kb, sco = sc, sro = sr;
         asm volatile("" : "+v"(jo), "+v"(kbo), "+v"(sco), "+v"(sro));
+        PATTN_WAIT4(kst, 4);          // (asm variant) the four V requests issued after these may still be pending
         write_k(buf ^ 1, sco, sro);   // tile it + 1, requested an iteration ago
         load_k(kv0 + 2 * BKV);
 
@@ -194,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
             }
             __builtin_amdgcn_sched_barrier(0);  // keeps the LDS reads of later KV sub-tiles from being hoisted (register budget)
         }
+        PATTN_WAIT4(vst, 4);
         write_v(buf ^ 1, sco, sro);
         load_v(kv0 + 2 * BKV);
 
@@ -275,6 +314,11 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
         }
         __syncthreads();
     }
+
+    // (asm variant) the last requests are never consumed: one wait that names both register sets keeps them allocated until they
+    // have landed -- otherwise their registers are free for the temporaries below while the loads are still in flight
+    PATTN_WAIT4(kst, 0);
+    PATTN_WAIT4(vst, 0);
 
     // ---- finish: the query's sum over its four lanes, O / l, fp16 store (lane: 4 consecutive d per dt)
 #pragma unroll

@@ -17,16 +17,18 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
 OUT = os.path.join(ROOT, "tools", "bin", "libprefill_attn.so")
+OUT_ASM = os.path.join(ROOT, "tools", "bin", "libprefill_attn_asm.so")  # -DAWQ_PATTN_ASM_LOADS: staging loads with hand-counted waits
 
 
 def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     src = os.path.join(HERE, "prefill_attn.hip")
-    if os.path.exists(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(src):
-        return
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                           "-fno-slp-vectorize", "-Wno-unused-function", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"),
-                           "-I" + os.path.join(ROOT, "autoawq_amd", "csrc"), "-shared", "-o", OUT, src])
+    for out, extra in ((OUT, []), (OUT_ASM, ["-DAWQ_PATTN_ASM_LOADS", "-Wno-inline-asm", "-Wno-unused-variable"])):
+        if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+            continue
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                               "-fno-slp-vectorize", "-Wno-unused-function", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "autoawq_amd", "csrc"), "-shared", "-o", out, src] + extra)
 
 
 def reference(q, kc, vc, start, scale, softcap, slopes):
@@ -53,17 +55,19 @@ def main():
         print("built", OUT)
         return 0
     build()
-    lib = ctypes.CDLL(OUT)
-    fn = lib.awq_exp_prefill_attention
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    fns = {}
+    for name, path in (("compiler waits", OUT), ("asm loads, counted waits", OUT_ASM)):
+        f = ctypes.CDLL(path).awq_exp_prefill_attention
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+        fns[name] = f
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def run(q, kc, vc, start, scale, softcap=0.0, slopes=None):
+    def run(q, kc, vc, start, scale, softcap=0.0, slopes=None, variant="compiler waits"):
         B, S, Hq, D = q.shape
         out = torch.full_like(q, float("nan"))
-        rc = fn(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), B, S, Hq, kc.shape[2], D, kc.shape[1], start, scale, softcap,
+        rc = fns[variant](q.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), B, S, Hq, kc.shape[2], D, kc.shape[1], start, scale, softcap,
                 slopes.data_ptr() if slopes is not None else None, stream)
         return rc, out
 
@@ -83,21 +87,22 @@ def main():
         vc[:, start + S:] = float("nan")
         slopes = (2.0 ** (-8.0 * torch.arange(1, Hq + 1) / Hq)).float().to(dev) if alibi else None
         scale = D ** -0.5
-        rc, out = run(q, kc, vc, start, scale, softcap, slopes)
-        if rc != 0:
-            bad += 1
-            print(f"B={B} S={S} start={start} Hq={Hq} Hkv={Hkv}: rc={rc}")
-            continue
         ref = reference(q, kc, vc, start, scale, softcap, slopes)
-        err = (out.float() - ref).abs().max().item()
-        # fp16 probabilities (rel 2^-11 each) under an fp32 sum + one fp16 rounding of the result (|o| <~ 4): 4e-3 absolute
-        ok = bool(torch.isfinite(out).all()) and err < 4e-3
-        bad += not ok
-        print(f"B={B} S={S} start={start} Hq={Hq} Hkv={Hkv} cap={softcap} alibi={alibi}: max err {err:.3g} {'ok' if ok else 'MISMATCH'}")
-        rc, out2 = run(q, kc, vc, start, scale, softcap, slopes)
-        if not torch.equal(out, out2):
-            bad += 1
-            print("   NOT reproducible run to run")
+        for variant in fns:
+            rc, out = run(q, kc, vc, start, scale, softcap, slopes, variant)
+            if rc != 0:
+                bad += 1
+                print(f"B={B} S={S} start={start} Hq={Hq} Hkv={Hkv} [{variant}]: rc={rc}")
+                continue
+            err = (out.float() - ref).abs().max().item()
+            # fp16 probabilities (rel 2^-11 each) under an fp32 sum + one fp16 rounding of the result (|o| <~ 4): 4e-3 absolute
+            ok = bool(torch.isfinite(out).all()) and err < 4e-3
+            bad += not ok
+            print(f"B={B} S={S} start={start} Hq={Hq} Hkv={Hkv} cap={softcap} alibi={alibi} [{variant}]: max err {err:.3g} {'ok' if ok else 'MISMATCH'}")
+            rc, out2 = run(q, kc, vc, start, scale, softcap, slopes, variant)
+            if not torch.equal(out, out2):
+                bad += 1
+                print("   NOT reproducible run to run")
 
     # timing: Llama-2-7B prefill (MHA 32 x 128) and a 70B-style GQA shape, beside the vendor path
     import torch.nn.functional as F
@@ -115,7 +120,9 @@ def main():
                 v = v.repeat_interleave(Hq // Hkv, dim=1)
             return F.scaled_dot_product_attention(q.transpose(1, 2), k, v, is_causal=True)
 
-        for name, call in (("prefill_attn", lambda: run(q, kc, vc, 0, 128 ** -0.5)), ("vendor sdpa", vendor)):
+        for name, call in (("prefill_attn (compiler waits)", lambda: run(q, kc, vc, 0, 128 ** -0.5)),
+                           ("prefill_attn (asm loads, counted waits)", lambda: run(q, kc, vc, 0, 128 ** -0.5, variant="asm loads, counted waits")),
+                           ("vendor sdpa", vendor)):
             for _ in range(3):
                 call()
             torch.cuda.synchronize()
