@@ -270,6 +270,25 @@ def test_row_streaming_kernel_never_touches_registers_with_loads_in_flight():
     assert checked >= 100, checked
 
 
+def test_hand_counted_waits_of_the_register_decoded_kernels_hold_in_the_generated_isa():
+    """csrc/gemm_regb.hip, gemm_skinny.hip and gemv_lds.hip issue their weight / activation loads in inline asm and wait with
+    HAND-COUNTED `s_waitcnt vmcnt(N)` (vector-memory operations retire in issue order).  tools/isa_audit.py::audit_vmcnt
+    simulates the vector-memory queue over the control-flow graph of the generated ISA -- every request enters it, a wait
+    retires all but the N youngest, both sides of every branch are followed, loops run to their steady state -- and reports
+    any instruction that names a VGPR whose load is still in the queue: a count that is too lax, a compiler copy or reuse of
+    an in-flight register, an output of an asm block that shares the register of an address operand a later load of the
+    block still reads.  (A wait that is too STRICT only costs time and is not an error here.)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for f, least in (("gemm_regb.hip", 6), ("gemm_skinny.hip", 2), ("gemv_lds.hip", 3)):
+        name, kernels, visits, bad = mod.audit_vmcnt(os.path.join(ROOT, "autoawq_amd", "csrc", f))
+        assert not bad, (name, bad[:5])
+        assert kernels >= least and visits > 0, (name, kernels, visits)
+
+
 def test_auto_dispatch_table_host_only():
     """awq_gemm_auto_kernel is a host-only query (no launch, no GPU): which kernel awq_gemm_forward's AUTO dispatch takes
     for the BASELINE shapes, by token count -- the table DESIGN.md section 1 (row a4/a5) describes."""

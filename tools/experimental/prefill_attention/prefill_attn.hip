@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
 #define PATTN_LOAD4(R, o0, o1, o2, o3, rs)                                                                                          \
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %8, 0 offen\n\tbuffer_load_dwordx4 %1, %5, %8, 0 offen\n\t"                 \
                  "buffer_load_dwordx4 %2, %6, %8, 0 offen\n\tbuffer_load_dwordx4 %3, %7, %8, 0 offen"                                 \
-                 : "=v"(R[0]), "=v"(R[1]), "=v"(R[2]), "=v"(R[3])                                                                  \
+                 : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3])  /* early-clobber: never the register of an address operand */ \
                  : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rs))
 #define PATTN_WAIT4(R, newer) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]) : "n"(newer))
     auto load_k = [&](int kv0) {

@@ -172,3 +172,92 @@ def main(files):
 
 if __name__ == "__main__":
     sys.exit(main(sys.argv[1:])[0])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# audit_vmcnt: are the hand-counted `s_waitcnt vmcnt(N)` of the asm-load kernels RIGHT?  (audit_inflight_regs above checks
+# that nothing touches a named register set between request and release; it takes the count itself on trust.)
+VMEM = re.compile(r"^(buffer_load|buffer_store|buffer_atomic|global_load|global_store|global_atomic|scratch_load|scratch_store|flat_load|flat_store)")
+
+
+def compile_isa(src, flags=()):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm",
+                               "-fno-slp-vectorize", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S",
+                               "--cuda-device-only", src, "-o", out] + list(flags), stderr=subprocess.DEVNULL)
+        return [l.strip() for l in open(out).read().splitlines()]
+
+
+def audit_vmcnt(src, flags=(), max_states=400000):
+    """Simulates the vector-memory queue of every kernel in `src` over its control-flow graph: vector-memory operations retire in
+    issue order (loads and stores both count on gfx950), `s_waitcnt vmcnt(N)` retires all but the N youngest.  A violation is any
+    instruction that names a VGPR which is the destination of a load still in the queue -- a counted wait that is too lax, a
+    compiler copy / spill / reuse of an in-flight register, or a request into a register whose previous load has not landed.
+    Both successors of every conditional branch are followed; a (program counter, queue) state is visited once, so loops run to
+    their steady state.  The model is validated by the compiler's own waits: every compiler-tracked load of the same kernels must
+    come out clean too.  Returns (file, kernels, vector-memory operations seen, list of problems)."""
+    lines = compile_isa(src, flags)
+    labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^[.\w$]+:", l)}
+    kernels = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) or (re.match(r"^\w+:", l) and i + 1 < len(lines) and "; @" in l)]
+    bad, nops, nk = [], 0, 0
+    for k0 in kernels:
+        if not any(lines[i].startswith("s_endpgm") for i in range(k0, min(len(lines), k0 + 200000))):
+            continue
+        nk += 1
+        seen, todo, reported = set(), [(k0 + 1, ())], set()
+        while todo:
+            pc, queue = todo.pop()
+            queue = list(queue)
+            while pc < len(lines):
+                key = (pc, tuple(queue))
+                if key in seen:
+                    break
+                seen.add(key)
+                if len(seen) > max_states:
+                    bad.append((pc + 1, "state limit reached: audit incomplete"))
+                    todo = []
+                    break
+                t = lines[pc]
+                if not t or t[0] in ";." or re.match(r"^[.\w$]+:", t):
+                    pc += 1
+                    continue
+                if t.startswith("s_endpgm"):
+                    break
+                if t.startswith("s_waitcnt"):
+                    m = re.search(r"vmcnt\((\d+)\)", t)
+                    if m:
+                        n = int(m.group(1))
+                        if len(queue) > n:
+                            queue = queue[len(queue) - n:] if n else []
+                    pc += 1
+                    continue
+                touched = regs_of(t.split(";")[0])
+                is_vmem = bool(VMEM.match(t))
+                if is_vmem and "_load" in t.split()[0] and " lds" not in t:
+                    # a load INTO a register whose previous load is still in flight is legal (loads return in order: the younger
+                    # one lands last) -- compiler-generated polling loops do it; only the address operands must have landed
+                    touched -= regs_of(t.split(",")[0])
+                inflight = set().union(*[q for q in queue]) if queue else set()
+                hit = touched & inflight
+                if hit and (pc, tuple(sorted(hit))) not in reported:
+                    reported.add((pc, tuple(sorted(hit))))
+                    bad.append((pc + 1, f"names v{sorted(hit)} while their load is in flight: {t[:90]}"))
+                if is_vmem:
+                    nops += 1
+                    is_load = "_load" in t.split()[0] or ("atomic" in t.split()[0] and " glc" in t or " sc0" in t and "atomic" in t.split()[0])
+                    dst = frozenset()
+                    if is_load and " lds" not in t and "_lds_" not in t.split()[0]:
+                        dst = frozenset(regs_of(t.split(",")[0]))
+                    queue.append(dst)
+                    if len(queue) > 64:  # (vmcnt is a 6-bit counter: the hardware itself stalls the 65th request)
+                        queue = queue[-64:]
+                    while queue and not queue[0]:  # the oldest entries without a destination register cannot matter any more
+                        queue.pop(0)
+                m = re.match(r"s_(c?branch)\w*\s+(\S+)", t)
+                if m and m.group(2) in labels:
+                    todo.append((labels[m.group(2)], tuple(queue)))
+                    if m.group(1) == "branch":
+                        break
+                pc += 1
+    return os.path.basename(src), nk, nops, bad
