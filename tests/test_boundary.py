@@ -271,7 +271,7 @@ def test_row_streaming_kernel_never_touches_registers_with_loads_in_flight():
 
 
 def test_hand_counted_waits_of_the_register_decoded_kernels_hold_in_the_generated_isa():
-    """csrc/gemm_regb.hip, gemm_skinny.hip and gemv_lds.hip issue their weight / activation loads in inline asm and wait with
+    """csrc/gemm_regb.hip, gemm_skinny.hip, gemv_lds.hip and gemv_rows.hip (the headline kernel) issue their weight / activation loads in inline asm and wait with
     HAND-COUNTED `s_waitcnt vmcnt(N)` (vector-memory operations retire in issue order).  tools/isa_audit.py::audit_vmcnt
     simulates the vector-memory queue over the control-flow graph of the generated ISA -- every request enters it, a wait
     retires all but the N youngest, both sides of every branch are followed, loops run to their steady state -- and reports
@@ -283,7 +283,7 @@ def test_hand_counted_waits_of_the_register_decoded_kernels_hold_in_the_generate
     spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    for f, least in (("gemm_regb.hip", 6), ("gemm_skinny.hip", 2), ("gemv_lds.hip", 3)):
+    for f, least in (("gemm_regb.hip", 6), ("gemm_skinny.hip", 2), ("gemv_lds.hip", 3), ("gemv_rows.hip", 64)):
         name, kernels, visits, bad = mod.audit_vmcnt(os.path.join(ROOT, "autoawq_amd", "csrc", f))
         assert not bad, (name, bad[:5])
         assert kernels >= least and visits > 0, (name, kernels, visits)

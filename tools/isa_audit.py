@@ -170,8 +170,7 @@ def main(files):
     return rc, res
 
 
-if __name__ == "__main__":
-    sys.exit(main(sys.argv[1:])[0])
+
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -249,6 +248,8 @@ def audit_vmcnt(src, flags=(), max_states=400000):
                     dst = frozenset()
                     if is_load and " lds" not in t and "_lds_" not in t.split()[0]:
                         dst = frozenset(regs_of(t.split(",")[0]))
+                    if dst:  # a register requested again is governed by the YOUNGER load from here on (in-order return)
+                        queue = [q - dst for q in queue]
                     queue.append(dst)
                     if len(queue) > 64:  # (vmcnt is a 6-bit counter: the hardware itself stalls the 65th request)
                         queue = queue[-64:]
@@ -261,3 +262,21 @@ def audit_vmcnt(src, flags=(), max_states=400000):
                         break
                 pc += 1
     return os.path.basename(src), nk, nops, bad
+
+
+def main_vmcnt(files):
+    files = files or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    rc = 0
+    for f in files:
+        name, kernels, visits, bad = audit_vmcnt(f, max_states=8000000)
+        print(f"{name:20s} kernels {kernels:3d}   vector-memory operations visited {visits:8d}   problems {len(bad)}")
+        for ln, text in bad[:10]:
+            print(f"    line {ln}: {text}")
+            rc = 1
+    return rc
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--vmcnt":  # tools/isa_audit.py --vmcnt [file.hip ...]
+        sys.exit(main_vmcnt(sys.argv[2:]))
+    sys.exit(main(sys.argv[1:])[0])
