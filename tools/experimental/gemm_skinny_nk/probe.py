@@ -20,17 +20,24 @@ OUT = os.path.join(ROOT, "tools", "bin", "libskinny_nk.so")
 
 def build():
     """csrc/gemm_skinny.hip + gemm_skinny_nk.patch -> tools/bin/gemm_skinny_nk.hip -> tools/bin/libskinny_nk.so (the experimental
-    kernel is kept as a patch against the product kernel it extends, not as a second copy of it)"""
+    kernel is kept as a patch against the product kernel it extends, not as a second copy of it).  tools/bin/ is git-ignored and
+    travels with a gpurun snapshot: build HERE first (`--build-only`); a stamp file holds the hash of the inputs (file times do not
+    survive the copy)."""
+    import hashlib
+
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     base = os.path.join(ROOT, "autoawq_amd", "csrc", "gemm_skinny.hip")
     patch = os.path.join(HERE, "gemm_skinny_nk.patch")
     src = os.path.join(os.path.dirname(OUT), "gemm_skinny_nk.hip")
-    if os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(base), os.path.getmtime(patch)):
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize", "-Wno-unused-function",
+             "-Wno-inline-asm", "-DAWQ_BUILDING_LIB"]
+    stamp = hashlib.sha1(open(base, "rb").read() + open(patch, "rb").read() + " ".join(flags).encode()).hexdigest()
+    if os.path.exists(OUT) and os.path.exists(OUT + ".stamp") and open(OUT + ".stamp").read() == stamp:
         return
     subprocess.check_call(["patch", "--quiet", "-o", src, base, patch])
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                           "-fno-slp-vectorize", "-Wno-unused-function", "-Wno-inline-asm", "-DAWQ_BUILDING_LIB",
-                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "autoawq_amd", "csrc"), "-shared", "-o", OUT, src])
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "autoawq_amd", "csrc"),
+                           "-shared", "-o", OUT, src])
+    open(OUT + ".stamp", "w").write(stamp)
 
 
 def random_gemv_layer(K, N, g, dev, seed):

@@ -23,11 +23,15 @@ OUT = os.path.join(ROOT, "tools", "bin", "libmall_prefetch.so")
 
 
 def build():
+    import hashlib
+
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     src = os.path.join(HERE, "prefetch.hip")
-    if os.path.exists(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(src):
+    stamp = hashlib.sha1(open(src, "rb").read()).hexdigest()
+    if os.path.exists(OUT) and os.path.exists(OUT + ".stamp") and open(OUT + ".stamp").read() == stamp:
         return
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, src])
+    open(OUT + ".stamp", "w").write(stamp)
 
 
 def main():

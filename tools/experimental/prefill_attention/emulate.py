@@ -39,6 +39,9 @@ def perm(a, b, sel):
     return out
 
 
+MFMA_ROWSUM = False  # --mfma-rowsum: model the -DAWQ_PATTN_MFMA_ROWSUM build (row sums from an all-ones MFMA)
+
+
 def run_block(q, kc, vc, b, h, kvh, qb, start, S, scale, softcap=0.0, slope_h=0.0):
     """q [B, S, Hq, 128] fp16, kc / vc [Bc, Tmax, Hkv, 128] fp16 -> {(row, d): value} of the block's stores"""
     mods = softcap > 0 or slope_h != 0.0
@@ -100,7 +103,7 @@ def run_block(q, kc, vc, b, h, kvh, qb, start, S, scale, softcap=0.0, slope_h=0.
                         d0 = 32 * ks + 8 * KB[ln]
                         qf[qt, ks, ln] = q[b, row[ln], h, d0:d0 + 8].astype(np.float32)
         state.append(dict(qw0=qw0, qf=qf, oacc=np.zeros((2, 8, 64, 4), np.float32), m=np.full((2, 64), -np.inf, np.float32),
-                          l=np.zeros((2, 64), np.float32)))
+                          l=np.zeros((2, 64), np.float32), lacc=np.zeros((2, 64, 4), np.float32)))
     stage_tile(0, 0)
     for it in range(ntiles):
         buf, kv0 = it & 1, it * BKV
@@ -141,10 +144,12 @@ def run_block(q, kc, vc, b, h, kvh, qb, start, S, scale, softcap=0.0, slope_h=0.
                 pr = np.exp2(sacc[qt] * sc2 - m_new[None, :, None])  # [t, lane, e]
                 st["l"][qt] = st["l"][qt] * alpha + pr.sum(axis=(0, 2))
                 st["oacc"][qt] *= alpha[None, :, None]
+                st["lacc"][qt] *= alpha[:, None]
                 prh = pr.astype(np.float16).astype(np.float32)
                 for u in range(2):
                     pf[qt, u, :, 0:4] = prh[2 * u]
                     pf[qt, u, :, 4:8] = prh[2 * u + 1]
+                    st["lacc"][qt] = mfma16(np.ones((64, 8), np.float32), pf[qt, u], st["lacc"][qt])
             for dt in range(8):
                 lane_x = 8 * (KB ^ J ^ (J >> 3))
                 row = base + K_TILE + (16 * dt + J) * 128
@@ -162,6 +167,8 @@ def run_block(q, kc, vc, b, h, kvh, qb, start, S, scale, softcap=0.0, slope_h=0.
             l = st["l"][qt]
             l = l + l[LANES ^ 16]
             l = l + l[LANES ^ 32]
+            if MFMA_ROWSUM:
+                l = st["lacc"][qt][:, 0]
             for ln in range(64):
                 row = st["qw0"] + 16 * qt + J[ln]
                 if row >= S:
@@ -257,6 +264,8 @@ def check_bank_conflicts():
 
 
 def main():
+    global MFMA_ROWSUM
+    MFMA_ROWSUM = "--mfma-rowsum" in sys.argv
     rng = np.random.default_rng(0)
     bad = check_block_map()
     check_bank_conflicts()

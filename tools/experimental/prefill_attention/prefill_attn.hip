@@ -168,6 +168,13 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
     // ---- per-query state (query qt: 16 qt + j; the four lanes of a query hold the same m, their own part of l)
     float4_t oacc[2][8];
     float m_run[2], l_run[2];
+#ifdef AWQ_PATTN_MFMA_ROWSUM
+    // Variant for an A/B on the GPU (-DAWQ_PATTN_MFMA_ROWSUM): the row sums come from the matrix pipe -- one more MFMA per (query
+    // tile, k step) with an all-ones A operand: C[any row][query j] = sum over the step's 32 KV slots of P (the fp16 values the
+    // numerator uses), already summed over the query's four lanes -- instead of 32 v_add_f32 per lane and tile.
+    float4_t lacc[2] = {float4_t{0.f, 0.f, 0.f, 0.f}, float4_t{0.f, 0.f, 0.f, 0.f}};
+    const u32x4v ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+#endif
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         m_run[qt] = -INFINITY;
@@ -279,12 +286,17 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
                 for (int e = 0; e < 4; ++e) {
                     const float pv = fast_exp2(fmaf(sacc[qt][t][e], sc2, -m_new));
                     pr[4 * t + e] = pv;
+#ifndef AWQ_PATTN_MFMA_ROWSUM
                     psum += pv;
+#endif
                 }
             l_run[qt] = l_run[qt] * alpha + psum;
             if (!__all(alpha == 1.0f)) {  // (wave-uniform) the running maximum moved for some query of the wave
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) oacc[qt][dt] *= alpha;
+#ifdef AWQ_PATTN_MFMA_ROWSUM
+                lacc[qt] *= alpha;
+#endif
             }
             // B fragments of the two k steps: slots 0-3 = sub-tile 2 u (e = 0 .. 3), slots 4-7 = sub-tile 2 u + 1
 #pragma unroll
@@ -293,6 +305,9 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
                 pf[qt][u][1] = pack_h2(pr[8 * u + 2], pr[8 * u + 3]);
                 pf[qt][u][2] = pack_h2(pr[8 * u + 4], pr[8 * u + 5]);
                 pf[qt][u][3] = pack_h2(pr[8 * u + 6], pr[8 * u + 7]);
+#ifdef AWQ_PATTN_MFMA_ROWSUM
+                lacc[qt] = mfma16(ones, pf[qt][u], lacc[qt]);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -323,9 +338,13 @@ __global__ __launch_bounds__(256, 2) void awq_prefill_attn_kernel(PrefillAttnPar
     // ---- finish: the query's sum over its four lanes, O / l, fp16 store (lane: 4 consecutive d per dt)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
+#ifdef AWQ_PATTN_MFMA_ROWSUM
+        const float l = lacc[qt][0];  // every row of the ones product is the query's sum, over all four lanes' slots
+#else
         float l = l_run[qt];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
+#endif
         const float inv = 1.0f / l;
         const int row = qw0 + 16 * qt + j;
         if (row >= p.S) continue;

@@ -16,19 +16,38 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
-OUT = os.path.join(ROOT, "tools", "bin", "libprefill_attn.so")
-OUT_ASM = os.path.join(ROOT, "tools", "bin", "libprefill_attn_asm.so")  # -DAWQ_PATTN_ASM_LOADS: staging loads with hand-counted waits
+BIN = os.path.join(ROOT, "tools", "bin")
+# build variants, all checked and timed side by side (the kernel's #ifdef switches)
+VARIANTS = {
+    "compiler waits": [],
+    "asm loads": ["-DAWQ_PATTN_ASM_LOADS"],
+    "mfma rowsum": ["-DAWQ_PATTN_MFMA_ROWSUM"],
+    "asm loads + mfma rowsum": ["-DAWQ_PATTN_ASM_LOADS", "-DAWQ_PATTN_MFMA_ROWSUM"],
+    "asm loads + mfma rowsum + no-nans": ["-DAWQ_PATTN_ASM_LOADS", "-DAWQ_PATTN_MFMA_ROWSUM", "-fno-honor-nans"],
+}
+
+
+def lib_path(name):
+    return os.path.join(BIN, "libprefill_attn_" + "".join(c if c.isalnum() else "_" for c in name) + ".so")
 
 
 def build():
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    """One library per variant under tools/bin/ (git-ignored, travels with a gpurun snapshot: build HERE first -- `--build-only` --
+    and the GPU box spends no time compiling).  A stamp file holds the hash of source + flags: file times do not survive the copy."""
+    import hashlib
+
+    os.makedirs(BIN, exist_ok=True)
     src = os.path.join(HERE, "prefill_attn.hip")
-    for out, extra in ((OUT, []), (OUT_ASM, ["-DAWQ_PATTN_ASM_LOADS", "-Wno-inline-asm", "-Wno-unused-variable"])):
-        if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+    for name, extra in VARIANTS.items():
+        out = lib_path(name)
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize",
+               "-Wno-unused-function", "-Wno-inline-asm", "-Wno-unused-variable", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(ROOT, "autoawq_amd", "csrc"), "-shared", "-o", out, src] + extra
+        stamp = hashlib.sha1(open(src, "rb").read() + " ".join(cmd[1:]).replace(ROOT, "").encode()).hexdigest()
+        if os.path.exists(out) and os.path.exists(out + ".stamp") and open(out + ".stamp").read() == stamp:
             continue
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                               "-fno-slp-vectorize", "-Wno-unused-function", "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include"),
-                               "-I" + os.path.join(ROOT, "autoawq_amd", "csrc"), "-shared", "-o", out, src] + extra)
+        subprocess.check_call(cmd)
+        open(out + ".stamp", "w").write(stamp)
 
 
 def reference(q, kc, vc, start, scale, softcap, slopes):
@@ -52,12 +71,12 @@ def reference(q, kc, vc, start, scale, softcap, slopes):
 def main():
     if "--build-only" in sys.argv:
         build()
-        print("built", OUT)
+        print("built", ", ".join(os.path.basename(lib_path(n)) for n in VARIANTS))
         return 0
     build()
     fns = {}
-    for name, path in (("compiler waits", OUT), ("asm loads, counted waits", OUT_ASM)):
-        f = ctypes.CDLL(path).awq_exp_prefill_attention
+    for name in VARIANTS:
+        f = ctypes.CDLL(lib_path(name)).awq_exp_prefill_attention
         f.restype = ctypes.c_int
         f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
         fns[name] = f
@@ -120,9 +139,8 @@ def main():
                 v = v.repeat_interleave(Hq // Hkv, dim=1)
             return F.scaled_dot_product_attention(q.transpose(1, 2), k, v, is_causal=True)
 
-        for name, call in (("prefill_attn (compiler waits)", lambda: run(q, kc, vc, 0, 128 ** -0.5)),
-                           ("prefill_attn (asm loads, counted waits)", lambda: run(q, kc, vc, 0, 128 ** -0.5, variant="asm loads, counted waits")),
-                           ("vendor sdpa", vendor)):
+        calls = [(f"prefill_attn [{v}]", (lambda v=v: run(q, kc, vc, 0, 128 ** -0.5, variant=v))) for v in VARIANTS] + [("vendor sdpa", vendor)]
+        for name, call in calls:
             for _ in range(3):
                 call()
             torch.cuda.synchronize()

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 5, first GPU call: everything staged at the end of round 4 (tools/experimental/README.md) in ONE box session, each step under
 # its own timeout, outputs under gpurun_out/r05_first/.   gpurun --timeout 1500 -- 'bash tools/r05_first_call.sh'
+# BEFORE the call, in the build container: `for p in gemm_skinny_nk prefill_attention mall_prefetch; do python tools/experimental/$p/probe.py --build-only; done`
+# (tools/bin/ travels with the snapshot; the probes then find their libraries built and the box compiles nothing).
 # Budget: smoke ~1 min, three probes ~2 min each (they build their own libraries: hipcc on the box), suite under xdist ~2-3 min.
 set -u
 cd "$(dirname "$0")/.."
