@@ -375,7 +375,11 @@ int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweight, const ui
 int awq_gemv_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0 || K % group_size || K % 8 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return -1;
     const int m = (int)M, k = (int)K, n = (int)N, g = (int)group_size;
-    if (M > 16) return -1;  // one call serves 16 rows (the host wrapper chunks); AWQ_GEMV_KERNEL_PREFILL is explicit only (header)
+    // round 5: from five rows the batched kernel (gemv_batch.hip: activations in registers, the K range split over the waves of a
+    // block, weights by LDS-DMA) -- up to 32 rows per launch, any M in one call (balanced chunks); it replaces gemv_lds / gemv_nk
+    // wherever it takes the shape (group_size 128): 4096 x 11008, M = 8: see profiles/r05_*; AWQ_GEMV_KERNEL_PREFILL is explicit only
+    if (M >= 5 && awq_gemv_batch_supports((int)(M > 32 ? 32 : M), k, n, g)) return (int)AWQ_GEMV_KERNEL_BATCH;
+    if (M > 16) return -1;  // the older decode kernels serve 16 rows per call (the host wrapper chunks)
     // round 4: batch 2 at every K and batches 3 .. 4 while K <= 6144 also run the row-streaming kernel -- it is ahead of the
     // 16-row tile kernel there on all four 7B shapes (profiles/r03_gemv_rows_sweep.txt: M = 2 4.65 / 7.05 / 10.77 / 8.57 us vs
     // 6.18 / 9.96 / 16.65 / 10.73; M = 4 at K = 4096 5.79 / 9.79 / 14.39 vs 6.59 / 10.40 / 18.29; at K = 11008 12.25 vs 11.79)
@@ -400,8 +404,21 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
         return awq_launch_gemm_regb_nk(x, qweight, scales, qzeros, nullptr, y, (int)M, (int)K, (int)N, (int)group_size, (int)zeros_width,
                                        AWQ_GEMM_FLAG_NLOG(flags) == 2 ? 256 : 0, static_cast<hipStream_t>(stream));
     }
-    if (M > 16) return AWQ_ERR_UNSUPPORTED;  // the decode kernels take at most 16 rows per call
     const int auto_k = kern == AWQ_GEMV_KERNEL_AUTO ? awq_gemv_auto_kernel(M, K, N, group_size) : -1;
+    if (kern == AWQ_GEMV_KERNEL_BATCH || auto_k == (int)AWQ_GEMV_KERNEL_BATCH) {
+        if (!awq_gemv_batch_supports((int)(M > 32 ? 32 : M), (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
+        g_last_kernel = "gemv_batch";
+        const int64_t nchunk = (M + 31) / 32, rows = (M + nchunk - 1) / nchunk;  // balanced chunks of at most 32 rows
+        for (int64_t m0 = 0; m0 < M; m0 += rows) {
+            const int mm = (int)(M - m0 < rows ? M - m0 : rows);
+            const int rc = awq_launch_gemv_batch(x + m0 * K, qweight, scales, qzeros, y + m0 * N, mm, (int)K, (int)N, (int)group_size,
+                                                 (int)zeros_width, (int)AWQ_GEMM_FLAG_UNIT(flags), (int)AWQ_GEMM_FLAG_SPLITK(flags),
+                                                 static_cast<hipStream_t>(stream));
+            if (rc != AWQ_OK) return rc;
+        }
+        return AWQ_OK;
+    }
+    if (M > 16) return AWQ_ERR_UNSUPPORTED;  // the older decode kernels take at most 16 rows per call
     if ((kern == AWQ_GEMV_KERNEL_ROWS && awq_gemv_rows_supports((int)M, (int)K, (int)N, (int)group_size)) ||
         auto_k == (int)AWQ_GEMV_KERNEL_ROWS) {
         g_last_kernel = "gemv_rows";

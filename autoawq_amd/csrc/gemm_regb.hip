@@ -174,26 +174,26 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
                  "buffer_load_dword %2, %8, %9, %12 offen\n\tbuffer_load_dword %3, %8, %9, %13 offen\n\t"                          \
                  "buffer_load_dword %4, %8, %9, %14 offen\n\tbuffer_load_dword %5, %8, %9, %15 offen\n\t"                          \
                  "buffer_load_dword %6, %8, %9, %16 offen\n\tbuffer_load_dword %7, %8, %9, %17 offen"                              \
-                 : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3]), "=v"(W[4]), "=v"(W[5]), "=v"(W[6]), "=v"(W[7])                  \
+                 : "=&v"(W[0]), "=&v"(W[1]), "=&v"(W[2]), "=&v"(W[3]), "=&v"(W[4]), "=&v"(W[5]), "=&v"(W[6]), "=&v"(W[7])                  \
                  : "v"(voff), "s"(rs), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]), "s"(so[4]), "s"(so[5]), "s"(so[6]), "s"(so[7]))
 #define AWQ_BLOADZS(Z, S2, zvoff, zrs, zso, svoff, srs, sso)                                                                  \
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %5, %6, %7 offen"                        \
-                 : "=v"(Z), "=v"(S2)                                                                                        \
+                 : "=&v"(Z), "=&v"(S2)                                                                                        \
                  : "v"(zvoff), "s"(zrs), "s"(zso), "v"(svoff), "s"(srs), "s"(sso))
-#define AWQ_BLOAD1(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff))
-#define AWQ_BLOAD2(dst, voff, rs, soff) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff))
+#define AWQ_BLOAD1(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff))
+#define AWQ_BLOAD2(dst, voff, rs, soff) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff))
 // NK form: four dwordx2 weight loads, then four zero words and four scales, each group behind one s_nop 4 (same hazard)
 #define AWQ_BLOADW4(W, vo, rs, so)                                                                                              \
     asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %4, %5, %6 offen\n\tbuffer_load_dwordx2 %1, %4, %5, %7 offen\n\t"              \
                  "buffer_load_dwordx2 %2, %4, %5, %8 offen\n\tbuffer_load_dwordx2 %3, %4, %5, %9 offen"                                \
-                 : "=v"(W[0]), "=v"(W[1]), "=v"(W[2]), "=v"(W[3])                                                               \
+                 : "=&v"(W[0]), "=&v"(W[1]), "=&v"(W[2]), "=&v"(W[3])                                                               \
                  : "v"(vo), "s"(rs), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]))
 #define AWQ_BLOADZS4(Z, S, zvo, zrs, zso, svo, srs, sso)                                                                        \
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %8, %9, %10 offen\n\tbuffer_load_dword %1, %8, %9, %11 offen\n\t"                \
                  "buffer_load_dword %2, %8, %9, %12 offen\n\tbuffer_load_dword %3, %8, %9, %13 offen\n\t"                            \
                  "buffer_load_ushort %4, %14, %15, %16 offen\n\tbuffer_load_ushort %5, %14, %15, %17 offen\n\t"                      \
                  "buffer_load_ushort %6, %14, %15, %18 offen\n\tbuffer_load_ushort %7, %14, %15, %19 offen"                            \
-                 : "=v"(Z[0]), "=v"(Z[1]), "=v"(Z[2]), "=v"(Z[3]), "=v"(S[0]), "=v"(S[1]), "=v"(S[2]), "=v"(S[3])               \
+                 : "=&v"(Z[0]), "=&v"(Z[1]), "=&v"(Z[2]), "=&v"(Z[3]), "=&v"(S[0]), "=&v"(S[1]), "=&v"(S[2]), "=&v"(S[3])               \
                  : "v"(zvo), "s"(zrs), "s"(zso[0]), "s"(zso[1]), "s"(zso[2]), "s"(zso[3]), "v"(svo), "s"(srs), "s"(sso[0]),       \
                    "s"(sso[1]), "s"(sso[2]), "s"(sso[3]))
     auto fetch_b = [&](BRegs& R, int t) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
     // whole prefetch round trip at the first ds_read of every step.  The asm reads are ordered by hand: all eight are
     // issued, the B decode runs in their shadow, ONE wait-only statement that names the registers, then the MFMAs.
     const uint32_t a_base = lds0 + (uint32_t)a_row_off;
-#define AWQ_LDS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define AWQ_LDS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(dst) : "v"(addr))
 
     auto compute = [&](BRegs& R, int buf, auto&& issue_next) {
         half2_t zm[4], sd[4];

@@ -1,0 +1,355 @@
+// gemv_batch.hip -- batched decode (5 <= M <= 32 per launch) on the GEMV layout: weights stream through LDS by DMA into MFMA,
+// the activations live in REGISTERS as MFMA A fragments, the K range of a tile is split over the waves of ONE block, gfx950.
+//
+// Replaces awq_ext.gemmv2_forward_cuda (awq/modules/linear/gemv.py:168-176: the reference's kernel for more than 8 rows on
+// this layout) and awq_ext.gemv_forward_cuda (:178-180) for the batches above the row-streaming kernel (gemv_rows.hip, M <= 4).
+// Layout: qweight [N, K/8] int32 (nibble i of word c = w[n, 8c+i]), qzeros [N, ZW] int32 (nibble i of word c =
+// z[n, group 8c+i]), scales [N, 8 ZW] fp16.  group_size == 128.
+//
+// Roofline: HBM.  Algorithmic bytes per call: K*N/2 + (K/g)*N/2 + (K/g)*N*2 + M*K*2 + M*N*2.
+//
+// Why this shape (round 5; what the predecessors measured):
+//  * gemv_lds.hip (M <= 16, M K <= 32768) stages ALL of x in LDS as A fragments per block -- 64 KB through registers and two
+//    barriers before the first MFMA: start-up bound (11.5 us at 4096 x 11008, M = 8, against 5.2 us at M = 1), and it cannot
+//    take M = 16 at K = 4096 or any batch at K = 11008.  The register-fetch N-major forms (gemm_skinny MODE 1 / 2, round 4's
+//    staged experiment, profiles/r05_first_call/skinny_nk.txt) read 16 rows x 64 bytes per wave instruction: 21-25 us at every M.
+//  * Here a block's eight waves split the K range of a 16-row tile: wave wk owns GW consecutive 128-k groups, so its
+//    activations are MI x GW x 4 MFMA A fragments that stay in (at most 128) REGISTERS for the whole launch -- no LDS
+//    staging, no block barrier before the first MFMA, no LDS read on the A side of any MFMA.  They come straight from L2 (x is
+//    M x K x 2 bytes) by 16-byte loads requested ahead of the weights.
+//  * Weights: a PIECE = 16 rows x (GW x 64) bytes of ONE wave's K range, by GW LDS-DMA instructions (`global_load_lds_dwordx4`,
+//    1 KiB each = 4 rows x 256 B for GW 4, 2 rows x 512 B for GW 8; the eight waves of the block together read the tile's rows
+//    end to end) + one for the rows' scales (16 bytes per row) + one for the zero words: GW + 2 identical vector-memory
+//    instructions per piece, so `s_waitcnt vmcnt((GW + 2)(RD - 1))` names exactly one ring slot; no VGPR is a DMA destination.
+//    A 16-byte chunk XOR swizzle applied on the GLOBAL side (lane i of a row fetches chunk i ^ row) makes the ds_read_b128
+//    fragment reads (lane (n, kq): chunk 4 u + kq of row n = the B operands of four MFMAs) bank-conflict free without padding.
+//  * Decode: (w - z) * s in fp16 -- the reference's dequantised weight exactly (awq/utils/packing_utils.py:98-100: integer
+//    subtract, one rounding in the multiply) -- nibbles stay in place under the exponents 2^10 / 2^6 (five VALU per word), four
+//    packed subtracts of (bias + z), four packed multiplies; the activations are pair-permuted to the (t, t+4) order that leaves.
+//    fp32 accumulation in v_mfma_f32_16x16x32_f16.  One-hot and zero inputs stay exact.
+//  * The wk partial tiles of a block meet in LDS behind ONE raw s_barrier per tile (the DMA ring stays in flight across it; LDS
+//    writes are drained by hand: `__syncthreads()` would wait for vmcnt(0)), summed in wave order: bitwise reproducible.  Nothing
+//    crosses a CU: no workspace, no exchange.  y is parked in LDS (fp32) and written after the stream has drained (a store
+//    inside the stream would break the counted waits: stores count in vmcnt but do not retire in order with loads).
+//  * K beyond one pass (8 waves x GW groups: 4096 / 8192 k) is walked in PASSES: the A fragments of the next K range are
+//    re-requested (a drain: they queue behind the ring), the ring keeps running across the pass edge, partial sums add up in the
+//    parked tiles.  K = 11008 (86 groups): two passes at GW 8, three at GW 4.
+//  * M > 32 is two launches from the C API (the A fragments of 64 rows do not fit the register file beside a useful K range).
+#include <type_traits>
+
+#include "awq_device.h"
+#include "awq_internal.h"
+
+namespace {
+
+struct BatchParams {
+    const uint32_t* qweight;
+    const uint32_t* qzeros;
+    const half_t* scales;
+    const half_t* x;
+    half_t* y;
+    int M, K, N;
+    int KW, ZW, SW;  // words per qweight / qzeros row, halfs per scales row
+    int G;           // groups: K / 128
+    int wk, wt;      // waves side by side on a tile's K range, tile owners per block (wk * wt == 8)
+    int passes;      // ceil(G / (wk * GW))
+    int tiles_base, tiles_rem, tiles_max;  // tiles per owner: base (+1 for the first rem owners)
+    int ring_off, pbuf_off, ystage_off;    // LDS byte offsets
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define AWQ_BT_DMA16(voff, base, ldsaddr) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(ldsaddr) : "memory", "m0")
+#define AWQ_BT_DMA4(voff, base, ldsaddr) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(ldsaddr) : "memory", "m0")
+#define AWQ_BT_LOAD16(dst, voff, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory")
+// 16 registers-quads per statement (asm operand lists are bounded); the count sits in the first one of a group
+#define AWQ_BT_WAIT16(X, o, cnt)                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(%16)"                                                                                            \
+                 : "+v"(X[o + 0]), "+v"(X[o + 1]), "+v"(X[o + 2]), "+v"(X[o + 3]), "+v"(X[o + 4]), "+v"(X[o + 5]), "+v"(X[o + 6]), \
+                   "+v"(X[o + 7]), "+v"(X[o + 8]), "+v"(X[o + 9]), "+v"(X[o + 10]), "+v"(X[o + 11]), "+v"(X[o + 12]),              \
+                   "+v"(X[o + 13]), "+v"(X[o + 14]), "+v"(X[o + 15])                                                               \
+                 : "n"(cnt))
+
+AWQ_DEV float4_t mfma16(u32x4 a, u32x4 b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+}
+
+// MI: 16-row batch tiles (1 | 2); GW: 128-k groups per wave and pass (4 | 8; MI * GW <= 8); RD: pieces in flight per wave
+template <int MI, int GW, int RD>
+__global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
+    static_assert(MI * GW <= 8, "the A fragments of a wave are 16 MI GW registers");
+    constexpr int PIECE_W = 16 * GW * 64;          // bytes of weights per piece: 16 rows x GW groups x 64 bytes
+    constexpr int PIECE_B = PIECE_W + 1024 + 256;  // + the rows' scales (64 x 16-byte slots) + zero words (64 x 4)
+    constexpr int LDM = GW + 2;                    // vector-memory instructions per piece request
+    constexpr int CPR = 4 * GW;                    // 16-byte chunks per row of a piece (16 | 32)
+    constexpr int RPI = 64 / CPR;                  // rows per DMA instruction (4 | 2)
+    constexpr int NA = MI * GW * 4;                // A fragments (16 bytes each) per lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    const int M = p.M;
+    const int wki = wave % p.wk, twi = wave / p.wk;
+    // owner = the wk waves that share tiles; owner ids interleave the blocks (consecutive owners sit on different CUs)
+    const int owner = twi * (int)gridDim.x + (int)blockIdx.x;
+    const int t0 = owner * p.tiles_base + min(owner, p.tiles_rem);
+    const int ntile = p.tiles_base + (owner < p.tiles_rem ? 1 : 0);
+    const int nunit = ntile * p.passes;  // live units of this wave, flat: u = pass * ntile + tile
+    const int ring = p.ring_off + wave * RD * PIECE_B;
+    const int rowbytes = p.KW * 4;
+
+    // ---- request flat unit u into ring slot u % RD (past the end: clamped addresses -- the counted waits need the requests)
+    auto request = [&](int u) {
+        const bool live = u < nunit;
+        const int uu = live ? u : 0;
+        const int nt1 = max(ntile, 1);
+        const int ps = uu / nt1, tl = uu - ps * nt1;
+        const int g0 = (ps * p.wk + wki) * GW;
+        const int row0 = live ? (t0 + tl) * 16 : 0;
+        const uint32_t slot = lds0 + (uint32_t)(ring + (u % RD) * PIECE_B);
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            const int r = i * RPI + lane / CPR;  // row of the tile
+            const int pos = lane % CPR;          // chunk slot in LDS
+            const int c = (pos & 16) | ((pos ^ r) & 15);
+            const int byte = min(g0 * 64 + 16 * c, rowbytes - 16);  // past the row end (a ragged or dead piece): its last chunk (A is 0 there)
+            const uint32_t voff = live ? (uint32_t)(min(row0 + r, p.N - 1) * rowbytes + byte) : 0u;
+            AWQ_BT_DMA16(voff, p.qweight, slot + 1024u * i);
+        }
+        {
+            const int r = min(row0 + n, p.N - 1);
+            const int sbyte = min((2 * g0) & ~15, p.SW * 2 - 16);
+            AWQ_BT_DMA16((uint32_t)(r * p.SW * 2 + sbyte), p.scales, slot + (uint32_t)PIECE_W);
+            const int zword = min(g0 >> 3, p.ZW - 1);
+            AWQ_BT_DMA4((uint32_t)((r * p.ZW + zword) * 4), p.qzeros, slot + (uint32_t)(PIECE_W + 1024));
+        }
+    };
+
+    // ---- activations of pass ps -> A fragments in registers (pair-permuted), zero for batch rows >= M and groups >= G
+    u32x4 afr[NA];
+    auto load_a = [&](int ps) {
+        const int g0 = (ps * p.wk + wki) * GW;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int u = 0; u < GW; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int m = min(16 * mi + n, M - 1);
+                    const int kk = min(128 * (g0 + u) + 32 * kq + 8 * c, p.K - 8);
+                    AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (uint32_t)((m * p.K + kk) * 2), p.x);
+                }
+    };
+    auto permute_a = [&](int ps) {
+        const int g0 = (ps * p.wk + wki) * GW;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int u = 0; u < GW; ++u) {
+                const bool valid = (16 * mi + n < M) && (g0 + u < p.G);
+                const uint32_t slo = valid ? 0x05040100u : 0x0C0C0C0Cu, shi = valid ? 0x07060302u : 0x0C0C0C0Cu;  // 0x0C: the constant 0
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const u32x4 d = afr[(mi * GW + u) * 4 + c];
+                    u32x4 v;
+                    v[0] = __builtin_amdgcn_perm(d[2], d[0], slo);  // (x0, x4)  bias 1024
+                    v[1] = __builtin_amdgcn_perm(d[2], d[0], shi);  // (x1, x5)  bias 64
+                    v[2] = __builtin_amdgcn_perm(d[3], d[1], slo);  // (x2, x6)  bias 1024
+                    v[3] = __builtin_amdgcn_perm(d[3], d[1], shi);  // (x3, x7)  bias 64
+                    afr[(mi * GW + u) * 4 + c] = v;
+                }
+            }
+    };
+    auto wait_a = [&](auto cnt_c) __attribute__((always_inline)) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        AWQ_BT_WAIT16(afr, 0, CNT);
+        if constexpr (NA > 16) AWQ_BT_WAIT16(afr, 16, CNT);
+    };
+
+    load_a(0);
+#pragma unroll
+    for (int d = 0; d < RD; ++d) request(d);
+    wait_a(std::integral_constant<int, LDM * RD>{});  // everything older than the ring requests: the activations
+    permute_a(0);
+
+    // ---- stream
+    float4_t* pbuf = reinterpret_cast<float4_t*>(smem + p.pbuf_off);      // [2][8 waves][MI][64 lanes]
+    float4_t* ystage = reinterpret_cast<float4_t*>(smem + p.ystage_off);  // [wt][tiles_max][MI][64 lanes]
+    int u = 0, it = 0;  // live units requested so far; iterations (the parity of the partial-tile buffer)
+    for (int ps = 0; ps < p.passes; ++ps) {
+        if (ps > 0) {  // the next K range of the activations (they queue behind the ring: a drain)
+            load_a(ps);
+            wait_a(std::integral_constant<int, 0>{});
+            permute_a(ps);
+        }
+        const int g0 = (ps * p.wk + wki) * GW;
+        for (int tl = 0; tl < p.tiles_max; ++tl, ++it) {
+            const bool live = tl < ntile;  // wave-uniform (and the same for the wk waves of an owner)
+            float4_t acc[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = float4_t{0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM * (RD - 1)) : "memory");
+                const unsigned char* slot = smem + ring + (u % RD) * PIECE_B;
+                const uint32_t zw = *reinterpret_cast<const uint32_t*>(slot + PIECE_W + 1024 + 4 * lane);
+                const u32x4 sq = *reinterpret_cast<const u32x4*>(slot + PIECE_W + 16 * lane);  // 8 scales: groups (g0 & ~7) ..
+                u32x4 wq[GW];
+#pragma unroll
+                for (int uu = 0; uu < GW; ++uu) {
+                    const int q = 4 * uu + kq;
+                    const int pos = (q & 16) | ((q ^ n) & 15);
+                    wq[uu] = *reinterpret_cast<const u32x4*>(slot + n * (CPR * 16) + pos * 16);
+                }
+#pragma unroll
+                for (int uu = 0; uu < GW; ++uu) {
+                    const int gi = (g0 & 7) + uu;  // index of the group in the zero word and in the 8-scale chunk
+                    const uint32_t z = (zw >> (4 * gi)) & 15u;
+                    const half2_t zlo = u2h2(0x64006400u | z | (z << 16));         // (1024 + z, 1024 + z)
+                    const half2_t zhi = u2h2(0x54005400u | (z << 4) | (z << 20));  // (64 + z, 64 + z)
+                    // (GW 4: g0 & 7 is 0 or 4 -- the piece's four scales are the low or the high 8 bytes of the chunk; GW 8: all of it)
+                    const uint32_t sw = GW == 8 ? sq[uu >> 1] : ((g0 & 4) ? sq[2 + (uu >> 1)] : sq[uu >> 1]);
+                    const half2_t s2 = u2h2((uu & 1) ? __builtin_amdgcn_perm(sw, sw, 0x03020302u) : __builtin_amdgcn_perm(sw, sw, 0x01000100u));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t ww = wq[uu][c], w8 = ww >> 8;
+                        u32x4 b;
+                        b[0] = h22u((u2h2(and_or(ww, 0x000F000Fu, 0x64006400u)) - zlo) * s2);
+                        b[1] = h22u((u2h2(and_or(ww, 0x00F000F0u, 0x54005400u)) - zhi) * s2);
+                        b[2] = h22u((u2h2(and_or(w8, 0x000F000Fu, 0x64006400u)) - zlo) * s2);
+                        b[3] = h22u((u2h2(and_or(w8, 0x00F000F0u, 0x54005400u)) - zhi) * s2);
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma16(afr[(mi * GW + uu) * 4 + c], b, acc[mi]);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the slot has returned before it is overwritten
+                request(u + RD);
+                ++u;
+            }
+            // ---- the wk partial tiles meet in LDS; lane (n, kq) holds D[m = 4 kq + r][n] in acc[mi][r]
+            if (p.wk > 1) {
+                if (live) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) pbuf[(((it & 1) * 8 + wave) * MI + mi) * 64 + lane] = acc[mi];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (live) {
+                    const int f = wki + p.wk * lane;  // this wave's share of the tile's MI x 64 float4 slots
+                    if (f < 64 * MI) {
+                        const int mi = f >> 6, sl = f & 63;
+                        float4_t s = pbuf[(((it & 1) * 8 + twi * p.wk) * MI + mi) * 64 + sl];
+                        for (int j = 1; j < p.wk; ++j) s += pbuf[(((it & 1) * 8 + twi * p.wk + j) * MI + mi) * 64 + sl];
+                        float4_t* dst = ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64 + sl;
+                        *dst = ps > 0 ? *dst + s : s;
+                    }
+                }
+            } else if (live) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    float4_t* dst = ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64 + lane;
+                    *dst = ps > 0 ? *dst + acc[mi] : acc[mi];
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy requests past the end
+    if (p.wk > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- y: the wk waves of an owner share its tiles; item (m, n) of a tile from slot (m / 4) * 16 + n, element m % 4
+    for (int tl = wki; tl < ntile; tl += p.wk) {
+        const int row0 = (t0 + tl) * 16;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const float* src = reinterpret_cast<const float*>(ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int item = lane + 64 * q, ml = item >> 4, nn = item & 15;
+                const int m = 16 * mi + ml;
+                if (m < M && row0 + nn < p.N) p.y[(int64_t)m * p.N + row0 + nn] = (half_t)src[((ml >> 2) * 16 + nn) * 4 + (ml & 3)];
+            }
+        }
+    }
+}
+
+constexpr int piece_bytes(int GW) { return 16 * GW * 64 + 1024 + 256; }
+
+struct BatchPlan {
+    int MI, GW, RD, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max;
+    size_t ring, pbuf, ystage;
+};
+
+bool plan_batch(int M, int K, int N, int g, int gw_req, int rd_req, BatchPlan* out) {
+    if (M < 1 || M > 32 || N < 1 || K < 128 || K % 128 || g != 128) return false;
+    if ((int64_t)N * K / 2 >= ((int64_t)1 << 31) || (int64_t)M * K * 2 >= ((int64_t)1 << 31)) return false;  // 32-bit lane offsets
+    BatchPlan b;
+    b.MI = M > 16 ? 2 : 1;
+    const int G = K / 128;
+    b.GW = (gw_req == 4 || gw_req == 8) ? gw_req : (b.MI == 1 && G >= 64 ? 8 : 4);
+    if (b.MI * b.GW > 8) b.GW = 4;
+    int wk = 1;
+    while (wk < 8 && wk * b.GW < G) wk *= 2;
+    b.wk = wk;
+    b.wt = 8 / wk;
+    b.passes = (G + wk * b.GW - 1) / (wk * b.GW);
+    const int tiles = (N + 15) / 16;
+    const int want = (tiles + b.wt - 1) / b.wt;
+    b.blocks = want < 256 ? want : 256;
+    const int owners = b.blocks * b.wt;
+    b.tiles_base = tiles / owners;
+    b.tiles_rem = tiles % owners;
+    b.tiles_max = b.tiles_base + (b.tiles_rem ? 1 : 0);
+    b.pbuf = wk > 1 ? (size_t)2 * 8 * b.MI * 1024 : 0;
+    b.ystage = (size_t)b.wt * b.tiles_max * b.MI * 1024;
+    const size_t fixed = b.pbuf + b.ystage;
+    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : (b.GW == 4 ? 3 : 2);
+    while (rd > 1 && fixed + (size_t)8 * rd * piece_bytes(b.GW) > 160 * 1024) --rd;
+    if (fixed + (size_t)8 * rd * piece_bytes(b.GW) > 160 * 1024) return false;
+    if (b.GW == 8 && rd == 3) rd = 2;  // (not instantiated)
+    b.RD = rd;
+    b.ring = (size_t)8 * rd * piece_bytes(b.GW);
+    *out = b;
+    return true;
+}
+
+}  // namespace
+
+bool awq_gemv_batch_supports(int M, int K, int N, int g) {
+    BatchPlan b;
+    return plan_batch(M, K, N, g, 0, 0, &b);
+}
+
+// gw: 128-k groups per wave and pass (4 | 8, 0 = auto); depth: pieces in flight per wave (1 .. 3, 0 = auto)
+int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
+                          int M, int K, int N, int g, int ZW, int gw, int depth, hipStream_t st) {
+    BatchPlan b;
+    if (!plan_batch(M, K, N, g, gw, depth, &b)) return AWQ_ERR_UNSUPPORTED;
+    if (ZW * 8 < K / 128) return AWQ_ERR_BAD_SHAPE;
+    BatchParams p;
+    p.qweight = reinterpret_cast<const uint32_t*>(qweight);
+    p.qzeros = reinterpret_cast<const uint32_t*>(qzeros);
+    p.scales = reinterpret_cast<const half_t*>(scales);
+    p.x = reinterpret_cast<const half_t*>(x);
+    p.y = reinterpret_cast<half_t*>(y);
+    p.M = M; p.K = K; p.N = N;
+    p.KW = K / 8; p.ZW = ZW; p.SW = 8 * ZW;
+    p.G = K / 128;
+    p.wk = b.wk; p.wt = b.wt; p.passes = b.passes;
+    p.tiles_base = b.tiles_base; p.tiles_rem = b.tiles_rem; p.tiles_max = b.tiles_max;
+    p.ring_off = 0;
+    p.pbuf_off = (int)b.ring;
+    p.ystage_off = (int)(b.ring + b.pbuf);
+    const size_t lds = b.ring + b.pbuf + b.ystage;
+#define AWQ_BT_CASE(MIV, GWV, RDV)                                                                                                 \
+    if (b.MI == MIV && b.GW == GWV && b.RD == RDV) {                                                                               \
+        static std::atomic<unsigned long long> opted{0};                                                                           \
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_batch_kernel<MIV, GWV, RDV>), opted)) return AWQ_ERR_LAUNCH;   \
+        hipLaunchKernelGGL((awq_gemv_batch_kernel<MIV, GWV, RDV>), dim3((unsigned)b.blocks), dim3(512), lds, st, p);               \
+        return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;                                                          \
+    }
+    AWQ_BT_CASE(1, 4, 1) AWQ_BT_CASE(1, 4, 2) AWQ_BT_CASE(1, 4, 3) AWQ_BT_CASE(1, 8, 1) AWQ_BT_CASE(1, 8, 2)
+    AWQ_BT_CASE(2, 4, 1) AWQ_BT_CASE(2, 4, 2) AWQ_BT_CASE(2, 4, 3)
+#undef AWQ_BT_CASE
+    return AWQ_ERR_UNSUPPORTED;
+}

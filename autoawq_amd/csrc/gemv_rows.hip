@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                 for (int j = 0; j < 4; ++j) {
                     dj[sb][j] = u32x4{0x3C003C00u + lane, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
                     if constexpr (!(AWQ_ROWS_DBG & 2))
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(dj[sb][j]) : "v"(lds0 + (uint32_t)(((m * 4 + j) * Cq + cidx[s0 + sb]) * 16)));
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(dj[sb][j]) : "v"(lds0 + (uint32_t)(((m * 4 + j) * Cq + cidx[s0 + sb]) * 16)));
                 }
             if constexpr (!(AWQ_ROWS_DBG & 2)) {
 #pragma unroll

@@ -9,9 +9,8 @@ Drop-in contract kept (reference awq/modules/linear/gemv.py:27-197):
   * forward (:156-186): any leading dims, any float dtype (computed in fp16, cast back), bias added
     AFTER the cast back, in the input dtype (:183-185).
 What differs by design: the arithmetic runs in libawq_hip.so on the module's own buffers at every batch
-size (csrc/gemv_rows.hip, gemv_lds.hip, gemv_nk.hip up to 16 rows per launch; from 17 rows the bit-exact
-dequantise kernel + a dense fp16 GEMM, or -- opt-in -- csrc/gemm_regb.hip in its N-major form); there is no
-CPU path -- a non-HIP tensor raises.
+size (csrc/gemv_rows.hip up to 4 rows, csrc/gemv_batch.hip from 5 rows in launches of <= 32 -- gemv_lds.hip / gemv_nk.hip for the
+group sizes it does not take; from PREFILL_MIN_ROWS rows PREFILL_IMPL); there is no CPU path -- a non-HIP tensor raises.
 """
 import torch
 import torch.nn as nn
@@ -33,7 +32,10 @@ def dequant_matmul_nk(x2d, wt):
     return torch.matmul(x2d, wt.t())
 
 
-PREFILL_MIN_ROWS = 17  # the decode kernels serve 16 rows per launch (the reference switches to its batched kernel at 8: gemv.py:168)
+# Up to this many rows the call runs the decode / batched-decode kernels on the layout's own buffers (round 5: csrc/gemv_batch.hip takes any
+# M in launches of <= 32 rows, each streaming the matrix once; the reference switches to its batched kernel at 8 rows: gemv.py:168).
+# Above it: PREFILL_IMPL.
+PREFILL_MIN_ROWS = 129
 
 
 class WQLinear_GEMV(nn.Module):
@@ -87,7 +89,7 @@ class WQLinear_GEMV(nn.Module):
         if input_dtype != torch.float16:
             inputs = inputs.half()
         # Every batch size on this layout's OWN buffers (round 4: the second, GEMM-layout copy of every matrix that rounds 2-3
-        # kept for prefill is gone).  Up to 16 rows: the decode kernels.  From 17 rows: PREFILL_IMPL --
+        # kept for prefill is gone).  Below PREFILL_MIN_ROWS rows: the decode / batched-decode kernels.  From there: PREFILL_IMPL --
         #   "two_pass" (default)  dequantise (hand-written kernel, bit-exact) into a temporary + a dense fp16 GEMM: the reference's
         #                         own prefill route (gemm.py:48-54); 0.42 of the MFMA peak at M = 16384, ~45 us at M = 32;
         #   "fused"               the register-decoded MFMA GEMM in its N-major form (AWQ_GEMV_KERNEL_PREFILL): no temporary, but
@@ -101,7 +103,9 @@ class WQLinear_GEMV(nn.Module):
             except _lib.AwqHipError as e:  # K % 64, group sizes below 64
                 if e.code != _lib.ERR_UNSUPPORTED:
                     raise
-        if out is None and rows < PREFILL_MIN_ROWS:
+        decode = rows <= 16 or (rows < PREFILL_MIN_ROWS and ops.gemv_auto_kernel(rows, self.in_features, self.out_features, self.group_size)
+                                == ops.GEMV_KERNEL_BATCH)  # (the older decode kernels serve 16 rows per launch: not worth chunking)
+        if out is None and decode:
             try:
                 out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
             except _lib.AwqHipError as e:  # a shape no decode kernel of this layout takes (K % 128 with odd group sizes)

@@ -259,6 +259,14 @@ def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
                                     _stream())
         _lib.check(rc, "awq_gemv_forward")
         return y
+    kern = flags & 0xF
+    if kern == GEMV_KERNEL_BATCH or (kern == 0 and L.awq_gemv_auto_kernel(M, K, N, group_size) == GEMV_KERNEL_BATCH):
+        # round 5: the batched kernel (csrc/gemv_batch.hip) takes ANY M in one call (launches of <= 32 rows inside the library)
+        with torch.cuda.device(x2d.device):
+            rc = L.awq_gemv_forward(_ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), M, K, N, group_size, ZW, flags,
+                                    _stream())
+        _lib.check(rc, "awq_gemv_forward")
+        return y
     chunk = 16
     while chunk > 1 and L.awq_gemv_lds_bytes(chunk, K, ZW) > 160 * 1024:
         chunk //= 2
@@ -271,8 +279,14 @@ def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     return y
 
 
+def gemv_auto_kernel(M, K, N, group_size):
+    """Which AWQ_GEMV_KERNEL_* awq_gemv_forward's AUTO dispatch takes for this shape (host only; -1: none)."""
+    return int(_lib.lib().awq_gemv_auto_kernel(M, K, N, group_size))
+
+
 GEMV_EX_SILU_PAIRS = 1  # include/awq_hip.h AWQ_GEMV_EX_SILU_PAIRS
 GEMV_KERNEL_PREFILL = 4  # include/awq_hip.h AWQ_GEMV_KERNEL_PREFILL
+GEMV_KERNEL_BATCH = 5    # include/awq_hip.h AWQ_GEMV_KERNEL_BATCH
 
 
 def gemv_forward_ex(x2d, qweight, scales, qzeros, group_size, norm_weight=None, norm_eps=0.0, add_residual=None,

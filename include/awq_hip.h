@@ -176,10 +176,10 @@ AWQ_EXPORT int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweigh
 
 /* Replaces awq_ext.gemv_forward_cuda(x, qweight, scales, qzeros, group_size) (M <= 8) and
  * awq_ext.gemmv2_forward_cuda(..., group_size, split_k_iters) (awq/modules/linear/gemv.py:168-180).
- * y [M, N] fp16 = x [M, K] fp16 @ dequant(qweight)^T, fp32 accumulation; decode kernels: 1 <= M <= 16 per call and
- * awq_gemv_lds_bytes(M, K, ZW) <= 160 KiB (the host wrapper chunks larger M where the prefill kernel refuses); no bias (the
- * reference adds it afterwards, gemv.py:185).  AUTO (M <= 16): M <= 2 (and M <= 4 for K <= 6144)
- * takes the row-streaming kernel
+ * y [M, N] fp16 = x [M, K] fp16 @ dequant(qweight)^T, fp32 accumulation; no bias (the reference adds it afterwards,
+ * gemv.py:185).  AUTO: from M = 5 the batched kernel AWQ_GEMV_KERNEL_BATCH (any M in one call) wherever it takes the shape
+ * (group_size 128); the older decode kernels below serve 1 <= M <= 16 per call with awq_gemv_lds_bytes(M, K, ZW) <= 160 KiB
+ * (the host wrapper chunks).  M <= 2 (and M <= 4 for K <= 6144) takes the row-streaming kernel
  * (gemv_rows.hip: a wave instruction reads 1 KiB of one row, activations in registers, no cross-CU exchange; needs
  * group_size % 128 == 0 and K <= 65536); 5 <= M with N >= 8192 and M K <= 32768 the LDS-streaming MFMA kernel (gemv_lds.hip:
  * weights by LDS-DMA, 1 KiB of two rows per instruction, into v_mfma_f32_16x16x32_f16); everything else up to M = 16 the 16-row
@@ -190,6 +190,10 @@ AWQ_EXPORT int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweigh
 #define AWQ_GEMV_KERNEL_TILE16 1u /* 16 rows per block through v_mfma_f32_16x16x32_f16, M <= 16 */
 #define AWQ_GEMV_KERNEL_ROWS 2u   /* row-streaming kernel (1 KiB of one row per wave instruction, activations in registers), M <= 4 */
 #define AWQ_GEMV_KERNEL_LDS 3u    /* weights through LDS by DMA into MFMA 16x16x32, 2 <= M <= 16 with M K <= 32768; _SPLITK: waves per tile */
+#define AWQ_GEMV_KERNEL_BATCH 5u  /* round 5: ANY M in one call (launches of <= 32 rows), group_size 128, K % 128 == 0: activations as MFMA A
+                                     fragments in registers, a tile's K range split over the eight waves of ONE block (no exchange, no
+                                     workspace), weights by LDS-DMA in row-contiguous pieces (gemv_batch.hip).  AUTO takes it from M = 5.
+                                     _UNIT: 128-k groups per wave and pass (4 | 8), _SPLITK: pieces in flight per wave (1 .. 3) */
 #define AWQ_GEMV_KERNEL_PREFILL 4u /* any M in ONE call: the register-decoded MFMA GEMM on this layout's own buffers (gemm_regb.hip, NK
                                      form; K % 64 == 0, group_size % 64 == 0, N % 4 == 0); _NLOG = 2: 256-row tiles.  EXPLICIT only:
                                      measured 0.29 of the MFMA peak at M = 16384 (dequantise + dense GEMM: 0.42) and latency-bound

@@ -239,8 +239,8 @@ def test_hand_counted_asm_loads_are_hazard_safe():
 
 
 def test_gemv_layout_auto_dispatch_table_host_only():
-    """awq_gemv_auto_kernel (host only): the row-streaming kernel at batches 1 - 2 (3 - 4 while K <= 6144), the LDS-DMA
-    -> MFMA kernel for 5..16 rows of tall matrices within its LDS budget, the 16-row tile kernel otherwise -- DESIGN.md 3.0 / 3.0b."""
+    """awq_gemv_auto_kernel (host only): the row-streaming kernel at batches 1 - 2 (3 - 4 while K <= 6144), from five rows the
+    batched kernel (round 5, group size 128), the 16-row tile kernel otherwise -- DESIGN.md 3.0 / 3.0c."""
     from autoawq_amd import _lib
 
     q = lambda M, K, N, g=128: _lib.lib().awq_gemv_auto_kernel(M, K, N, g)
@@ -249,8 +249,10 @@ def test_gemv_layout_auto_dispatch_table_host_only():
         assert q(1, K, N) == ROWS, (K, N)
     assert q(2, 4096, 12288) == ROWS and q(2, 11008, 4096) == ROWS   # batch 2: ahead of the tile kernel on every 7B shape (r03 sweep)
     assert q(3, 4096, 22016) == ROWS and q(4, 4096, 11008) == ROWS and q(4, 11008, 4096) == TILE and q(3, 8192, 1280) == TILE
-    assert q(8, 4096, 11008) == LDS and q(8, 4096, 22016) == LDS and q(16, 4096, 11008) == TILE  # M K <= 32768
-    assert q(8, 4096, 4096) == TILE
+    BATCH = 5  # round 5: csrc/gemv_batch.hip from five rows at group size 128, any M in one call
+    assert q(8, 4096, 11008) == BATCH and q(8, 4096, 22016) == BATCH and q(16, 4096, 11008) == BATCH and q(8, 4096, 4096) == BATCH
+    assert q(5, 11008, 4096) == BATCH and q(32, 8192, 1280) == BATCH and q(64, 4096, 11008) == BATCH and q(100, 3584, 8192) == BATCH
+    assert q(8, 4096, 11008, 64) == TILE and q(17, 4096, 11008, 64) == -1  # other group sizes: the 16-row kernels (the wrapper chunks)
     assert q(1, 4096, 4096, 64) == TILE       # groups below 128: the tile kernel
     assert q(0, 4096, 4096) == -1 and q(1, 4100, 4096) == -1
 
@@ -283,7 +285,7 @@ def test_hand_counted_waits_of_the_register_decoded_kernels_hold_in_the_generate
     spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    for f, least in (("gemm_regb.hip", 6), ("gemm_skinny.hip", 2), ("gemv_lds.hip", 3), ("gemv_rows.hip", 64)):
+    for f, least in (("gemm_regb.hip", 6), ("gemm_skinny.hip", 2), ("gemv_lds.hip", 3), ("gemv_rows.hip", 64), ("gemv_batch.hip", 8)):
         name, kernels, visits, bad = mod.audit_vmcnt(os.path.join(ROOT, "autoawq_amd", "csrc", f))
         assert not bad, (name, bad[:5])
         assert kernels >= least and visits > 0, (name, kernels, visits)

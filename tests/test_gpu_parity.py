@@ -493,6 +493,11 @@ def gemv_rows_takes(M, K, g):
     return g % 128 == 0 and K % g == 0 and K >= 128 and (M <= 2 or (M <= 4 and K <= 6144))
 
 
+def gemv_batch_takes(M, K, g):
+    """AUTO dispatch of awq_gemv_forward from five rows (round 5): csrc/gemv_batch.hip wherever it takes the shape"""
+    return g == 128 and M >= 5 and K % 128 == 0 and K >= 128
+
+
 @pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (11008, 4096, 128), (4096, 11008, 128), (1024, 72, 64),
                                    (512, 40, 32), (2048, 200, 2048), (256, 16, 128)])
 @pytest.mark.parametrize("M", [1, 2, 5, 8, 16, 33])
@@ -506,9 +511,8 @@ def test_gemv_layout_vs_oracle(ops, oracle, K, N, g, M):
     tile16 = ops.gemm_flags(kernel=GEMV_KERNEL_TILE16)
     for flags in (0, tile16, tile16 | ops.gemm_flags(waves=4, unit=8), tile16 | ops.gemm_flags(waves=16, unit=4)):
         y = ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=flags)
-        if flags == 0 and (M <= 2 or (M <= 16 and K <= 4096)):  # (wider K: the wrapper splits the batch to fit the tile kernel's LDS)
-            lds = g == 128 and 5 <= M <= 16 and N >= 8192 and M * K <= 32768
-            assert ops.last_kernel() == ("gemv_rows" if gemv_rows_takes(M, K, g) else ("gemv_lds" if lds else "gemv_nk"))
+        if flags == 0 and (M <= 2 or gemv_batch_takes(M, K, g) or (M <= 16 and K <= 4096)):  # (wider K: the wrapper splits the batch to fit the tile kernel's LDS)
+            assert ops.last_kernel() == ("gemv_rows" if gemv_rows_takes(M, K, g) else ("gemv_batch" if gemv_batch_takes(M, K, g) else "gemv_nk"))
         elif flags:
             assert ops.last_kernel() == "gemv_nk"
         assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemv K{K} N{N} g{g} M{M} f{flags:x}", wsigma=wsig)
@@ -703,10 +707,10 @@ def test_gemv_lds_kernel_vs_oracle(ops, oracle, K, N, M):
         y1, y2 = ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=lds).float(), ops.gemv_forward(2 * x.cuda(), qwc, scc, qzc, g, flags=lds).float()
         normal = y1.abs() >= 2.0 ** -13  # (an fp16 SUBNORMAL output is rounded on a coarser grid than its double)
         assert torch.equal(y2[normal], 2 * y1[normal]), "f(2x) != 2 f(x)"
-    # AUTO: this kernel from five rows on wide matrices, else the row-streaming / tile kernels
+    # AUTO (round 5): the batched kernel from five rows, else the row-streaming / tile kernels; this kernel stays reachable by flag
     ops.gemv_forward(x.cuda(), qwc, scc, qzc, g)
-    want = "gemv_rows" if gemv_rows_takes(M, K, g) else ("gemv_lds" if (takes and M >= 5 and N >= 8192) else "gemv_nk")
-    if M <= 2 or K <= 4096:
+    want = "gemv_rows" if gemv_rows_takes(M, K, g) else ("gemv_batch" if gemv_batch_takes(M, K, g) else "gemv_nk")
+    if M <= 2 or M >= 5 or K <= 4096:
         assert ops.last_kernel() == want, (ops.last_kernel(), want)
 
 
@@ -717,6 +721,67 @@ def test_gemv_rows_refuses_what_it_cannot_take(ops):
         qw, qz, sc, x = gemv_case(K, N, g, M, seed=1)
         with pytest.raises(Exception, match="code -3"):
             ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=rows)
+        ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g)
+        assert ops.last_kernel() == ("gemv_batch" if gemv_batch_takes(M, K, g) else "gemv_nk")
+
+
+GEMV_KERNEL_BATCH = 5
+BATCH_SHAPES = [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096),       # the four 7B Linears
+                (8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192),           # the four 70B TP = 8 shards
+                (4096, 11008), (2048, 4099), (1024, 200), (256, 16), (14336, 4096), (16512, 72)]
+
+
+@pytest.mark.parametrize("K,N", BATCH_SHAPES)
+def test_gemv_batch_kernel_vs_oracle(ops, oracle, K, N):
+    """csrc/gemv_batch.hip (GEMV layout, round 5: activations as MFMA A fragments in registers, a tile's K range split over the
+    eight waves of one block, weights by LDS-DMA): the four 7B and the four 70B-shard shapes, ragged N, one and several passes
+    over K (11008: two / three, 14336, 16512: three / five), few tiles (N = 16, 72, 200: idle owners at the barriers), every batch
+    5 .. 64 at the benched shape and a ragged sample elsewhere (17, 33 ...: two 16-row tiles with a ragged second one, balanced
+    chunks above 32), both piece widths (128-k groups per wave: 4 | 8) and every ring depth; against the CPU oracle (the
+    reference's dequantised fp16 weights, fp32 product), bitwise reproducible, one-hot rows select rows of the bit-exact W, zero
+    in -> zero out, f(2x) == 2 f(x)."""
+    g = 128
+    all_m = list(range(5, 65)) if (K, N) == (4096, 11008) else [5, 8, 13, 16, 17, 24, 31, 32, 33, 48, 64]
+    if K * N > 4096 * 12288:
+        all_m = [5, 16, 17, 32, 64]
+    qw, qz, sc, xall = gemv_case(K, N, g, 64, seed=K + 7 * N)
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+    qwc, qzc, scc, xc = qw.cuda(), qz.cuda(), sc.cuda(), xall.cuda()
+    Wt = ops.dequantize_weights_gemv(qwc, scc, qzc, g)
+    y32_all, _ = oracle.matmul(xall.numpy(), W)
+    wsig_all = oracle.weight_rounding_sigma(xall.numpy(), W)
+    bt = ops.gemm_flags(kernel=GEMV_KERNEL_BATCH)
+    for M in all_m:
+        x = xc[64 - M:]  # (a row offset: chunk boundaries of the 33 .. 64-row calls fall elsewhere for every M)
+        y32, wsig = y32_all[64 - M:], wsig_all[64 - M:]
+        variants = [0] if M not in (5, 16, 17, 32, 64) else [0, ops.gemm_flags(unit=4, splitk=1), ops.gemm_flags(unit=4, splitk=2), ops.gemm_flags(unit=4, splitk=3),
+                                                             ops.gemm_flags(unit=8, splitk=1), ops.gemm_flags(unit=8, splitk=2)]
+        for f in variants:
+            y = ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt | f)
+            assert ops.last_kernel() == "gemv_batch"
+            assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"batch K{K} N{N} M{M} f{f:x}", wsigma=wsig)
+            assert torch.equal(y, ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt | f)), "not bitwise reproducible"
+        ya = ops.gemv_forward(x, qwc, scc, qzc, g)  # AUTO takes it from five rows
+        assert ops.last_kernel() == "gemv_batch" and torch.equal(ya, ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt))
+    for M in (5, 16, 20, 64):
+        e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+        ks = (torch.arange(M, device="cuda") * 977 + K - 5) % K
+        e[torch.arange(M, device="cuda"), ks] = 1.0
+        assert torch.equal(ops.gemv_forward(e, qwc, scc, qzc, g, flags=bt), Wt.t()[ks]), "one-hot rows must select rows of W"
+        assert int(ops.gemv_forward(torch.zeros_like(e), qwc, scc, qzc, g, flags=bt).abs().max()) == 0
+        x = xc[:M]
+        y1, y2 = ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt).float(), ops.gemv_forward(2 * x, qwc, scc, qzc, g, flags=bt).float()
+        normal = y1.abs() >= 2.0 ** -13
+        assert torch.equal(y2[normal], 2 * y1[normal]), "f(2x) != 2 f(x)"
+
+
+def test_gemv_batch_refuses_what_it_cannot_take(ops):
+    """group sizes other than 128: AWQ_ERR_UNSUPPORTED when forced, the older decode kernels on AUTO"""
+    bt = ops.gemm_flags(kernel=GEMV_KERNEL_BATCH)
+    for K, N, g, M in [(1024, 72, 64, 8), (512, 40, 32, 8), (2048, 200, 2048, 8)]:
+        qw, qz, sc, x = gemv_case(K, N, g, M, seed=1)
+        with pytest.raises(Exception, match="code -3"):
+            ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=bt)
         ops.gemv_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g)
         assert ops.last_kernel() == "gemv_nk"
 

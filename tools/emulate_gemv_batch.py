@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""CPU model of csrc/gemv_batch.hip's index algebra (no GPU): the DMA lane -> (row, chunk) map with its global-side XOR
+swizzle, the LDS image of a piece, the fragment reads, the nibble decode order against the pair-permuted activations, the
+MFMA operand / accumulator layouts (those of csrc/gemv_lds.hip, which the GPU suite pins), the K split over the waves of a
+block with passes, the partial-tile reduction and the final store map.  It follows the kernel's expressions line by line and
+compares the result with x @ dequant(W)^T; tests/test_gemv_batch_model.py runs it on ragged shapes."""
+import numpy as np
+
+
+def plan(M, K, N, gw_req=0, rd_req=0, blocks_cap=256):
+    """plan_batch() of csrc/gemv_batch.hip"""
+    MI = 2 if M > 16 else 1
+    G = K // 128
+    GW = gw_req if gw_req in (4, 8) else (8 if (MI == 1 and G >= 64) else 4)
+    if MI * GW > 8:
+        GW = 4
+    wk = 1
+    while wk < 8 and wk * GW < G:
+        wk *= 2
+    wt = 8 // wk
+    passes = -(-G // (wk * GW))
+    tiles = -(-N // 16)
+    want = -(-tiles // wt)
+    blocks = min(want, blocks_cap)  # (the launcher: 256 = one block per CU; the model lowers it to reach several tiles per owner)
+    owners = blocks * wt
+    tb, tr = tiles // owners, tiles % owners
+    return dict(MI=MI, GW=GW, wk=wk, wt=wt, passes=passes, blocks=blocks, tiles_base=tb, tiles_rem=tr, tiles_max=tb + (1 if tr else 0),
+                RD=rd_req or 2, G=G)
+
+
+def decode_word(ww, z, s):
+    """B fragment of one packed word: 8 halfs in the register order (n0, n4, n1, n5, n2, n6, n3, n7), (w - z) * s in fp16"""
+    nib = [(ww >> (4 * i)) & 15 for i in range(8)]
+    order = [0, 4, 1, 5, 2, 6, 3, 7]
+    d = np.array([nib[i] - z for i in order], dtype=np.float16)  # exact
+    return (d * np.float16(s)).astype(np.float16)
+
+
+def run(x, qweight, qzeros, scales, gw_req=0, rd_req=0, blocks_cap=None):
+    M, K = x.shape
+    N, KW = qweight.shape
+    ZW = qzeros.shape[1]
+    SW = scales.shape[1]
+    p = plan(M, K, N, gw_req, rd_req, blocks_cap or 256)
+    MI, GW, wk, wt, RD, G = p["MI"], p["GW"], p["wk"], p["wt"], p["RD"], p["G"]
+    PIECE_W = 16 * GW * 64
+    PIECE_B = PIECE_W + 1024 + 256
+    CPR, RPI = 4 * GW, 64 // (4 * GW)
+    rowbytes = KW * 4
+    qwb = qweight.astype(np.uint32).view(np.uint8).reshape(-1)
+    qzb = qzeros.astype(np.uint32).view(np.uint8).reshape(-1)
+    scb = scales.astype(np.float16).view(np.uint8).reshape(-1)
+    xh = x.astype(np.float16)
+    y = np.full((M, N), np.nan, dtype=np.float32)
+    lanes = np.arange(64)
+    n_l, kq_l = lanes & 15, lanes >> 4
+    for block in range(p["blocks"]):
+        ystage = {}
+        ring = {w: [bytearray(PIECE_B) for _ in range(RD)] for w in range(8)}
+        info = {}
+        for wave in range(8):
+            wki, twi = wave % wk, wave // wk
+            owner = twi * p["blocks"] + block
+            t0 = owner * p["tiles_base"] + min(owner, p["tiles_rem"])
+            ntile = p["tiles_base"] + (1 if owner < p["tiles_rem"] else 0)
+            info[wave] = (wki, twi, t0, ntile)
+
+        def request(wave, u):
+            wki, twi, t0, ntile = info[wave]
+            nunit = ntile * p["passes"]
+            live = u < nunit
+            uu = u if live else 0
+            nt1 = max(ntile, 1)
+            ps, tl = uu // nt1, uu % nt1
+            g0 = (ps * wk + wki) * GW
+            row0 = (t0 + tl) * 16 if live else 0
+            slot = ring[wave][u % RD]
+            for i in range(GW):
+                for lane in range(64):
+                    r = i * RPI + lane // CPR
+                    pos = lane % CPR
+                    c = (pos & 16) | ((pos ^ r) & 15)
+                    byte = min(g0 * 64 + 16 * c, rowbytes - 16)
+                    voff = (min(row0 + r, N - 1) * rowbytes + byte) if live else 0
+                    slot[1024 * i + 16 * lane:1024 * i + 16 * lane + 16] = qwb[voff:voff + 16].tobytes()
+            for lane in range(64):
+                n = lane & 15
+                r = min(row0 + n, N - 1)
+                sbyte = min((2 * g0) & ~15, SW * 2 - 16)
+                vs = r * SW * 2 + sbyte
+                slot[PIECE_W + 16 * lane:PIECE_W + 16 * lane + 16] = scb[vs:vs + 16].tobytes()
+                zword = min(g0 >> 3, ZW - 1)
+                vz = (r * ZW + zword) * 4
+                slot[PIECE_W + 1024 + 4 * lane:PIECE_W + 1024 + 4 * lane + 4] = qzb[vz:vz + 4].tobytes()
+
+        def afrag(wave, ps):
+            """afr[mi][u][c] per lane: 8 halfs in the permuted order, zero where invalid"""
+            wki = info[wave][0]
+            g0 = (ps * wk + wki) * GW
+            out = np.zeros((MI, GW, 4, 64, 8), dtype=np.float16)
+            for mi in range(MI):
+                for u in range(GW):
+                    for c in range(4):
+                        for lane in range(64):
+                            n, kq = lane & 15, lane >> 4
+                            m = min(16 * mi + n, M - 1)
+                            kk = min(128 * (g0 + u) + 32 * kq + 8 * c, K - 8)
+                            d = xh[m, kk:kk + 8]
+                            valid = (16 * mi + n < M) and (g0 + u < G)
+                            if valid:
+                                out[mi, u, c, lane] = d[[0, 4, 1, 5, 2, 6, 3, 7]]
+            return out
+
+        units = {w: 0 for w in range(8)}
+        for wave in range(8):
+            for d in range(RD):
+                request(wave, d)
+        for ps in range(p["passes"]):
+            A = {w: afrag(w, ps) for w in range(8)}
+            for tl in range(p["tiles_max"]):
+                pbuf = {}
+                for wave in range(8):
+                    wki, twi, t0, ntile = info[wave]
+                    live = tl < ntile
+                    if not live:
+                        continue
+                    g0 = (ps * wk + wki) * GW
+                    u = units[wave]
+                    slot = ring[wave][u % RD]
+                    acc = np.zeros((MI, 16, 16), dtype=np.float32)  # D[m][n]
+                    for uu in range(GW):
+                        bfr = np.zeros((4, 64, 8), dtype=np.float16)
+                        for lane in range(64):
+                            n, kq = lane & 15, lane >> 4
+                            zw = int(np.frombuffer(bytes(slot[PIECE_W + 1024 + 4 * lane:PIECE_W + 1024 + 4 * lane + 4]), dtype=np.uint32)[0])
+                            sq = np.frombuffer(bytes(slot[PIECE_W + 16 * lane:PIECE_W + 16 * lane + 16]), dtype=np.float16)
+                            q = 4 * uu + kq
+                            pos = (q & 16) | ((q ^ n) & 15)
+                            off = n * (CPR * 16) + pos * 16
+                            wq = np.frombuffer(bytes(slot[off:off + 16]), dtype=np.uint32)
+                            gi = (g0 & 7) + uu
+                            z = (zw >> (4 * gi)) & 15
+                            if GW == 8:
+                                s = sq[uu]
+                            else:
+                                s = sq[(4 if (g0 & 4) else 0) + uu]
+                            for c in range(4):
+                                bfr[c, lane] = decode_word(int(wq[c]), z, s)
+                        for c in range(4):
+                            # v_mfma_f32_16x16x32_f16: D[i][j] += sum_{kq, e} A[lane (i, kq)][e] * B[lane (j, kq)][e]
+                            Bm = bfr[c].astype(np.float32).reshape(4, 16, 8)  # [kq][j][e]
+                            for mi in range(MI):
+                                Am = A[wave][mi, uu, c].astype(np.float32).reshape(4, 16, 8)  # [kq][i][e]
+                                acc[mi] += np.einsum("kie,kje->ij", Am, Bm)
+                    request(wave, u + RD)
+                    units[wave] = u + 1
+                    pbuf[wave] = acc
+                for twi in range(wt):
+                    ws = [twi * wk + j for j in range(wk)]
+                    if ws[0] not in pbuf:
+                        continue
+                    s = pbuf[ws[0]].copy()
+                    for w in ws[1:]:
+                        s += pbuf[w]
+                    key = (twi, tl)
+                    ystage[key] = ystage[key] + s if ps > 0 else s
+        for wave in range(8):
+            wki, twi, t0, ntile = info[wave]
+            for tl in range(wki, ntile, wk):
+                row0 = (t0 + tl) * 16
+                t = ystage[(twi, tl)]
+                for mi in range(MI):
+                    for ml in range(16):
+                        for nn in range(16):
+                            m = 16 * mi + ml
+                            if m < M and row0 + nn < N:
+                                assert np.isnan(y[m, row0 + nn]), "an output written twice"
+                                y[m, row0 + nn] = t[mi, ml, nn]
+    assert not np.isnan(y).any(), "an output never written"
+    return y.astype(np.float16)
+
+
+def reference(x, qweight, qzeros, scales):
+    """x @ dequant^T with the reference's dequantised fp16 weights ((w - z) * s, awq/utils/packing_utils.py:98-100)"""
+    N, KW = qweight.shape
+    K = KW * 8
+    q = qweight.astype(np.uint32)
+    w = np.stack([(q >> (4 * i)) & 15 for i in range(8)], axis=-1).reshape(N, K).astype(np.int32)
+    G = K // 128
+    qz = qzeros.astype(np.uint32)
+    z = np.stack([(qz >> (4 * i)) & 15 for i in range(8)], axis=-1).reshape(N, -1)[:, :G].astype(np.int32)
+    s = scales[:, :G].astype(np.float16)
+    wd = ((w - np.repeat(z, 128, axis=1)).astype(np.float16) * np.repeat(s, 128, axis=1)).astype(np.float16)
+    return x.astype(np.float32) @ wd.astype(np.float32).T
+
+
+def random_case(M, K, N, seed=0):
+    rng = np.random.default_rng(seed)
+    G = K // 128
+    ZW = -(-G // 8)
+    qweight = rng.integers(0, 2**32, size=(N, K // 8), dtype=np.uint64).astype(np.uint32)
+    qzeros = rng.integers(0, 2**32, size=(N, ZW), dtype=np.uint64).astype(np.uint32)
+    scales = np.zeros((N, ZW * 8), dtype=np.float16)
+    scales[:, :G] = (rng.random((N, G)) * 0.02 + 0.005).astype(np.float16)
+    x = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    return x, qweight, qzeros, scales
+
+
+if __name__ == "__main__":
+    import sys
+
+    cases = [(5, 512, 40, 0, 0), (8, 1024, 72, 0, 0), (16, 1280, 33, 4, 0), (20, 768, 48, 0, 0), (32, 1152, 100, 0, 0), (7, 2432, 24, 8, 0),
+             (9, 4224, 20, 4, 0), (6, 1024, 200, 0, 1), (17, 4224, 88, 0, 2), (12, 8320, 56, 8, 1)]
+    bad = 0
+    for M, K, N, gw, cap in cases:
+        x, qw, qz, sc = random_case(M, K, N, seed=M + K + N)
+        y = run(x, qw, qz, sc, gw_req=gw, blocks_cap=cap).astype(np.float32)
+        ref = reference(x, qw, qz, sc)
+        err = np.abs(y - ref).max()
+        tol = 2e-3 * np.abs(ref).max() + 1e-3
+        ok = err <= tol
+        bad += not ok
+        print(f"M={M} K={K} N={N} gw={gw} plan={plan(M, K, N, gw, 0, cap or 256)} max err {err:.4g} (max |ref| {np.abs(ref).max():.3g}) {'ok' if ok else 'MISMATCH'}")
+    sys.exit(1 if bad else 0)

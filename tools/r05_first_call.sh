@@ -23,6 +23,6 @@ step prefill_attn 400 python tools/experimental/prefill_attention/probe.py
 step mall_prefetch 300 python tools/experimental/mall_prefetch/probe.py
 # the GPU suite on 8 worker processes (is it xdist-safe on one GPU, and how long does it take?); the round-end run stays the
 # driver's exact single-process command
-step suite_xdist8 900 python -m pytest tests/ -q -m gpu -p no:cacheprovider -n 8
+step suite_xdist8 900 python -m pytest tests/ -q -m gpu -p no:cacheprovider -n 8 --durations=120
 tail -n 3 "$OUT"/*.txt | tail -n 60
 cat "$OUT/summary.txt"
