@@ -64,6 +64,8 @@ SIGNATURES = {
     "awq_rope_kv_append": (c_int, [c_void_p] * 7 + [c_int64] * 8 + [c_void_p]),
     "awq_decode_attention_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "awq_decode_attention": (c_int, [c_void_p] * 5 + [c_int64] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
+    "awq_repack_gemv_to_gemm": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_void_p]),
+    "awq_prefill_attention": (c_int, [c_void_p] * 4 + [c_int64] * 7 + [c_float, c_float, c_void_p, c_void_p]),
     "awq_decode_attention_ex": (c_int, [c_void_p] * 5 + [c_int64] * 7 + [c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "awq_decode_attention_rope": (c_int, [c_void_p] * 7 + [c_int64] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
     "awq_moe_route": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_int64, c_int, c_int64, c_void_p]),

@@ -22,6 +22,11 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
          "-DAWQ_BUILDING_LIB", "-I" + os.path.join(ROOT, "include")]
 
 
+# per-file extras: the prefill attention takes its running maxima with plain v_max_f32 (-fno-honor-nans drops the canonicalising
+# v_max(x, x) hipcc puts in front of every fmaxf: +3 .. 5 %, profiles/r05_first_call/prefill_attn.txt); masked scores are -inf, never NaN
+EXTRA = {"prefill_attn.hip": ["-fno-honor-nans"]}
+
+
 def sources():
     return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
 
@@ -38,7 +43,7 @@ def compile_one(src, force, verbose, save_temps):
     sp = os.path.join(HERE, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), headers_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ["-c", sp, "-o", obj]
     if save_temps:
         cmd += ["-save-temps=obj"]
     if verbose:

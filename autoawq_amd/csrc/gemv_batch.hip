@@ -55,7 +55,20 @@ struct BatchParams {
     int passes;      // ceil(G / (wk * GW))
     int tiles_base, tiles_rem, tiles_max;  // tiles per owner: base (+1 for the first rem owners)
     int ring_off, pbuf_off, ystage_off;    // LDS byte offsets
+    unsigned long long* trace;             // debug builds only (tools/trace_gemv_batch.py)
 };
+
+// Debug builds only (tools/trace_gemv_batch.py): -DAWQ_GEMV_TRACE stamps the phases of every wave (kept in registers, stored after the
+// stream has drained); -DAWQ_BT_DBG=bits switches parts off (results are wrong by design): 1 = every lane requests the SAME 16 bytes of
+// x (the request count stays, the 16-rows-x-64-bytes scatter goes), 2 = no decode / MFMA, 4 = no partial-tile exchange (no barrier).
+#ifndef AWQ_BT_DBG
+#define AWQ_BT_DBG 0
+#endif
+#ifdef AWQ_GEMV_TRACE
+#define BT_STAMP(slot) ts[slot] = wall_clock64()
+#else
+#define BT_STAMP(slot) do { } while (0)
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -100,6 +113,10 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     const int nunit = ntile * p.passes;  // live units of this wave, flat: u = pass * ntile + tile
     const int ring = p.ring_off + wave * RD * PIECE_B;
     const int rowbytes = p.KW * 4;
+#ifdef AWQ_GEMV_TRACE
+    unsigned long long ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    BT_STAMP(0);
 
     // ---- request flat unit u into ring slot u % RD (past the end: clamped addresses -- the counted waits need the requests)
     auto request = [&](int u) {
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 for (int c = 0; c < 4; ++c) {
                     const int m = min(16 * mi + n, M - 1);
                     const int kk = min(128 * (g0 + u) + 32 * kq + 8 * c, p.K - 8);
-                    AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (uint32_t)((m * p.K + kk) * 2), p.x);
+                    AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (AWQ_BT_DBG & 1) ? 0u : (uint32_t)((m * p.K + kk) * 2), p.x);
                 }
     };
     auto permute_a = [&](int ps) {
@@ -172,8 +189,11 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     load_a(0);
 #pragma unroll
     for (int d = 0; d < RD; ++d) request(d);
+    BT_STAMP(1);
     wait_a(std::integral_constant<int, LDM * RD>{});  // everything older than the ring requests: the activations
+    BT_STAMP(2);
     permute_a(0);
+    BT_STAMP(3);
 
     // ---- stream
     float4_t* pbuf = reinterpret_cast<float4_t*>(smem + p.pbuf_off);      // [2][8 waves][MI][64 lanes]
@@ -193,6 +213,9 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             for (int mi = 0; mi < MI; ++mi) acc[mi] = float4_t{0.f, 0.f, 0.f, 0.f};
             if (live) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM * (RD - 1)) : "memory");
+#ifdef AWQ_GEMV_TRACE
+                if (u < 3) ts[4 + 2 * u] = wall_clock64();
+#endif
                 const unsigned char* slot = smem + ring + (u % RD) * PIECE_B;
                 const uint32_t zw = *reinterpret_cast<const uint32_t*>(slot + PIECE_W + 1024 + 4 * lane);
                 const u32x4 sq = *reinterpret_cast<const u32x4*>(slot + PIECE_W + 16 * lane);  // 8 scales: groups (g0 & ~7) ..
@@ -203,6 +226,10 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                     const int pos = (q & 16) | ((q ^ n) & 15);
                     wq[uu] = *reinterpret_cast<const u32x4*>(slot + n * (CPR * 16) + pos * 16);
                 }
+                if constexpr (AWQ_BT_DBG & 2) {
+#pragma unroll
+                    for (int uu = 0; uu < GW; ++uu) acc[0] += __builtin_bit_cast(float4_t, wq[uu]) + __builtin_bit_cast(float4_t, sq) + (float)zw;
+                } else
 #pragma unroll
                 for (int uu = 0; uu < GW; ++uu) {
                     const int gi = (g0 & 7) + uu;  // index of the group in the zero word and in the 8-scale chunk
@@ -226,10 +253,13 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the slot has returned before it is overwritten
                 request(u + RD);
+#ifdef AWQ_GEMV_TRACE
+                if (u < 3) ts[5 + 2 * u] = wall_clock64();
+#endif
                 ++u;
             }
             // ---- the wk partial tiles meet in LDS; lane (n, kq) holds D[m = 4 kq + r][n] in acc[mi][r]
-            if (p.wk > 1) {
+            if (p.wk > 1 && !(AWQ_BT_DBG & 4)) {
                 if (live) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) pbuf[(((it & 1) * 8 + wave) * MI + mi) * 64 + lane] = acc[mi];
@@ -254,6 +284,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             }
         }
     }
+    BT_STAMP(10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy requests past the end
     if (p.wk > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -271,6 +302,13 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             }
         }
     }
+#ifdef AWQ_GEMV_TRACE
+    BT_STAMP(11);
+    if (p.trace && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) p.trace[((size_t)blockIdx.x * 8 + wave) * 12 + i] = ts[i];
+    }
+#endif
 }
 
 constexpr int piece_bytes(int GW) { return 16 * GW * 64 + 1024 + 256; }
@@ -315,6 +353,13 @@ bool plan_batch(int M, int K, int N, int g, int gw_req, int rd_req, BatchPlan* o
 
 }  // namespace
 
+#ifdef AWQ_GEMV_TRACE
+static unsigned long long* g_batch_trace = nullptr;
+extern "C" __attribute__((visibility("default"))) void awq_debug_set_trace_batch(void* dev_buf) {
+    g_batch_trace = static_cast<unsigned long long*>(dev_buf);
+}
+#endif
+
 bool awq_gemv_batch_supports(int M, int K, int N, int g) {
     BatchPlan b;
     return plan_batch(M, K, N, g, 0, 0, &b);
@@ -340,6 +385,11 @@ int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint1
     p.ring_off = 0;
     p.pbuf_off = (int)b.ring;
     p.ystage_off = (int)(b.ring + b.pbuf);
+#ifdef AWQ_GEMV_TRACE
+    p.trace = g_batch_trace;
+#else
+    p.trace = nullptr;
+#endif
     const size_t lds = b.ring + b.pbuf + b.ystage;
 #define AWQ_BT_CASE(MIV, GWV, RDV)                                                                                                 \
     if (b.MI == MIV && b.GW == GWV && b.RD == RDV) {                                                                               \

@@ -76,6 +76,7 @@ class ALiBi(nn.Module):
 
 class QuantAttentionFused(nn.Module):
     FUSE_ROPE_INTO_ATTENTION = True  # decode steps, head_dim 128, full rotary
+    PREFILL_KERNEL = True            # prefill steps, head_dim 128: csrc/prefill_attn.hip (False: the vendor's attention, for A/B runs)
 
     def __init__(self, hidden_size, n_heads, n_kv_heads, qkv_layer, o_proj, dev, max_seq_len=2048, use_alibi=False,
                  attention_shapes=None, rope_theta=10000, partial_rotary_factor=1.0, head_dim=None,
@@ -201,7 +202,13 @@ class QuantAttentionFused(nn.Module):
         xq = ops.rope_kv_append(xqkv, self.cache.k, self.cache.v, self.rope.cos, self.rope.sin, self.start_pos,
                                 self.n_heads, self.n_kv_heads, self.head_dim, self.rotary_dim,
                                 pos_dev=self._pos_dev if device_pos else None)
-        if seqlen > 1:
+        if seqlen > 1 and self.head_dim == 128 and self.n_heads % self.n_kv_heads == 0 and self.PREFILL_KERNEL:
+            # prefill: the hand-written flash-style kernel (csrc/prefill_attn.hip; the reference's flash_attn_func call, attn.py:269-277),
+            # chunked prefill, GQA, ALiBi and the soft cap included -- no mask tensor, no repeat_interleave copy of the cache
+            out = ops.prefill_attention(xq, self.cache.k, self.cache.v, self.start_pos, softcap=self.attn_logit_softcapping,
+                                        alibi_slopes=self.alibi.slopes if self.alibi is not None else None)
+            output = out.reshape(bsz, seqlen, -1)
+        elif seqlen > 1:  # other head sizes: the vendor's attention (fp32 matmul softmax when the scores carry a bias or a cap)
             end = self.start_pos + seqlen
             q = xq.transpose(1, 2)                                  # [B, Hq, S, D]
             k = self.cache.k[:bsz, :end].transpose(1, 2)            # [B, Hkv, T, D]

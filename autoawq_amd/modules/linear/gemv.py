@@ -39,7 +39,7 @@ PREFILL_MIN_ROWS = 129
 
 
 class WQLinear_GEMV(nn.Module):
-    PREFILL_IMPL = "two_pass"  # | "fused" (see forward)
+    PREFILL_IMPL = "repack"  # | "two_pass" | "fused" (see forward)
 
     def __init__(self, w_bit, group_size, in_features, out_features, bias, dev):
         super().__init__()
@@ -89,22 +89,31 @@ class WQLinear_GEMV(nn.Module):
         if input_dtype != torch.float16:
             inputs = inputs.half()
         # Every batch size on this layout's OWN buffers (round 4: the second, GEMM-layout copy of every matrix that rounds 2-3
-        # kept for prefill is gone).  Below PREFILL_MIN_ROWS rows: the decode / batched-decode kernels.  From there: PREFILL_IMPL --
-        #   "two_pass" (default)  dequantise (hand-written kernel, bit-exact) into a temporary + a dense fp16 GEMM: the reference's
-        #                         own prefill route (gemm.py:48-54); 0.42 of the MFMA peak at M = 16384, ~45 us at M = 32;
+        # kept resident for prefill is gone).  Below PREFILL_MIN_ROWS rows: the decode / batched-decode kernels.  From there: PREFILL_IMPL --
+        #   "repack" (default, round 5)  transpose the packed nibbles into a TEMPORARY of the call (csrc/repack.hip, K N / 2 bytes) and run
+        #                         the fused MFMA GEMM on it (csrc/gemm_regb.hip): two hand-written launches, no vendor GEMM, no fp16
+        #                         copy of the weights, bit-identical to what a GEMM-format checkpoint of the same weights computes;
+        #   "two_pass"            dequantise (hand-written kernel, bit-exact) into an fp16 temporary + a dense fp16 GEMM: the reference's
+        #                         own prefill route (gemm.py:48-54);
         #   "fused"               the register-decoded MFMA GEMM in its N-major form (AWQ_GEMV_KERNEL_PREFILL): no temporary, but
         #                         0.29 of the peak at M = 16384 and latency-bound below ~2000 rows (profiles/r04_bench_*.json).
         out = None
         rows = inputs.shape[0]
-        if rows >= PREFILL_MIN_ROWS and self.PREFILL_IMPL == "fused":
+        decode = rows <= 16 or (rows < PREFILL_MIN_ROWS and ops.gemv_auto_kernel(rows, self.in_features, self.out_features, self.group_size)
+                                == ops.GEMV_KERNEL_BATCH)  # (the older decode kernels serve 16 rows per launch: not worth chunking)
+        if not decode and self.PREFILL_IMPL == "repack":
+            try:
+                out = ops.gemv_prefill_repack(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
+            except _lib.AwqHipError as e:  # a shape the GEMM kernels refuse
+                if e.code != _lib.ERR_UNSUPPORTED:
+                    raise
+        if not decode and self.PREFILL_IMPL == "fused":
             try:
                 out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size,
                                        flags=ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL))
             except _lib.AwqHipError as e:  # K % 64, group sizes below 64
                 if e.code != _lib.ERR_UNSUPPORTED:
                     raise
-        decode = rows <= 16 or (rows < PREFILL_MIN_ROWS and ops.gemv_auto_kernel(rows, self.in_features, self.out_features, self.group_size)
-                                == ops.GEMV_KERNEL_BATCH)  # (the older decode kernels serve 16 rows per launch: not worth chunking)
         if out is None and decode:
             try:
                 out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)

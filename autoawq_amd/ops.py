@@ -340,6 +340,29 @@ def dequantize_weights_gemv(qweight, scales, qzeros, group_size):
     return out
 
 
+def repack_gemv_to_gemm(qweight, scales, qzeros, group_size):
+    """GEMV-layout buffers -> (qweight [K, N/8], scales [K/g, N], qzeros [K/g, N/8]) in the GEMM layout: the same integers and
+    scales, bit for bit (awq_repack_gemv_to_gemm, csrc/repack.hip).  The outputs are fresh temporaries."""
+    _require_gpu(qweight, scales, qzeros)
+    qweight, scales, qzeros = qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    N, K = qweight.shape[0], qweight.shape[1] * 8
+    G = K // group_size
+    qw = torch.empty((K, N // 8), dtype=torch.int32, device=qweight.device)
+    sc = torch.empty((G, N), dtype=torch.float16, device=qweight.device)
+    qz = torch.empty((G, N // 8), dtype=torch.int32, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        _lib.check(_lib.lib().awq_repack_gemv_to_gemm(_ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(qw), _ptr(sc), _ptr(qz), K, N,
+                                                      group_size, qzeros.shape[1], _stream()), "awq_repack_gemv_to_gemm")
+    return qw, sc, qz
+
+
+def gemv_prefill_repack(x2d, qweight, scales, qzeros, group_size, bias=None):
+    """Prefill-sized batches on the GEMV layout's own buffers: transpose the packed nibbles into a temporary of this call
+    (repack_gemv_to_gemm) and run the fused MFMA GEMM on it (gemm_forward) -- two hand-written launches, nothing resident."""
+    qw, sc, qz = repack_gemv_to_gemm(qweight, scales, qzeros, group_size)
+    return gemm_forward(x2d, qw, sc, qz, bias)
+
+
 def silu_and_mul(gate_up, out=None):
     """[..., 2d] fp16 = [gate | up] -> [..., d] = silu(gate) * up (awq_silu_and_mul)."""
     _require_gpu(gate_up)
@@ -538,6 +561,31 @@ def rope_kv_append(qkv, k_cache, v_cache, cos, sin, start_pos, n_heads, n_kv_hea
                                                  _ptr(pos_dev), int(start_pos), B, S, n_heads, n_kv_heads, head_dim,
                                                  rotary_dim, k_cache.shape[1], _stream()), "awq_rope_kv_append")
     return q
+
+
+def prefill_attention(q, k_cache, v_cache, start_pos, scale=None, softcap=0.0, alibi_slopes=None):
+    """q [B, S, Hq, 128] fp16 (after RoPE), caches [>= B, Tmax, Hkv, 128] fp16 already holding rows 0 .. start_pos + S - 1 ->
+    [B, S, Hq, 128]: causal attention of the S new rows over the cache (awq_prefill_attention, csrc/prefill_attn.hip; the
+    reference's flash_attn_func call, attn.py:269-277).  Raises AwqHipError code -3 for head sizes other than 128."""
+    _require_gpu(q, k_cache, v_cache, alibi_slopes)
+    if q.dtype != torch.float16 or k_cache.dtype != torch.float16 or v_cache.dtype != torch.float16:
+        raise _lib.AwqHipError("prefill_attention expects fp16 tensors")
+    B, S, Hq, D = q.shape
+    Tmax, Hkv = k_cache.shape[1], k_cache.shape[2]
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()) or k_cache.shape[0] < B or k_cache.shape != v_cache.shape:
+        raise _lib.AwqHipError("prefill_attention: caches must be contiguous [>=B, Tmax, Hkv, D]")
+    q = q.contiguous()
+    out = torch.empty_like(q)
+    if alibi_slopes is not None:
+        alibi_slopes = alibi_slopes.to(torch.float32).contiguous()
+        if alibi_slopes.numel() != Hq:
+            raise _lib.AwqHipError("prefill_attention: alibi_slopes must have one entry per query head")
+    if scale is None:
+        scale = D ** -0.5
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().awq_prefill_attention(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), B, S, Hq, Hkv, D, Tmax, int(start_pos),
+                                                    float(scale), float(softcap), _ptr(alibi_slopes), _stream()), "awq_prefill_attention")
+    return out
 
 
 _attn_workspaces = {}

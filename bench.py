@@ -311,6 +311,45 @@ def leg_gemm_prefill(dev, ops):
             "fused_vs_two_pass_max_rel": rel}
 
 
+def leg_prefill_attention(dev, ops):
+    """BASELINE configs[2]'s attention (bs 8 x seq 2048, 32 heads x 128): the hand-written flash-style prefill kernel
+    (csrc/prefill_attn.hip, the reference's flash_attn_func call attn.py:269-277) beside the vendor's scaled_dot_product_attention on
+    the same tensors; MFMA roofline on the causal flops 2 * 2 * B * H * D * S (S + 1) / 2."""
+    import torch.nn.functional as F
+
+    B, S, H, D = 8, 2048, 32, 128
+    gen = torch.Generator(device=dev).manual_seed(8)
+    q = torch.randn((B, S, H, D), device=dev, generator=gen).half()
+    kc = torch.randn((B, S, H, D), device=dev, generator=gen).half()
+    vc = torch.randn((B, S, H, D), device=dev, generator=gen).half()
+    fl = 4.0 * B * H * D * S * (S + 1) / 2
+
+    def timeit(fn, reps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    us = timeit(lambda: ops.prefill_attention(q, kc, vc, 0))
+    qt, kt, vt = q.transpose(1, 2), kc.transpose(1, 2), vc.transpose(1, 2)
+    us_v = timeit(lambda: F.scaled_dot_product_attention(qt, kt, vt, is_causal=True))
+    a = ops.prefill_attention(q[:1], kc[:1], vc[:1], 0).float()
+    b = F.scaled_dot_product_attention(qt[:1].float(), kt[:1].float(), vt[:1].float(), is_causal=True).transpose(1, 2)
+    rel = float((a - b).abs().max() / b.abs().max())
+    assert rel < 5e-3, f"prefill attention disagrees with fp32 attention: {rel}"
+    out = {"shape": f"B {B} x S {S} x {H} heads x {D} (causal, start 0)", "flops": fl, "us": us, "kernel": "awq_prefill_attn_kernel",
+           "roofline": {"bound": "mfma", "achieved": fl / us / 1e6, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / us / 1e6 / MFMA_PEAK_TF},
+           "vendor_sdpa_us": us_v, "vendor_sdpa_tflops": fl / us_v / 1e6, "vs_fp32_attention_max_rel": rel,
+           "note": "what QuantAttentionFused runs for prefill steps at head_dim 128 (GQA, chunked prefill, ALiBi, soft cap in the same kernel)"}
+    return out
+
+
 def leg_moe_prefill(dev):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_moe
@@ -719,6 +758,7 @@ def main():
                     ("decode_dependent", lambda: leg_decode_dependent(dev, ops, model, bytes_step)),
                     ("by_layout", lambda: (model.clear(), torch.cuda.empty_cache(), leg_by_layout(dev, ops, layers, a.layout))[2]),
                     ("gemm_bs", lambda: leg_gemm_bs(dev, ops)), ("gemm_prefill", lambda: leg_gemm_prefill(dev, ops)),
+                    ("prefill_attention", lambda: leg_prefill_attention(dev, ops)),
                     ("moe_bs4", lambda: leg_moe(dev)), ("moe_prefill", lambda: leg_moe_prefill(dev))]
             if not a.no_whole_model:
                 legs.append(("whole_model", lambda: (model.clear(), torch.cuda.empty_cache(), leg_whole_model(dev))[2]))

@@ -211,6 +211,14 @@ AWQ_EXPORT int awq_dequantize_weights_gemv(const int32_t* qweight, const uint16_
                                            uint16_t* out, int64_t K, int64_t N, int64_t group_size,
                                            int64_t zeros_width, void* stream);
 
+/* GEMV-layout buffers -> GEMM-layout buffers of the same integers and scales (csrc/repack.hip): qweight_out [K, N/8] i32 (AWQ nibble
+ * order, awq/modules/linear/gemm.py:220-249), scales_out [K/g, N] f16, qzeros_out [K/g, N/8] i32 -- caller-owned temporaries.  The
+ * prefill route of WQLinear_GEMV (the reference runs awq_ext.gemmv2_forward_cuda there, gemv.py:168-176): repack into a temporary of
+ * the call, then awq_gemm_forward's fused MFMA kernel on it.  Bit-exact nibble moves; N % 8 == 0. */
+AWQ_EXPORT int awq_repack_gemv_to_gemm(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, int32_t* qweight_out,
+                                       uint16_t* scales_out, int32_t* qzeros_out, int64_t K, int64_t N, int64_t group_size,
+                                       int64_t zeros_width, void* stream);
+
 /* ---- GEMVFast layout: qweight [N/4, K] i16 (4-row interleave, awq/modules/linear/gemv_fast.py:26-65),
  *      scales [8*ZW, N] f16, qzeros [8*ZW, N] f16 = -(scale*zero) (gemv_fast.py:86-118,175-181) ------- */
 
@@ -269,6 +277,17 @@ AWQ_EXPORT int awq_decode_attention_ex(const uint16_t* q, const uint16_t* k_cach
                                        int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq, float scale,
                                        float softcap, const float* alibi_slopes, void* workspace, size_t workspace_bytes,
                                        void* stream);
+
+/* Replaces flash_attn_func(xq, keys, values, causal=True, alibi_slopes=..., softcap=...) -- the PREFILL step of the fused attention
+ * (awq/modules/fused/attn.py:269-277): out [B, S, n_heads, 128] fp16 = causal attention of the S new query rows q [B, S, n_heads, 128]
+ * (after RoPE) over the caches [>= B, max_seq, n_kv_heads, 128], which already hold rows 0 .. start_pos + S - 1 of every sequence
+ * (awq_rope_kv_append appended them); query row s sees cache rows <= start_pos + s (start_pos > 0: chunked prefill).  softcap /
+ * alibi_slopes as in awq_decode_attention_ex (the bias of key row t for query position p is slope_h * (t - p)).  Flash style: no
+ * workspace, fp32 online softmax, MFMA 16x16x32 (csrc/prefill_attn.hip).  AWQ_ERR_UNSUPPORTED: head_dim != 128, n_heads % n_kv_heads,
+ * tensors beyond 32-bit byte offsets per sequence. */
+AWQ_EXPORT int awq_prefill_attention(const uint16_t* q, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* out, int64_t B,
+                                     int64_t S, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t max_seq,
+                                     int64_t start_pos, float scale, float softcap, const float* alibi_slopes, void* stream);
 
 /* awq_rmsnorm_forward folded into the projection that follows it (decode, M <= 4, GEMM layout):
  * y = rmsnorm(x (+ residual_in)) * norm_weight @ W.  Every block of the decode kernel recomputes the

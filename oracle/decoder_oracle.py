@@ -87,3 +87,16 @@ def attention_reference(q, k_cache, v_cache, seq_len, scale=None, softcap=0.0, a
             p = np.exp(s - s.max())
             out[b, h] = (p / p.sum()) @ v
     return out
+
+
+def prefill_attention_reference(q, k_cache, v_cache, start, rows, scale=None, softcap=0.0, alibi_slopes=None):
+    """The prefill step of the fused attention -- flash_attn_func(xq, keys, values, causal=True, alibi_slopes=..., softcap=...),
+    awq/modules/fused/attn.py:269-277 -- for the sampled query rows `rows` of q [B, S, Hq, D] (numpy fp16, after RoPE) over caches
+    [B, Tmax, Hkv, D] that hold rows 0 .. start + S - 1: query row s is ONE query token at position start + s, i.e. exactly
+    attention_reference over the first start + s + 1 cache rows (the causal mask), with the same score modifiers.
+    Returns [B, len(rows), Hq, D] float64."""
+    q = np.asarray(q)
+    out = np.zeros((q.shape[0], len(rows), q.shape[2], q.shape[3]))
+    for i, s_ in enumerate(rows):
+        out[:, i] = attention_reference(q[:, s_], k_cache, v_cache, start + int(s_) + 1, scale=scale, softcap=softcap, alibi_slopes=alibi_slopes)
+    return out

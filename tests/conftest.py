@@ -55,11 +55,46 @@ def pytest_collection_modifyitems(config, items):
         if drop:
             config.hook.pytest_deselected(items=drop)
             items[:] = [it for it in items if "gpu_fault" not in it.keywords]
+    thin_cross_products(config, items)
     if os.environ.get("AWQ_GUARD_ALLOC", "") in ("end", "start"):
         skip = pytest.mark.skip(reason="not under the guard-band allocator")
         for it in items:
             if "guard_skip" in it.keywords:
                 it.add_marker(skip)
+
+
+# The big shape x batch x variant cross products of the GPU suite: the default selection keeps every STRIDE-th parametrisation of
+# these functions (collection order: a stride coprime with both parameter lists walks a diagonal that still meets every shape and
+# every batch size), so that the driver's `pytest -m gpu` takes ~3 minutes instead of 8.5 (GPU minutes belong
+# to kernels).  AWQ_FULL_MATRIX=1 runs the whole matrix -- once per kernel change (tools/final_r05.sh does).  Every SURVEY.md section 8
+# row keeps its BASELINE-shape tests (tests/test_gpu_baseline_configs.py, the golden tests, the *_kernel_vs_oracle tests of the
+# headline kernels) in the default selection; nothing here thins those.
+THIN = {"test_gemm_vs_oracle_all_variants": 3, "test_skinny_gemm_vs_oracle": 3, "test_tiled_gemm_vs_oracle": 3, "test_regb_gemm_vs_oracle": 3,
+        "test_gemv_lds_kernel_vs_oracle": 5, "test_gemv_layout_vs_oracle": 3, "test_gemvfast_layout_vs_oracle": 2,
+        "test_gated_silu_staging_equals_separate_kernel": 2, "test_decode_attention_softcap_and_alibi_vs_oracle": 2,
+        "test_oneshot_allreduce_sums_in_rank_order_bitwise_identical": 2, "test_batched_decode_at_benched_shapes_vs_oracle": 2}
+
+
+def full_matrix():
+    return os.environ.get("AWQ_FULL_MATRIX", "") == "1"
+
+
+def thin_cross_products(config, items):
+    if full_matrix():
+        return
+    seen, keep, drop = {}, [], []
+    for it in items:
+        name = getattr(it, "originalname", None) or it.name.split("[")[0]
+        k = THIN.get(name)
+        if k is None or "gpu" not in it.keywords:
+            keep.append(it)
+            continue
+        i = seen.get(name, 0)
+        seen[name] = i + 1
+        (keep if i % k == 0 else drop).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def pytest_terminal_summary(terminalreporter):

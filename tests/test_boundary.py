@@ -232,7 +232,7 @@ def test_hand_counted_asm_loads_are_hazard_safe():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     csrc = os.path.join(ROOT, "autoawq_amd", "csrc")
-    for f, min_blocks in (("gemm_regb.hip", 10), ("gemm_skinny.hip", 10)):
+    for f, min_blocks in (("gemm_regb.hip", 10), ("gemm_skinny.hip", 10), ("prefill_attn.hip", 10)):
         name, blocks, bad = mod.audit_asm_loads(os.path.join(csrc, f))
         assert not bad, (name, bad[:5])
         assert blocks >= min_blocks, (name, blocks)
@@ -285,8 +285,11 @@ def test_hand_counted_waits_of_the_register_decoded_kernels_hold_in_the_generate
     spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    for f, least in (("gemm_regb.hip", 6), ("gemm_skinny.hip", 2), ("gemv_lds.hip", 3), ("gemv_rows.hip", 64), ("gemv_batch.hip", 8)):
-        name, kernels, visits, bad = mod.audit_vmcnt(os.path.join(ROOT, "autoawq_amd", "csrc", f))
+    for f, least in (("gemm_regb.hip", 6), ("gemm_skinny.hip", 2), ("gemv_lds.hip", 3), ("gemv_rows.hip", 64), ("gemv_batch.hip", 8),
+                     ("prefill_attn.hip", 2)):
+        from autoawq_amd.csrc import build as hip_build
+
+        name, kernels, visits, bad = mod.audit_vmcnt(os.path.join(ROOT, "autoawq_amd", "csrc", f), flags=tuple(hip_build.EXTRA.get(f, [])))
         assert not bad, (name, bad[:5])
         assert kernels >= least and visits > 0, (name, kernels, visits)
 

@@ -65,6 +65,25 @@ def test_oracle_attention_matches_torch_sdpa():
     assert np.abs(got - want).max() <= 1e-5
 
 
+def test_oracle_prefill_attention_matches_torch_sdpa():
+    """The prefill restatement (one causal row = one decode query over the first start + s + 1 cache rows) against torch's own
+    scaled_dot_product_attention with the chunked-prefill mask (CPU, fp32): the definition flash_attn_func(causal=True) implements."""
+    from oracle import decoder_oracle
+    import torch.nn.functional as F
+
+    gen = torch.Generator().manual_seed(1)
+    B, S, Hq, Hkv, start = 2, 9, 4, 2, 5
+    q = torch.randn((B, S, Hq, 128), generator=gen).half()
+    kc = torch.randn((B, start + S + 3, Hkv, 128), generator=gen).half()
+    vc = torch.randn((B, start + S + 3, Hkv, 128), generator=gen).half()
+    ref = decoder_oracle.prefill_attention_reference(q.numpy(), kc.numpy(), vc.numpy(), start, list(range(S)))
+    k = kc[:, :start + S].float().transpose(1, 2).repeat_interleave(2, dim=1)
+    v = vc[:, :start + S].float().transpose(1, 2).repeat_interleave(2, dim=1)
+    mask = torch.ones((S, start + S), dtype=torch.bool).tril(diagonal=start)
+    want = F.scaled_dot_product_attention(q.float().transpose(1, 2), k, v, attn_mask=mask).transpose(1, 2).numpy()
+    assert np.abs(want - ref).max() <= 1e-5
+
+
 def test_input_id_and_cache_bookkeeping():
     from autoawq_amd.modules.fused.cache import WindowedCache
     from autoawq_amd.modules.fused.model import prepare_input_ids
@@ -286,6 +305,71 @@ class _HeadRMSNorm(torch.nn.Module):
     def forward(self, x):
         xf = x.float()
         return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * self.weight.float()).to(x.dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,Hq,Hkv,start,softcap,alibi", [
+    (1, 2048, 32, 32, 0, 0.0, False),    # BASELINE configs[2]'s attention: 32 heads x d128 x 2048 tokens
+    (2, 300, 8, 1, 0, 0.0, False),       # GQA 8:1, ragged S (partial last row block and KV tile)
+    (1, 257, 16, 4, 1000, 0.0, False),   # chunked prefill: the new rows sit behind 1000 cached ones
+    (3, 129, 4, 4, 63, 0.0, False),      # three sequences, an odd start
+    (1, 1, 32, 8, 77, 0.0, False),       # one row (a decode step through the prefill kernel)
+    (2, 200, 8, 2, 40, 30.0, False),     # soft cap (Gemma-2's attn_logit_softcapping)
+    (1, 333, 12, 12, 0, 0.0, True),      # ALiBi slopes (MPT / Falcon)
+    (2, 160, 8, 4, 500, 8.0, True),      # both, chunked
+])
+def test_prefill_attention_vs_oracle(ops, B, S, Hq, Hkv, start, softcap, alibi):
+    """csrc/prefill_attn.hip (the reference's flash_attn_func call, attn.py:269-277) against oracle/decoder_oracle.py::
+    prefill_attention_reference on sampled query rows (every row block boundary, the first and the last rows), and every output
+    against a plain fp32 torch attention of the same tensors; cache rows past start + S are NaN-poisoned (never read); bitwise
+    reproducible.  Tolerance: fp16 probabilities in the second product -> 2e-3 of the row's largest |value| + 2 fp16 ulps."""
+    from oracle import decoder_oracle
+
+    gen = torch.Generator().manual_seed(B * 1000 + S + Hq + start)
+    Tmax = start + S + 70
+    q = torch.randn((B, S, Hq, 128), generator=gen).half()
+    kc = torch.randn((B + 1, Tmax, Hkv, 128), generator=gen).half()
+    vc = torch.randn((B + 1, Tmax, Hkv, 128), generator=gen).half()
+    kc[:, start + S:] = float("nan")
+    vc[:, start + S:] = float("nan")
+    slopes = (0.5 ** torch.arange(1, Hq + 1, dtype=torch.float32) * 4.0) if alibi else None
+    qd, kd, vd = q.cuda(), kc.cuda(), vc.cuda()
+    out = ops.prefill_attention(qd, kd, vd, start, softcap=softcap, alibi_slopes=slopes.cuda() if alibi else None)
+    assert out.shape == q.shape and bool(torch.isfinite(out).all())
+    assert torch.equal(out, ops.prefill_attention(qd, kd, vd, start, softcap=softcap, alibi_slopes=slopes.cuda() if alibi else None))
+    rows = sorted(set([0, 1, S - 1, S // 2] + [r for r in (31, 32, 63, 64, 127, 128, 129, 255, 256, 1023, 1024, 2047) if r < S]))
+    ref = decoder_oracle.prefill_attention_reference(q.numpy(), kc.numpy()[:B], vc.numpy()[:B], start, rows, softcap=softcap,
+                                                     alibi_slopes=slopes.numpy() if alibi else None)
+    got = out.cpu().numpy().astype(np.float64)[:, rows]
+    tol = 2e-3 * np.abs(ref).max(axis=-1, keepdims=True) + 2 * ulp16(ref)
+    assert (np.abs(got - ref) <= tol).all(), float(np.abs(got - ref).max())
+    # every output element against fp32 torch attention on the GPU
+    G = Hq // Hkv
+    qf = qd.float().transpose(1, 2)
+    kf = kd[:B, :start + S].float().transpose(1, 2).repeat_interleave(G, dim=1)
+    vf = vd[:B, :start + S].float().transpose(1, 2).repeat_interleave(G, dim=1)
+    sc = torch.matmul(qf, kf.transpose(-1, -2)) * (128 ** -0.5)
+    if softcap:
+        sc = softcap * torch.tanh(sc / softcap)
+    qpos = start + torch.arange(S, device="cuda").view(-1, 1)
+    kpos = torch.arange(start + S, device="cuda").view(1, -1)
+    if alibi:
+        sc = sc + slopes.cuda().view(1, -1, 1, 1) * (kpos - qpos).float()
+    sc = sc.masked_fill(kpos > qpos, float("-inf"))
+    full = torch.matmul(torch.softmax(sc, dim=-1), vf).transpose(1, 2)
+    d = (out.float() - full).abs()
+    assert bool((d <= 2e-3 * full.abs().amax(dim=-1, keepdim=True) + 2e-3).all()), float(d.max())
+
+
+@pytest.mark.gpu
+def test_prefill_attention_refuses_other_head_sizes(ops):
+    from autoawq_amd import _lib
+
+    q = torch.zeros((1, 4, 2, 64), dtype=torch.float16, device="cuda")
+    kc = torch.zeros((1, 8, 2, 64), dtype=torch.float16, device="cuda")
+    with pytest.raises(_lib.AwqHipError) as ei:
+        ops.prefill_attention(q, kc, kc.clone(), 0)
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
 
 
 @pytest.mark.gpu

@@ -141,9 +141,18 @@ def test_gemv_layout_prefill_kernel_vs_oracle(ops, oracle, K, N, M, bm):
 
         mod = WQLinear_GEMV(4, 128, K, N, False, "cuda")
         mod.qweight, mod.qzeros, mod.scales = dq, dz, ds
+        from autoawq_amd.modules.linear.gemv import PREFILL_MIN_ROWS
+
+        # the module's routes: below PREFILL_MIN_ROWS the batched-decode kernel; from there "repack" (default: csrc/repack.hip + the
+        # fused MFMA GEMM on the temporary), "two_pass" (dequantise + dense GEMM) or "fused" (this kernel)
+        assert mod.PREFILL_IMPL == "repack"
+        assert_product_close(mod(dx)[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module default {K}x{N} M{M}")
+        assert ops.last_kernel() == "gemv_batch" if M < PREFILL_MIN_ROWS else ops.last_kernel() in ("gemm_regb", "gemm_tiled"), ops.last_kernel()
+        mod.PREFILL_IMPL = "two_pass"
         assert_product_close(mod(dx)[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module two-pass {K}x{N} M{M}")
         mod.PREFILL_IMPL = "fused"
-        assert torch.equal(mod(dx), y) and ops.last_kernel() == "gemm_regb_nk"
+        if M >= PREFILL_MIN_ROWS:
+            assert torch.equal(mod(dx), y) and ops.last_kernel() == "gemm_regb_nk"
 
 
 def test_gemv_layout_prefill_kernel_group_sizes_and_refusals(ops, oracle):

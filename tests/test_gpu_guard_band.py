@@ -15,7 +15,12 @@ pytestmark = [pytest.mark.gpu, pytest.mark.guard_skip]
 # the kernel-facing tests (every HIP kernel family, BASELINE shapes + ragged ones, M = 1 ... 16 and prefill sizes); the
 # whole suite runs under the same allocator by tools/guard_run.sh (profiles/r04_fault_hunt/)
 SUBSET = ("test_gemv_rows_kernel_vs_oracle or test_gemv_rows_block_fusions or config4 or dequant or unpack or gemv_lds or gemvfast or "
-          "test_gemm_vs_oracle_all_variants or attention or rmsnorm or rope or silu or moe or chain")
+          "test_gemm_vs_oracle_all_variants or attention or rmsnorm or rope or silu or moe or chain or gemv_batch or repack")
+# default selection: one placement (flush against the END of the mapping: an over-read past an operand, the usual failure) of a compact
+# subset -- one family each; AWQ_FULL_MATRIX=1: both placements of the whole subset (135 s each on an MI355X; round 5: the driver's
+# suite is held near three minutes)
+COMPACT = ("test_gemv_rows_kernel_vs_oracle or gemv_batch or repack or prefill_attention or test_decode_attention_vs_oracle or unpack or "
+           "test_dequant_golden or test_gemm_golden or test_moe_block_vs_oracle or rmsnorm or rope_kv or test_gemvfast_layout_golden")
 
 
 def _env(mode):
@@ -45,8 +50,11 @@ def test_guard_allocator_faults_on_an_access_outside_an_allocation(mode):
 
 @pytest.mark.parametrize("mode", ["end", "start"])
 def test_kernels_touch_nothing_outside_their_operands(mode):
+    full = os.environ.get("AWQ_FULL_MATRIX", "") == "1"
+    if mode == "start" and not full:
+        pytest.skip("the START placement runs with AWQ_FULL_MATRIX=1 (tools/final_r05.sh)")
     _lib_built()
-    cmd = [sys.executable, "-X", "faulthandler", "-m", "pytest", "tests", "-m", "gpu", "-v", "-p", "no:cacheprovider", "-x", "-k", SUBSET]
+    cmd = [sys.executable, "-X", "faulthandler", "-m", "pytest", "tests", "-m", "gpu", "-v", "-p", "no:cacheprovider", "-x", "-k", SUBSET if full else COMPACT]
     r = subprocess.run(cmd, env=_env(mode), cwd=ROOT, capture_output=True, text=True, timeout=1500)
     tail = "\n".join(r.stdout.splitlines()[-12:])
     assert r.returncode == 0, f"guard-band run ({mode}) rc {r.returncode}:\n{tail}\n{r.stderr[-1500:]}"

@@ -786,6 +786,29 @@ def test_gemv_batch_refuses_what_it_cannot_take(ops):
         assert ops.last_kernel() == "gemv_nk"
 
 
+@pytest.mark.parametrize("K,N,g", [(4096, 11008, 128), (11008, 4096, 128), (1024, 200, 128), (512, 264, 64), (256, 8, 32), (2048, 4104, 2048), (8192, 1280, 128)])
+def test_repack_gemv_to_gemm_bit_exact(ops, oracle, K, N, g):
+    """csrc/repack.hip (the prefill route of WQLinear_GEMV: GEMV-layout buffers -> a GEMM-layout temporary of the call): the packed
+    words, zero words and scales it writes equal, bit for bit, what the torch repack of utils/convert.py produces (pinned against
+    reference-written checkpoints in tests/test_checkpoint.py) -- ragged tiles in both directions, every group size; and the
+    product on the repacked buffers equals the product on a GEMM-layout packing of the same integers."""
+    from autoawq_amd import WQLinear_GEMV
+    from autoawq_amd.utils.convert import convert_linear
+
+    qw, qz, sc, x = gemv_case(K, N, g, 40, seed=K + N + g)
+    m = WQLinear_GEMV(4, g, K, N, False, "cuda")
+    m.qweight, m.qzeros, m.scales = qw.cuda(), qz.cuda(), sc.cuda()
+    want = convert_linear(m, "gemm")
+    rq, rs, rz = ops.repack_gemv_to_gemm(m.qweight, m.scales, m.qzeros, g)
+    assert torch.equal(rq, want.qweight) and torch.equal(rz, want.qzeros)
+    assert torch.equal(rs.view(torch.int16), want.scales.view(torch.int16))
+    y = ops.gemv_prefill_repack(x.cuda(), m.qweight, m.scales, m.qzeros, g)
+    assert torch.equal(y, ops.gemm_forward(x.cuda(), want.qweight, want.scales, want.qzeros))
+    W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
+    y32, _ = oracle.matmul(x.numpy(), W)
+    assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"repack route K{K} N{N} g{g}", wsigma=oracle.weight_rounding_sigma(x.numpy(), W))
+
+
 def test_gemv_module_forward_semantics(ops, oracle):
     from autoawq_amd import WQLinear_GEMV
 

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""WQLinear_GEMV's prefill routes at 4096 x 11008 by token count: "repack" (csrc/repack.hip + the fused MFMA GEMM on the temporary),
+"two_pass" (dequantise + vendor GEMM), "fused" (the N-major form of gemm_regb), the batched-decode kernel in 32-row launches; and the
+repack kernel alone against its bytes (K N / 2 read + written)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from autoawq_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def main():
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(2)
+    for K, N in [(4096, 11008), (11008, 4096)]:
+        qw, qz, sc = bench.rand_packed_nk(K, N, 128, dev, gen)
+        us = timeit(lambda: ops.repack_gemv_to_gemm(qw, sc, qz, 128), reps=50)
+        by = K * N  # K N / 2 read + K N / 2 written
+        print(f"repack {K}x{N}: {us:.1f} us = {by / us / 1e3:.0f} GB/s of {by / 1e6:.1f} MB")
+        for M in (64, 128, 256, 512, 1024, 2048, 4096, 16384):
+            x = torch.randn((M, K), device=dev, generator=gen).half()
+            fl = 2.0 * M * K * N
+            r = {}
+            r["repack"] = timeit(lambda: ops.gemv_prefill_repack(x, qw, sc, qz, 128))
+            r["two_pass"] = timeit(lambda: torch.matmul(x, ops.dequantize_weights_gemv(qw, sc, qz, 128).t()))
+            r["fused_nk"] = timeit(lambda: ops.gemv_forward(x, qw, sc, qz, 128, flags=ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL)))
+            if M <= 1024:
+                r["batch32"] = timeit(lambda: ops.gemv_forward(x, qw, sc, qz, 128, flags=ops.gemm_flags(kernel=ops.GEMV_KERNEL_BATCH)))
+            print(f"  M={M}: " + "  ".join(f"{k} {v:.1f} us ({fl / v / 1e6:.0f} TF)" for k, v in r.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
