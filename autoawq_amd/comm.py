@@ -125,21 +125,32 @@ class OneShotAllReduce:
         agree(mine is not None, "allocation / IPC export", err)
         everyone = [None] * world
         dist.all_gather_object(everyone, mine, group=group)
-        staging, flags, err = [], [], None
+        staging, flags, keep, err = [], [], [st, fl], None
+
+        def view(b):
+            """the tensor view of a mapping must BE the mapping: torch infers the device of a raw pointer from the driver, and for a
+            peer's IPC mapping a wrong answer would make as_tensor copy it silently -- flags and staging would then be private
+            copies, the one-shot path would time out on every call; the mappings are kept alive explicitly"""
+            t = b.tensor(device)
+            if t.data_ptr() != b.ptr or t.device != device:
+                raise RuntimeError(f"the view of a mapped buffer is a copy (pointer {t.data_ptr():#x} on {t.device}, mapping {b.ptr:#x} on {device})")
+            keep.append(b)
+            return t
+
         try:
             with torch.cuda.device(device):
                 for r, (hs, ns, hf, nf) in enumerate(everyone):
                     if r == rank:
-                        staging.append(st.tensor(device))
-                        flags.append(fl.tensor(device))
+                        staging.append(view(st))
+                        flags.append(view(fl))
                     else:
-                        staging.append(_DeviceBytes(ns, handle=hs).tensor(device))
-                        flags.append(_DeviceBytes(nf, handle=hf).tensor(device))
+                        staging.append(view(_DeviceBytes(ns, handle=hs)))
+                        flags.append(view(_DeviceBytes(nf, handle=hf)))
         except Exception as e:  # noqa: BLE001
             err = e
         agree(err is None, "mapping the peers' buffers", err)
         dist.barrier(group=group)  # nobody launches before everybody has mapped (and zeroed) everything
-        return cls(rank, world, staging, flags, state, max_halfs)
+        return cls(rank, world, staging, flags, state, max_halfs, keepalive=keep)
 
     # ---- use --------------------------------------------------------------------------------------------------------
     def __call__(self, x, out=None):

@@ -5,21 +5,24 @@
 // projections (8 KiB at batch 1 for a 7B model, 16 KiB for 70B): at that size a ring collective is pure latency
 // (2 (P - 1) hops), and -- what matters for bench.py --gpus N -- the whole decode step must stay inside ONE hipGraph.
 //
-// Protocol (one launch per rank, no host involvement, hipGraph-replayable):
-//   every rank owns a staging buffer and a flag block that all peers have mapped (P2P / IPC; the caller passes the P
-//   pointers of each -- in a single-GPU test they are simply P local allocations).  Epoch e = launches so far + 1, kept on
-//   the device; parity e & 1 selects one of two staging / flag halves.  Block b of rank r
-//     1. copies its slice of the input into its own staging half (write-through, system scope),
-//     2. fences, then stores e into flag [e & 1][b][r] of EVERY peer (one xGMI store each),
-//     3. spins (bounded) until its own flags [e & 1][b][0 .. P-1] all read e,
-//     4. reads the slice from every peer's staging half (system-scope loads over xGMI), adds the P vectors in rank order
-//        in fp32 -- every rank computes the bitwise identical sum -- rounds once and writes the output.
-//   No second barrier: a rank overwrites staging half e & 1 at epoch e + 2 only after passing the wait of epoch e + 1, and a
-//   peer raises its flag for e + 1 only after it has finished reading at epoch e.  Blocks are independent (per-block flags),
-//   so nothing needs all blocks of a launch to be resident.
+// Protocol (round 5: a PUSH of self-validating granules -- SURVEY.md 8(e)'s plan; rounds 3-4 wrote locally, flagged the peers and
+// then PULLED every peer's staging over xGMI: one more link round trip on a collective that is pure latency).  One launch per
+// rank, no host involvement, hipGraph-replayable:
+//   every rank owns a staging buffer that all peers have mapped (P2P / IPC; the caller passes the P pointers -- in a single-GPU test
+//   they are simply P local allocations): [2 parities][AWQ_AR_MAX_RANKS sources][n_max / 2] GRANULES of 8 bytes = {two fp16 values,
+//   32-bit epoch tag}, each written by ONE naturally aligned 8-byte system-scope store (untorn: MI355X_MICROARCH.md, hand-off price
+//   list, row handoff-1to1).  Epoch e = launches so far + 1, kept on the device; parity e & 1 selects the half.  Block b of rank r
+//     1. turns its slice of the input into granules tagged e and stores each one into slot [e & 1][r] of EVERY rank's staging
+//        (its own included): P - 1 xGMI store hops, driven in parallel (xGMI is point to point), nothing to fence, no flag;
+//     2. polls ITS OWN staging (local memory) until the granules of all P sources of its slice carry tag e (bounded), adds the P
+//        vectors in rank order in fp32 -- every rank computes the bitwise identical sum -- rounds once and writes the output.
+//   No remote read, no second barrier: a rank overwrites parity e & 1 at epoch e + 2 only after finishing epoch e + 1, whose
+//   granules a peer sends only after it has finished reading at epoch e; a stale granule carries tag e - 2.  Blocks are
+//   independent, so nothing needs all blocks of a launch to be resident.  A peer that never arrives: sticky error word AND NaN in
+//   the affected outputs.  The flag blocks of rounds 3-4 are no longer used (the arguments stay in the ABI; pass any mapped buffer).
 //
-// Cost model: one xGMI store + one dependent poll (~1-2 us) + P remote reads of n / blocks bytes; the P - 1 links of a GPU
-// are driven in parallel (xGMI is point to point), each carrying n bytes once.
+// Cost model: one xGMI store hop + a local poll; each of the P - 1 links of a GPU carries 2 n bytes (granules double the payload)
+// once.  NOT measured over xGMI: this pool has one GPU per box (tests: P ranks in one launch on one GPU, two processes over IPC).
 #include <string.h>
 
 #include "awq_device.h"
@@ -28,8 +31,8 @@
 namespace {
 
 struct ArParams {
-    const unsigned long long* peer_data[AWQ_AR_MAX_RANKS];  // staging of rank p: [2][n_max] fp16 as 8-byte words
-    uint32_t* peer_flags[AWQ_AR_MAX_RANKS];                 // flags of rank p: [2][AWQ_AR_BLOCKS][AWQ_AR_MAX_RANKS]
+    const unsigned long long* peer_data[AWQ_AR_MAX_RANKS];  // staging of rank p: [2][AWQ_AR_MAX_RANKS][n_max / 2] granules {2 x fp16, epoch}
+    uint32_t* peer_flags[AWQ_AR_MAX_RANKS];                 // unused since round 5 (the granules validate themselves)
     // blockIdx.y selects the rank this block acts for: one entry (the product: one process per GPU), or all `world` of them
     // in ONE launch (awq_allreduce_oneshot_group: every rank of a single-process group, guaranteed co-resident)
     const uint16_t* in[AWQ_AR_MAX_RANKS];
@@ -53,51 +56,43 @@ __global__ __launch_bounds__(256) void awq_allreduce_oneshot_kernel(ArParams p) 
     const int rank = p.rank0 + blockIdx.y;
     uint32_t* const state = p.state[blockIdx.y];
     const uint32_t e = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const int par = (int)(e & 1u);
-    const long long words = p.n / 4, per = (words + gridDim.x - 1) / gridDim.x;
-    const long long w0 = (long long)b * per, w1 = w0 + per < words ? w0 + per : words;
-    const long long half_words = p.n_max / 4;
+    const long long par = (long long)(e & 1u);
+    const long long gran = p.n / 2, per = (gran + gridDim.x - 1) / gridDim.x;  // granules (two halfs each); this block's share
+    const long long g0 = (long long)b * per, g1 = g0 + per < gran ? g0 + per : gran;
+    const long long src_stride = p.n_max / 2, par_stride = src_stride * AWQ_AR_MAX_RANKS;
 
-    // 1. my slice -> my staging half
-    unsigned long long* mine = const_cast<unsigned long long*>(p.peer_data[rank]) + par * half_words;
-    const unsigned long long* in64 = reinterpret_cast<const unsigned long long*>(p.in[blockIdx.y]);
-    for (long long w = w0 + tid; w < w1; w += 256) st_sys_u64(mine + w, in64[w]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: my stores are visible before my flag
-    __syncthreads();
-    // 2. tell everybody
-    if (tid < p.world)
-        __hip_atomic_store(p.peer_flags[tid] + ((par * AWQ_AR_BLOCKS + b) * AWQ_AR_MAX_RANKS + rank), e, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    // 3. wait for everybody (bounded).  A peer that never arrives: sticky error word AND a result nobody can mistake for a sum
-    //    (every element of this block's slice becomes NaN) -- ADVICE r03: the first version summed whatever the late peer's
-    //    staging held and returned it as if nothing had happened.
-    __shared__ int timed_out;
-    if (tid == 0) timed_out = 0;
-    __syncthreads();
-    if (tid < p.world) {
-        const uint32_t* f = p.peer_flags[rank] + ((par * AWQ_AR_BLOCKS + b) * AWQ_AR_MAX_RANKS + tid);
-        uint32_t spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > p.max_spin) {
-                __hip_atomic_store(state + 1, 1u + (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                timed_out = 1;
-                break;
-            }
-        }
+    // 1. push: my granules, tagged with the epoch, into slot [parity][my rank] of every rank's staging (one 8-byte store each)
+    const uint32_t* in32 = reinterpret_cast<const uint32_t*>(p.in[blockIdx.y]);
+    for (long long g = g0 + tid; g < g1; g += 256) {
+        const unsigned long long v = (unsigned long long)in32[g] | ((unsigned long long)e << 32);
+        for (int r = 0; r < p.world; ++r)
+            st_sys_u64(const_cast<unsigned long long*>(p.peer_data[r]) + par * par_stride + (long long)rank * src_stride + g, v);
     }
-    __syncthreads();
-    // 4. gather + add in rank order (fp32), one rounding
-    for (long long w = w0 + tid; w < w1; w += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // 2. gather from my own staging: wait (bounded) for the tag of every source, add in rank order (fp32), one rounding.  A peer that
+    //    never arrives: sticky error word AND a result nobody can mistake for a sum (NaN) -- ADVICE r03.
+    const unsigned long long* mine = p.peer_data[rank] + par * par_stride;
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(p.out[blockIdx.y]);
+    for (long long g = g0 + tid; g < g1; g += 256) {
+        float a0 = 0.f, a1 = 0.f;
+        bool late = false;
         for (int r = 0; r < p.world; ++r) {
-            const unsigned long long v = ld_sys_u64(p.peer_data[r] + par * half_words + w);
-            const half2_t lo = u2h2((uint32_t)v), hi = u2h2((uint32_t)(v >> 32));
-            a0 += (float)lo[0]; a1 += (float)lo[1]; a2 += (float)hi[0]; a3 += (float)hi[1];
+            const unsigned long long* src = mine + (long long)r * src_stride + g;
+            unsigned long long v = ld_sys_u64(src);
+            for (uint32_t spins = 0; (uint32_t)(v >> 32) != e; ++spins) {
+                if (spins > p.max_spin) {
+                    __hip_atomic_store(state + 1, 1u + (uint32_t)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    late = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                v = ld_sys_u64(src);
+            }
+            const half2_t h = u2h2((uint32_t)v);
+            a0 += (float)h[0];
+            a1 += (float)h[1];
         }
-        const half2_t lo = {(half_t)a0, (half_t)a1}, hi = {(half_t)a2, (half_t)a3};
-        const unsigned long long sum = (unsigned long long)h22u(lo) | ((unsigned long long)h22u(hi) << 32);
-        reinterpret_cast<unsigned long long*>(p.out[blockIdx.y])[w] = timed_out ? 0x7E007E007E007E00ull : sum;
+        const half2_t o = {(half_t)a0, (half_t)a1};
+        out32[g] = late ? 0x7E007E00u : h22u(o);
     }
     // the last block of the launch closes the epoch
     __syncthreads();
@@ -112,7 +107,8 @@ __global__ __launch_bounds__(256) void awq_allreduce_oneshot_kernel(ArParams p) 
 
 }  // namespace
 
-size_t awq_allreduce_staging_bytes(int64_t max_halfs) { return max_halfs > 0 ? (size_t)2 * ((max_halfs + 3) / 4 * 4) * 2 : 0; }
+// [2 parities][AWQ_AR_MAX_RANKS sources][n_max / 2 granules] x 8 bytes
+size_t awq_allreduce_staging_bytes(int64_t max_halfs) { return max_halfs > 0 ? (size_t)2 * AWQ_AR_MAX_RANKS * (((max_halfs + 3) / 4 * 4) / 2) * 8 : 0; }
 size_t awq_allreduce_flag_bytes(void) { return (size_t)2 * AWQ_AR_BLOCKS * AWQ_AR_MAX_RANKS * sizeof(uint32_t); }
 size_t awq_allreduce_state_bytes(void) { return 4 * sizeof(uint32_t); }
 
@@ -191,7 +187,7 @@ int launch_allreduce(const void* const* peer_staging, void* const* peer_flags, i
     p.n = n_halfs; p.n_max = (max_halfs + 3) / 4 * 4;
     p.rank0 = rank0; p.world = (int)world;
     p.max_spin = 1u << 20;  // ~ a second: a peer that never arrives raises the sticky error instead of hanging the GPU
-    int blocks = (int)((n_halfs / 4 + 511) / 512);  // >= 512 8-byte words (4 KiB) per block
+    int blocks = (int)((n_halfs / 2 + 1023) / 1024);  // >= 1024 granules (2 KiB of payload) per block
     if (blocks < 1) blocks = 1;
     if (blocks > AWQ_AR_BLOCKS) blocks = AWQ_AR_BLOCKS;
     hipLaunchKernelGGL(awq_allreduce_oneshot_kernel, dim3((unsigned)blocks, (unsigned)nranks), dim3(256), 0, static_cast<hipStream_t>(stream), p);

@@ -106,11 +106,11 @@ bool awq_gemv_lds_supports(int M, int K, int N, int g);
 int awq_launch_gemv_lds(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
                         int M, int K, int N, int g, int ZW, int ks, int depth, hipStream_t st);
 // GEMV layout, 1 <= M <= 32 per launch, group_size 128: activations as MFMA A fragments in registers, the K range of a 16-row tile
-// split over the waves of one block, weights by LDS-DMA (gemv_batch.hip).  gw: 128-k groups per wave and pass (4|8), depth: pieces
-// in flight per wave (1..3); 0 = auto.
+// split over the waves of one block, weights by LDS-DMA (gemv_batch.hip).  form: activations through a wave-private LDS staging area
+// (1) or by direct fragment loads (2); depth: pieces in flight per wave (1..3); 0 = auto.
 bool awq_gemv_batch_supports(int M, int K, int N, int g);
 int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
-                          int M, int K, int N, int g, int ZW, int gw, int depth, hipStream_t st);
+                          int M, int K, int N, int g, int ZW, int form, int depth, hipStream_t st);
 // GEMV layout, prefill-sized batches: the register-decoded MFMA GEMM reading the layout's own buffers (gemm_regb.hip, NK form)
 bool awq_gemm_regb_nk_supports(int M, int K, int N, int g, int ZW);
 int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,

@@ -13,27 +13,31 @@
 //    barriers before the first MFMA: start-up bound (11.5 us at 4096 x 11008, M = 8, against 5.2 us at M = 1), and it cannot
 //    take M = 16 at K = 4096 or any batch at K = 11008.  The register-fetch N-major forms (gemm_skinny MODE 1 / 2, round 4's
 //    staged experiment, profiles/r05_first_call/skinny_nk.txt) read 16 rows x 64 bytes per wave instruction: 21-25 us at every M.
-//  * Here a block's eight waves split the K range of a 16-row tile: wave wk owns GW consecutive 128-k groups, so its
-//    activations are MI x GW x 4 MFMA A fragments that stay in (at most 128) REGISTERS for the whole launch -- no LDS
-//    staging, no block barrier before the first MFMA, no LDS read on the A side of any MFMA.  They come straight from L2 (x is
-//    M x K x 2 bytes) by 16-byte loads requested ahead of the weights.
-//  * Weights: a PIECE = 16 rows x (GW x 64) bytes of ONE wave's K range, by GW LDS-DMA instructions (`global_load_lds_dwordx4`,
-//    1 KiB each = 4 rows x 256 B for GW 4, 2 rows x 512 B for GW 8; the eight waves of the block together read the tile's rows
-//    end to end) + one for the rows' scales (16 bytes per row) + one for the zero words: GW + 2 identical vector-memory
-//    instructions per piece, so `s_waitcnt vmcnt((GW + 2)(RD - 1))` names exactly one ring slot; no VGPR is a DMA destination.
-//    A 16-byte chunk XOR swizzle applied on the GLOBAL side (lane i of a row fetches chunk i ^ row) makes the ds_read_b128
-//    fragment reads (lane (n, kq): chunk 4 u + kq of row n = the B operands of four MFMAs) bank-conflict free without padding.
-//  * Decode: (w - z) * s in fp16 -- the reference's dequantised weight exactly (awq/utils/packing_utils.py:98-100: integer
-//    subtract, one rounding in the multiply) -- nibbles stay in place under the exponents 2^10 / 2^6 (five VALU per word), four
-//    packed subtracts of (bias + z), four packed multiplies; the activations are pair-permuted to the (t, t+4) order that leaves.
-//    fp32 accumulation in v_mfma_f32_16x16x32_f16.  One-hot and zero inputs stay exact.
+//  * Here a block's eight waves split the K range of a 16-row tile: wave wk owns GW = 4 consecutive 128-k groups (512 k), so its
+//    activations are MI x 16 MFMA A fragments that stay in (at most 128) REGISTERS for the whole pass -- no block barrier before
+//    the first MFMA, no LDS read on the A side of any MFMA.
+//  * Weights: a PIECE = 16 rows x 256 bytes of ONE wave's K range, by four LDS-DMA instructions (`global_load_lds_dwordx4`, 1 KiB
+//    each = 4 rows x 256 B; the eight waves of the block together read the tile's rows end to end) + one for the rows' scales
+//    (16 bytes per row) + one for the zero words: LDM = 6 identical vector-memory instructions per piece, so
+//    `s_waitcnt vmcnt(6 (RD - 1))` names exactly one ring slot; no VGPR is a DMA destination.  A 16-byte chunk XOR swizzle applied
+//    on the GLOBAL side (lane i of a row fetches chunk i ^ row) makes the ds_read_b128 fragment reads (lane (n, kq): chunk
+//    4 u + kq of row n = the B operands of four MFMAs) bank-conflict free without padding.
+//  * Activations (first version, profiles/r05_gemv_batch_trace_first.txt: 16 bytes per lane straight into fragment position =
+//    16 rows x 4 x 16 B per instruction; ISSUING those took 1.3 us per wave at M = 8 and 5.4 us at M = 32 -- the CU's one address
+//    path walks 32 cache lines per instruction): XS form -- each batch row's 1 KiB of the wave's K range arrives by ONE coalesced
+//    LDS-DMA instruction into a wave-private staging area (swizzled on the global side), then 16 MI ds_read_b128 put the fragments
+//    into registers; no barrier (the wave reads only what it requested itself).  The staging area is dead afterwards and holds the
+//    partial-tile buffers.  When M KiB x 8 waves do not fit beside the ring (M > 12 or so) the direct form stays.
+//  * Decode: nibbles stay in place under the exponents 2^10 / 2^6 (five VALU per word), four packed subtracts of (bias + z): the
+//    EXACT integers w - z in fp16; products and the fp32 accumulation in v_mfma_f32_16x16x32_f16 are exact per term; the group's
+//    scale multiplies the group's fp32 sum (4 MI fused multiply-adds per group instead of four packed multiplies per word: the first
+//    version spent 13 VALU per word and 0.85 us per piece, VALU-bound).  One-hot and zero inputs stay exact; f(2x) = 2 f(x).
 //  * The wk partial tiles of a block meet in LDS behind ONE raw s_barrier per tile (the DMA ring stays in flight across it; LDS
 //    writes are drained by hand: `__syncthreads()` would wait for vmcnt(0)), summed in wave order: bitwise reproducible.  Nothing
 //    crosses a CU: no workspace, no exchange.  y is parked in LDS (fp32) and written after the stream has drained (a store
 //    inside the stream would break the counted waits: stores count in vmcnt but do not retire in order with loads).
-//  * K beyond one pass (8 waves x GW groups: 4096 / 8192 k) is walked in PASSES: the A fragments of the next K range are
-//    re-requested (a drain: they queue behind the ring), the ring keeps running across the pass edge, partial sums add up in the
-//    parked tiles.  K = 11008 (86 groups): two passes at GW 8, three at GW 4.
+//  * K beyond one pass (8 waves x 512 k) is walked in PASSES: the A fragments of the next K range are re-requested (a drain: they
+//    queue behind the ring), the ring keeps running across the pass edge, partial sums add up in the parked tiles.
 //  * M > 32 is two launches from the C API (the A fragments of 64 rows do not fit the register file beside a useful K range).
 #include <type_traits>
 
@@ -41,6 +45,11 @@
 #include "awq_internal.h"
 
 namespace {
+
+constexpr int GW = 4;                          // 128-k groups per wave and pass
+constexpr int PIECE_W = 16 * GW * 64;          // bytes of weights per piece: 16 rows x GW groups x 64 bytes
+constexpr int PIECE_B = PIECE_W + 1024 + 256;  // + the rows' scales (64 x 16-byte slots) + zero words (64 x 4)
+constexpr int LDM = GW + 2;                    // vector-memory instructions per piece request
 
 struct BatchParams {
     const uint32_t* qweight;
@@ -54,13 +63,13 @@ struct BatchParams {
     int wk, wt;      // waves side by side on a tile's K range, tile owners per block (wk * wt == 8)
     int passes;      // ceil(G / (wk * GW))
     int tiles_base, tiles_rem, tiles_max;  // tiles per owner: base (+1 for the first rem owners)
-    int ring_off, pbuf_off, ystage_off;    // LDS byte offsets
+    int ring_off, pbuf_off, pbuf_pitch, ystage_off;  // LDS byte offsets; pbuf_pitch: bytes per wave (XS: the wave's staging area)
     unsigned long long* trace;             // debug builds only (tools/trace_gemv_batch.py)
 };
 
 // Debug builds only (tools/trace_gemv_batch.py): -DAWQ_GEMV_TRACE stamps the phases of every wave (kept in registers, stored after the
 // stream has drained); -DAWQ_BT_DBG=bits switches parts off (results are wrong by design): 1 = every lane requests the SAME 16 bytes of
-// x (the request count stays, the 16-rows-x-64-bytes scatter goes), 2 = no decode / MFMA, 4 = no partial-tile exchange (no barrier).
+// x (direct form: the request count stays, the 16-rows-x-64-bytes scatter goes), 2 = no decode / MFMA, 4 = no partial-tile exchange.
 #ifndef AWQ_BT_DBG
 #define AWQ_BT_DBG 0
 #endif
@@ -77,7 +86,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define AWQ_BT_DMA4(voff, base, ldsaddr) \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(ldsaddr) : "memory", "m0")
 #define AWQ_BT_LOAD16(dst, voff, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory")
-// 16 registers-quads per statement (asm operand lists are bounded); the count sits in the first one of a group
+// 16 register quads per statement (asm operand lists are bounded)
 #define AWQ_BT_WAIT16(X, o, cnt)                                                                                                   \
     asm volatile("s_waitcnt vmcnt(%16)"                                                                                            \
                  : "+v"(X[o + 0]), "+v"(X[o + 1]), "+v"(X[o + 2]), "+v"(X[o + 3]), "+v"(X[o + 4]), "+v"(X[o + 5]), "+v"(X[o + 6]), \
@@ -89,16 +98,16 @@ AWQ_DEV float4_t mfma16(u32x4 a, u32x4 b, float4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
 }
 
-// MI: 16-row batch tiles (1 | 2); GW: 128-k groups per wave and pass (4 | 8; MI * GW <= 8); RD: pieces in flight per wave
-template <int MI, int GW, int RD>
+// staging swizzle of the activations (XS form): chunk j (16 bytes = 8 k) of batch row m sits at chunk slot
+// (j & 48) | ((j & 15) ^ f(m)), f(m) = the two 2-bit halves of m & 15 swapped: the sixteen lanes a ds_read_b128 serves together
+// (rows {0-3, 12-15} of one kq with rows {4-11} of the next) then hit sixteen different 16-byte columns
+AWQ_DEV int xs_f(int m) { return ((m & 3) << 2) | ((m >> 2) & 3); }
+
+// MI: 16-row batch tiles (1 | 2); RD: pieces in flight per wave; XS: the activations reach the registers through a wave-private
+// LDS staging area (coalesced LDS-DMA) instead of 16-byte fragment loads
+template <int MI, int RD, bool XS>
 __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
-    static_assert(MI * GW <= 8, "the A fragments of a wave are 16 MI GW registers");
-    constexpr int PIECE_W = 16 * GW * 64;          // bytes of weights per piece: 16 rows x GW groups x 64 bytes
-    constexpr int PIECE_B = PIECE_W + 1024 + 256;  // + the rows' scales (64 x 16-byte slots) + zero words (64 x 4)
-    constexpr int LDM = GW + 2;                    // vector-memory instructions per piece request
-    constexpr int CPR = 4 * GW;                    // 16-byte chunks per row of a piece (16 | 32)
-    constexpr int RPI = 64 / CPR;                  // rows per DMA instruction (4 | 2)
-    constexpr int NA = MI * GW * 4;                // A fragments (16 bytes each) per lane
+    constexpr int NA = MI * GW * 4;  // A fragments (16 bytes each) per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,6 +122,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     const int nunit = ntile * p.passes;  // live units of this wave, flat: u = pass * ntile + tile
     const int ring = p.ring_off + wave * RD * PIECE_B;
     const int rowbytes = p.KW * 4;
+    const int xs_w = p.pbuf_off + wave * p.pbuf_pitch;  // XS: this wave's staging area [M][1 KiB]; later its partial-tile buffers
 #ifdef AWQ_GEMV_TRACE
     unsigned long long ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -129,9 +139,8 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
         const uint32_t slot = lds0 + (uint32_t)(ring + (u % RD) * PIECE_B);
 #pragma unroll
         for (int i = 0; i < GW; ++i) {
-            const int r = i * RPI + lane / CPR;  // row of the tile
-            const int pos = lane % CPR;          // chunk slot in LDS
-            const int c = (pos & 16) | ((pos ^ r) & 15);
+            const int r = i * 4 + (lane >> 4);  // row of the tile (four rows of 256 bytes per instruction)
+            const int c = ((lane & 15) ^ r) & 15;
             const int byte = min(g0 * 64 + 16 * c, rowbytes - 16);  // past the row end (a ragged or dead piece): its last chunk (A is 0 there)
             const uint32_t voff = live ? (uint32_t)(min(row0 + r, p.N - 1) * rowbytes + byte) : 0u;
             AWQ_BT_DMA16(voff, p.qweight, slot + 1024u * i);
@@ -147,21 +156,47 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 
     // ---- activations of pass ps -> A fragments in registers (pair-permuted), zero for batch rows >= M and groups >= G
     u32x4 afr[NA];
-    auto load_a = [&](int ps) {
+    auto request_a = [&](int ps) {
         const int g0 = (ps * p.wk + wki) * GW;
+        if constexpr (XS) {  // one coalesced 1-KiB instruction per batch row (the wave's 512 k of it), swizzled on the global side
+            for (int m = 0; m < M; ++m) {
+                const int j = (lane & 48) | ((lane & 15) ^ xs_f(m));
+                const int byte = min(256 * g0 + 16 * j, p.K * 2 - 16);
+                AWQ_BT_DMA16((uint32_t)(m * p.K * 2 + byte), p.x, lds0 + (uint32_t)(xs_w + m * 1024));
+            }
+        } else {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int u = 0; u < GW; ++u)
+                for (int u = 0; u < GW; ++u)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int m = min(16 * mi + n, M - 1);
-                    const int kk = min(128 * (g0 + u) + 32 * kq + 8 * c, p.K - 8);
-                    AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (AWQ_BT_DBG & 1) ? 0u : (uint32_t)((m * p.K + kk) * 2), p.x);
-                }
+                    for (int c = 0; c < 4; ++c) {  // (lanes of batch rows >= M repeat row M - 1's addresses: no more lines per instruction)
+                        const int m = min(16 * mi + n, M - 1);
+                        const int kk = min(128 * (g0 + u) + 32 * kq + 8 * c, p.K - 8);
+                        AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (AWQ_BT_DBG & 1) ? 0u : (uint32_t)((m * p.K + kk) * 2), p.x);
+                    }
+        }
     };
-    auto permute_a = [&](int ps) {
+    auto collect_a = [&](int ps, auto cnt_c) __attribute__((always_inline)) {  // wait (cnt newer requests may be pending), then fragments
+        constexpr int CNT = decltype(cnt_c)::value;
         const int g0 = (ps * p.wk + wki) * GW;
+        if constexpr (XS) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = min(16 * mi + n, M - 1);
+                const unsigned char* row = smem + xs_w + m * 1024;
+                const int f = xs_f(m);
+#pragma unroll
+                for (int u = 0; u < GW; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) afr[(mi * GW + u) * 4 + c] = *reinterpret_cast<const u32x4*>(row + 16 * (16 * u + ((4 * kq + c) ^ f)));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area is dead from here (it becomes the partial-tile buffers)
+        } else {
+            AWQ_BT_WAIT16(afr, 0, CNT);
+            if constexpr (NA > 16) AWQ_BT_WAIT16(afr, 16, CNT);
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -180,30 +215,25 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 }
             }
     };
-    auto wait_a = [&](auto cnt_c) __attribute__((always_inline)) {
-        constexpr int CNT = decltype(cnt_c)::value;
-        AWQ_BT_WAIT16(afr, 0, CNT);
-        if constexpr (NA > 16) AWQ_BT_WAIT16(afr, 16, CNT);
-    };
 
-    load_a(0);
+    request_a(0);
 #pragma unroll
     for (int d = 0; d < RD; ++d) request(d);
     BT_STAMP(1);
-    wait_a(std::integral_constant<int, LDM * RD>{});  // everything older than the ring requests: the activations
-    BT_STAMP(2);
-    permute_a(0);
+    collect_a(0, std::integral_constant<int, LDM * RD>{});  // everything older than the ring requests: the activations
     BT_STAMP(3);
 
     // ---- stream
-    float4_t* pbuf = reinterpret_cast<float4_t*>(smem + p.pbuf_off);      // [2][8 waves][MI][64 lanes]
     float4_t* ystage = reinterpret_cast<float4_t*>(smem + p.ystage_off);  // [wt][tiles_max][MI][64 lanes]
+    auto pbuf = [&](int w, int parity, int mi) { return reinterpret_cast<float4_t*>(smem + p.pbuf_off + w * p.pbuf_pitch + (parity * MI + mi) * 1024); };
     int u = 0, it = 0;  // live units requested so far; iterations (the parity of the partial-tile buffer)
     for (int ps = 0; ps < p.passes; ++ps) {
         if (ps > 0) {  // the next K range of the activations (they queue behind the ring: a drain)
-            load_a(ps);
-            wait_a(std::integral_constant<int, 0>{});
-            permute_a(ps);
+            if constexpr (XS) {
+                if (p.wk > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // nobody still reads the partial tiles the staging overwrites
+            }
+            request_a(ps);
+            collect_a(ps, std::integral_constant<int, 0>{});
         }
         const int g0 = (ps * p.wk + wki) * GW;
         for (int tl = 0; tl < p.tiles_max; ++tl, ++it) {
@@ -221,11 +251,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 const u32x4 sq = *reinterpret_cast<const u32x4*>(slot + PIECE_W + 16 * lane);  // 8 scales: groups (g0 & ~7) ..
                 u32x4 wq[GW];
 #pragma unroll
-                for (int uu = 0; uu < GW; ++uu) {
-                    const int q = 4 * uu + kq;
-                    const int pos = (q & 16) | ((q ^ n) & 15);
-                    wq[uu] = *reinterpret_cast<const u32x4*>(slot + n * (CPR * 16) + pos * 16);
-                }
+                for (int uu = 0; uu < GW; ++uu) wq[uu] = *reinterpret_cast<const u32x4*>(slot + n * 256 + (((4 * uu + kq) ^ n) & 15) * 16);
                 if constexpr (AWQ_BT_DBG & 2) {
 #pragma unroll
                     for (int uu = 0; uu < GW; ++uu) acc[0] += __builtin_bit_cast(float4_t, wq[uu]) + __builtin_bit_cast(float4_t, sq) + (float)zw;
@@ -236,20 +262,27 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                     const uint32_t z = (zw >> (4 * gi)) & 15u;
                     const half2_t zlo = u2h2(0x64006400u | z | (z << 16));         // (1024 + z, 1024 + z)
                     const half2_t zhi = u2h2(0x54005400u | (z << 4) | (z << 20));  // (64 + z, 64 + z)
-                    // (GW 4: g0 & 7 is 0 or 4 -- the piece's four scales are the low or the high 8 bytes of the chunk; GW 8: all of it)
-                    const uint32_t sw = GW == 8 ? sq[uu >> 1] : ((g0 & 4) ? sq[2 + (uu >> 1)] : sq[uu >> 1]);
-                    const half2_t s2 = u2h2((uu & 1) ? __builtin_amdgcn_perm(sw, sw, 0x03020302u) : __builtin_amdgcn_perm(sw, sw, 0x01000100u));
+                    // (g0 & 7 is 0 or 4: the piece's four scales are the low or the high 8 bytes of the chunk)
+                    const uint32_t sw = (g0 & 4) ? sq[2 + (uu >> 1)] : sq[uu >> 1];
+                    const float sc = (float)u2h2(sw)[uu & 1];
+                    float4_t gacc[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) gacc[mi] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const uint32_t ww = wq[uu][c], w8 = ww >> 8;
-                        u32x4 b;
-                        b[0] = h22u((u2h2(and_or(ww, 0x000F000Fu, 0x64006400u)) - zlo) * s2);
-                        b[1] = h22u((u2h2(and_or(ww, 0x00F000F0u, 0x54005400u)) - zhi) * s2);
-                        b[2] = h22u((u2h2(and_or(w8, 0x000F000Fu, 0x64006400u)) - zlo) * s2);
-                        b[3] = h22u((u2h2(and_or(w8, 0x00F000F0u, 0x54005400u)) - zhi) * s2);
+                        u32x4 b;  // the exact integers w - z
+                        b[0] = h22u(u2h2(and_or(ww, 0x000F000Fu, 0x64006400u)) - zlo);
+                        b[1] = h22u(u2h2(and_or(ww, 0x00F000F0u, 0x54005400u)) - zhi);
+                        b[2] = h22u(u2h2(and_or(w8, 0x000F000Fu, 0x64006400u)) - zlo);
+                        b[3] = h22u(u2h2(and_or(w8, 0x00F000F0u, 0x54005400u)) - zhi);
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma16(afr[(mi * GW + uu) * 4 + c], b, acc[mi]);
+                        for (int mi = 0; mi < MI; ++mi) gacc[mi] = mfma16(afr[(mi * GW + uu) * 4 + c], b, gacc[mi]);
                     }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[mi][r] = __builtin_fmaf(sc, gacc[mi][r], acc[mi][r]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the slot has returned before it is overwritten
                 request(u + RD);
@@ -262,15 +295,15 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             if (p.wk > 1 && !(AWQ_BT_DBG & 4)) {
                 if (live) {
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) pbuf[(((it & 1) * 8 + wave) * MI + mi) * 64 + lane] = acc[mi];
+                    for (int mi = 0; mi < MI; ++mi) pbuf(wave, it & 1, mi)[lane] = acc[mi];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (live) {
                     const int f = wki + p.wk * lane;  // this wave's share of the tile's MI x 64 float4 slots
                     if (f < 64 * MI) {
                         const int mi = f >> 6, sl = f & 63;
-                        float4_t s = pbuf[(((it & 1) * 8 + twi * p.wk) * MI + mi) * 64 + sl];
-                        for (int j = 1; j < p.wk; ++j) s += pbuf[(((it & 1) * 8 + twi * p.wk + j) * MI + mi) * 64 + sl];
+                        float4_t s = pbuf(twi * p.wk, it & 1, mi)[sl];
+                        for (int j = 1; j < p.wk; ++j) s += pbuf(twi * p.wk + j, it & 1, mi)[sl];
                         float4_t* dst = ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64 + sl;
                         *dst = ps > 0 ? *dst + s : s;
                     }
@@ -311,26 +344,23 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 #endif
 }
 
-constexpr int piece_bytes(int GW) { return 16 * GW * 64 + 1024 + 256; }
-
 struct BatchPlan {
-    int MI, GW, RD, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max;
-    size_t ring, pbuf, ystage;
+    int MI, RD, XS, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max;
+    size_t ring, pbuf_pitch, ystage;
 };
 
-bool plan_batch(int M, int K, int N, int g, int gw_req, int rd_req, BatchPlan* out) {
+// form: 0 = auto, 1 = activations through the LDS staging area (XS), 2 = direct fragment loads
+bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out) {
     if (M < 1 || M > 32 || N < 1 || K < 128 || K % 128 || g != 128) return false;
     if ((int64_t)N * K / 2 >= ((int64_t)1 << 31) || (int64_t)M * K * 2 >= ((int64_t)1 << 31)) return false;  // 32-bit lane offsets
     BatchPlan b;
     b.MI = M > 16 ? 2 : 1;
     const int G = K / 128;
-    b.GW = (gw_req == 4 || gw_req == 8) ? gw_req : (b.MI == 1 && G >= 64 ? 8 : 4);
-    if (b.MI * b.GW > 8) b.GW = 4;
     int wk = 1;
-    while (wk < 8 && wk * b.GW < G) wk *= 2;
+    while (wk < 8 && wk * GW < G) wk *= 2;
     b.wk = wk;
     b.wt = 8 / wk;
-    b.passes = (G + wk * b.GW - 1) / (wk * b.GW);
+    b.passes = (G + wk * GW - 1) / (wk * GW);
     const int tiles = (N + 15) / 16;
     const int want = (tiles + b.wt - 1) / b.wt;
     b.blocks = want < 256 ? want : 256;
@@ -338,15 +368,20 @@ bool plan_batch(int M, int K, int N, int g, int gw_req, int rd_req, BatchPlan* o
     b.tiles_base = tiles / owners;
     b.tiles_rem = tiles % owners;
     b.tiles_max = b.tiles_base + (b.tiles_rem ? 1 : 0);
-    b.pbuf = wk > 1 ? (size_t)2 * 8 * b.MI * 1024 : 0;
     b.ystage = (size_t)b.wt * b.tiles_max * b.MI * 1024;
-    const size_t fixed = b.pbuf + b.ystage;
-    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : (b.GW == 4 ? 3 : 2);
-    while (rd > 1 && fixed + (size_t)8 * rd * piece_bytes(b.GW) > 160 * 1024) --rd;
-    if (fixed + (size_t)8 * rd * piece_bytes(b.GW) > 160 * 1024) return false;
-    if (b.GW == 8 && rd == 3) rd = 2;  // (not instantiated)
+    const size_t plain = wk > 1 ? (size_t)2 * b.MI * 1024 : 0, staged = (size_t)M * 1024 > plain ? (size_t)M * 1024 : plain;
+    const size_t budget = 160 * 1024;
+    // XS when the staging area (M KiB per wave, the partial-tile buffers live in it afterwards) fits beside at least one ring slot per wave
+    const bool xs = form != 2 && b.ystage + 8 * staged + (size_t)8 * PIECE_B <= budget;
+    if (form == 1 && !xs) return false;
+    b.XS = xs ? 1 : 0;
+    b.pbuf_pitch = xs ? staged : plain;
+    const size_t fixed = b.ystage + 8 * b.pbuf_pitch;
+    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : 2;
+    while (rd > 1 && fixed + (size_t)8 * rd * PIECE_B > budget) --rd;
+    if (fixed + (size_t)8 * rd * PIECE_B > budget) return false;
     b.RD = rd;
-    b.ring = (size_t)8 * rd * piece_bytes(b.GW);
+    b.ring = (size_t)8 * rd * PIECE_B;
     *out = b;
     return true;
 }
@@ -365,11 +400,12 @@ bool awq_gemv_batch_supports(int M, int K, int N, int g) {
     return plan_batch(M, K, N, g, 0, 0, &b);
 }
 
-// gw: 128-k groups per wave and pass (4 | 8, 0 = auto); depth: pieces in flight per wave (1 .. 3, 0 = auto)
+// form: how the activations reach the registers (0 = auto, 1 = LDS staging area, 2 = direct fragment loads); depth: pieces in flight
+// per wave (1 .. 3, 0 = auto)
 int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
-                          int M, int K, int N, int g, int ZW, int gw, int depth, hipStream_t st) {
+                          int M, int K, int N, int g, int ZW, int form, int depth, hipStream_t st) {
     BatchPlan b;
-    if (!plan_batch(M, K, N, g, gw, depth, &b)) return AWQ_ERR_UNSUPPORTED;
+    if (!plan_batch(M, K, N, g, form, depth, &b)) return AWQ_ERR_UNSUPPORTED;
     if (ZW * 8 < K / 128) return AWQ_ERR_BAD_SHAPE;
     BatchParams p;
     p.qweight = reinterpret_cast<const uint32_t*>(qweight);
@@ -384,22 +420,23 @@ int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint1
     p.tiles_base = b.tiles_base; p.tiles_rem = b.tiles_rem; p.tiles_max = b.tiles_max;
     p.ring_off = 0;
     p.pbuf_off = (int)b.ring;
-    p.ystage_off = (int)(b.ring + b.pbuf);
+    p.pbuf_pitch = (int)b.pbuf_pitch;
+    p.ystage_off = (int)(b.ring + 8 * b.pbuf_pitch);
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_batch_trace;
 #else
     p.trace = nullptr;
 #endif
-    const size_t lds = b.ring + b.pbuf + b.ystage;
-#define AWQ_BT_CASE(MIV, GWV, RDV)                                                                                                 \
-    if (b.MI == MIV && b.GW == GWV && b.RD == RDV) {                                                                               \
-        static std::atomic<unsigned long long> opted{0};                                                                           \
-        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_batch_kernel<MIV, GWV, RDV>), opted)) return AWQ_ERR_LAUNCH;   \
-        hipLaunchKernelGGL((awq_gemv_batch_kernel<MIV, GWV, RDV>), dim3((unsigned)b.blocks), dim3(512), lds, st, p);               \
-        return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;                                                          \
+    const size_t lds = b.ring + 8 * b.pbuf_pitch + b.ystage;
+#define AWQ_BT_CASE(MIV, RDV, XSV)                                                                                                   \
+    if (b.MI == MIV && b.RD == RDV && b.XS == XSV) {                                                                                 \
+        static std::atomic<unsigned long long> opted{0};                                                                             \
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_batch_kernel<MIV, RDV, (XSV != 0)>), opted)) return AWQ_ERR_LAUNCH; \
+        hipLaunchKernelGGL((awq_gemv_batch_kernel<MIV, RDV, (XSV != 0)>), dim3((unsigned)b.blocks), dim3(512), lds, st, p);          \
+        return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;                                                            \
     }
-    AWQ_BT_CASE(1, 4, 1) AWQ_BT_CASE(1, 4, 2) AWQ_BT_CASE(1, 4, 3) AWQ_BT_CASE(1, 8, 1) AWQ_BT_CASE(1, 8, 2)
-    AWQ_BT_CASE(2, 4, 1) AWQ_BT_CASE(2, 4, 2) AWQ_BT_CASE(2, 4, 3)
+    AWQ_BT_CASE(1, 1, 0) AWQ_BT_CASE(1, 2, 0) AWQ_BT_CASE(1, 3, 0) AWQ_BT_CASE(2, 1, 0) AWQ_BT_CASE(2, 2, 0) AWQ_BT_CASE(2, 3, 0)
+    AWQ_BT_CASE(1, 1, 1) AWQ_BT_CASE(1, 2, 1) AWQ_BT_CASE(1, 3, 1) AWQ_BT_CASE(2, 1, 1) AWQ_BT_CASE(2, 2, 1) AWQ_BT_CASE(2, 3, 1)
 #undef AWQ_BT_CASE
     return AWQ_ERR_UNSUPPORTED;
 }

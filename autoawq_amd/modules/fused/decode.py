@@ -37,6 +37,16 @@ class GraphedDecoder:
         if self.device.type != "cuda":
             raise RuntimeError("GraphedDecoder needs the model on a HIP device")
         self.batch = int(batch)
+        # A captured step bakes every HOST-side length into the graph.  Only the native decode path of QuantAttentionFused (head_dim
+        # 128 with 1, 2, 4 or 8 query heads per KV head: csrc/decoder.hip) reads its positions from the device words; other head
+        # shapes slice the cache with the host's start_pos and would attend over the capture-time row count on every replay
+        # (ADVICE r04): refuse them here instead of returning silently wrong logits.
+        for i, b in enumerate(self.blocks):
+            a = b.attn
+            if a.head_dim != 128 or a.n_kv_groups not in (1, 2, 4, 8):
+                raise NotImplementedError(f"GraphedDecoder: block {i} has head_dim {a.head_dim} and {a.n_kv_groups} query heads per KV head; "
+                                          "only the native decode attention (head_dim 128; 1, 2, 4 or 8 heads per KV head) takes its "
+                                          "positions from the device -- decode this model eagerly")
         self.max_seq_len = min(b.attn.max_seq_len for b in self.blocks)
         bounds = sorted(set(min(int(b), self.max_seq_len) for b in (buckets or self.BUCKETS)))
         if bounds[-1] < self.max_seq_len:
@@ -60,7 +70,7 @@ class GraphedDecoder:
 
     def seek(self, position):
         """Declare that `position` cache rows are valid (benchmarks and tests that fill the caches themselves)."""
-        if not 0 <= position < self.max_seq_len:
+        if not 0 <= position <= self.max_seq_len:  # (== max_seq_len: a full window -- the next step rolls it first)
             raise ValueError(f"position {position} outside the cache window {self.max_seq_len}")
         self.position = int(position)
         self.pos.fill_(self.position)
@@ -112,19 +122,14 @@ class GraphedDecoder:
         self.graphs[bound] = (graph, logits)
         return self.graphs[bound]
 
-    @torch.inference_mode()
-    def step(self, token_ids):
-        """token_ids [batch, 1] (or [batch]): the tokens at the current position.  Returns the logits [batch, 1, vocab] -- the
-        graph's static output buffer, overwritten by the next step."""
+    def _advance(self):
+        """What `step` and `replay` share: roll a full window, pick (or capture) the bucket's graph, replay it on the decoder's stream
+        between the caller's work, advance the position on the host as the graph did on the device."""
         if self.position + 1 > self.max_seq_len:  # past the window: forget the oldest positions (eagerly)
             live = [b.attn.cache.roll_kv_n_steps(self.position, n=StepPlan.ROLL) for b in self.blocks][0]
             self.seek(live)
         bound = self.bucket(self.position + 1)
-        entry = self.graphs.get(bound)
-        self.tok.copy_(token_ids.reshape(self.batch, 1))
-        if entry is None:
-            entry = self._capture(bound)
-        graph, logits = entry
+        graph, logits = self.graphs.get(bound) or self._capture(bound)
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)   # the ids were copied on the caller's stream
         with torch.cuda.stream(self.stream):
@@ -135,11 +140,14 @@ class GraphedDecoder:
         return logits
 
     @torch.inference_mode()
+    def step(self, token_ids):
+        """token_ids [batch, 1] (or [batch]): the tokens at the current position.  Returns the logits [batch, 1, vocab] -- the
+        graph's static output buffer, overwritten by the next step."""
+        self.tok.copy_(token_ids.reshape(self.batch, 1))
+        return self._advance()
+
+    @torch.inference_mode()
     def replay(self):
         """The current bucket's graph once more on the decoder's stream with the ids already in place (benchmarks: no host
-        copies in the timed region).  Advances the position like `step`."""
-        bound = self.bucket(self.position + 1)
-        graph, logits = self.graphs.get(bound) or self._capture(bound)
-        graph.replay()
-        self.position += 1
-        return logits
+        copies in the timed region).  Same roll / stream / host bookkeeping as `step`."""
+        return self._advance()

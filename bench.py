@@ -43,7 +43,7 @@ MODELS = {  # hidden, intermediate, layers, heads, kv heads
     "70b": dict(hidden=8192, inter=28672, layers=80, heads=64, kv_heads=8, name="Llama-3-70B"),
 }
 HIDDEN, INTER, LAYERS = 4096, 11008, 32  # the headline model (kept as names for tools/ that import them)
-PMC_FILE = "r04_pmc_fetch_size.txt"      # rocprofv3 --pmc FETCH_SIZE pass of the headline command (tools/prof_r04.sh)
+PMC_FILE = "r05_pmc_fetch_size.txt"      # rocprofv3 --pmc FETCH_SIZE pass of the headline command (tools/prof_r05.sh)
 KERNEL_OF_LAYOUT = {"gemv": "awq_gemv_rows_kernel", "gemm": "awq_gemv_mfma_kernel", "gemvfast": "awq_gemv_fast_kernel"}
 
 
@@ -63,7 +63,7 @@ def kernel_fingerprint():
 
 def pmc_traffic_per_launch():
     """(mean HBM bytes per launch of the headline kernels from the committed FETCH_SIZE pass, note).  The pass is its own
-    rocprofv3 run (tools/prof_r04.sh); its file records the kernel-source fingerprint it was taken at, and a file taken from
+    rocprofv3 run (tools/prof_r05.sh); its file records the kernel-source fingerprint it was taken at, and a file taken from
     other kernel sources than the ones in this tree is NOT reported as this build's traffic."""
     import re
 

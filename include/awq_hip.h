@@ -193,7 +193,8 @@ AWQ_EXPORT int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweigh
 #define AWQ_GEMV_KERNEL_BATCH 5u  /* round 5: ANY M in one call (launches of <= 32 rows), group_size 128, K % 128 == 0: activations as MFMA A
                                      fragments in registers, a tile's K range split over the eight waves of ONE block (no exchange, no
                                      workspace), weights by LDS-DMA in row-contiguous pieces (gemv_batch.hip).  AUTO takes it from M = 5.
-                                     _UNIT: 128-k groups per wave and pass (4 | 8), _SPLITK: pieces in flight per wave (1 .. 3) */
+                                     _UNIT: how the activations reach the registers (1 = coalesced LDS-DMA into a wave-private staging
+                                     area, 2 = direct 16-byte fragment loads; 0 = auto: staged when it fits), _SPLITK: pieces in flight (1 .. 3) */
 #define AWQ_GEMV_KERNEL_PREFILL 4u /* any M in ONE call: the register-decoded MFMA GEMM on this layout's own buffers (gemm_regb.hip, NK
                                      form; K % 64 == 0, group_size % 64 == 0, N % 4 == 0); _NLOG = 2: 256-row tiles.  EXPLICIT only:
                                      measured 0.29 of the MFMA peak at M = 16384 (dequantise + dense GEMM: 0.42) and latency-bound
@@ -382,11 +383,14 @@ AWQ_EXPORT int awq_decode_attention_rope(const uint16_t* qkv, uint16_t* k_cache,
 /* ---- one-shot small-message all-reduce for tensor-parallel decode (no reference counterpart: SURVEY.md 2.3 / 8e) ------
  * out[i] = sum over ranks of in_r[i], fp16 with fp32 accumulation in rank order (bitwise identical on every rank), for the
  * [M, hidden] outputs of row-parallel projections (n_halfs % 4 == 0, n_halfs <= max_halfs; <= 64 KiB is what it is built for).
- * One launch per rank, no host involvement, hipGraph-replayable; see csrc/allreduce.hip for the protocol.
- * Setup (once): every rank allocates awq_allreduce_staging_bytes(max_halfs) of staging and awq_allreduce_flag_bytes() of
- * flags -- both ZEROED, both mapped by every peer (hipIpc / P2P), both FINE-GRAINED / UNCACHED device memory when the peers are
- * other GPUs (awq_allreduce_alloc below: a kernel that spins on a flag a peer GPU writes is only guaranteed to see the store
- * in such memory) -- and awq_allreduce_state_bytes() of private, zeroed state (any device memory).
+ * One launch per rank, no host involvement, hipGraph-replayable.  Protocol (csrc/allreduce.hip; round 5): a PUSH -- every rank
+ * stores its slice as 8-byte {two fp16 values, epoch tag} granules straight into every peer's staging (one xGMI store hop, no
+ * flag, no fence), then sums what arrived in its OWN staging on tag match; no remote read.  peer_flags is unused since round 5
+ * (the argument stays in the ABI).
+ * Setup (once): every rank allocates awq_allreduce_staging_bytes(max_halfs) of staging (2 parities x AWQ_AR_MAX_RANKS sources x
+ * max_halfs / 2 granules) and awq_allreduce_flag_bytes() of flags -- both ZEROED, both mapped by every peer (hipIpc / P2P), both
+ * FINE-GRAINED / UNCACHED device memory when the peers are other GPUs (awq_allreduce_alloc below: a kernel that polls memory a
+ * peer GPU writes is only guaranteed to see the store in such memory) -- and awq_allreduce_state_bytes() of private, zeroed state.
  * peer_staging[r] / peer_flags[r] are THIS process's addresses of rank r's buffers (entry `rank` = its own); every rank must
  * pass the same max_halfs and issue the same sequence of calls.  A peer that never arrives raises a sticky error word
  * (state[1] != 0) after a bounded spin instead of hanging the GPU, and the slices that gave up are written as NaN: a late

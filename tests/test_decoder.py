@@ -337,7 +337,7 @@ def test_prefill_attention_vs_oracle(ops, B, S, Hq, Hkv, start, softcap, alibi):
     out = ops.prefill_attention(qd, kd, vd, start, softcap=softcap, alibi_slopes=slopes.cuda() if alibi else None)
     assert out.shape == q.shape and bool(torch.isfinite(out).all())
     assert torch.equal(out, ops.prefill_attention(qd, kd, vd, start, softcap=softcap, alibi_slopes=slopes.cuda() if alibi else None))
-    rows = sorted(set([0, 1, S - 1, S // 2] + [r for r in (31, 32, 63, 64, 127, 128, 129, 255, 256, 1023, 1024, 2047) if r < S]))
+    rows = sorted(set(r for r in (0, 1, S - 1, S // 2, 31, 32, 63, 64, 127, 128, 129, 255, 256, 1023, 1024, 2047) if r < S))
     ref = decoder_oracle.prefill_attention_reference(q.numpy(), kc.numpy()[:B], vc.numpy()[:B], start, rows, softcap=softcap,
                                                      alibi_slopes=slopes.numpy() if alibi else None)
     got = out.cpu().numpy().astype(np.float64)[:, rows]

@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
 """CPU model of csrc/gemv_batch.hip's index algebra (no GPU): the DMA lane -> (row, chunk) map with its global-side XOR
-swizzle, the LDS image of a piece, the fragment reads, the nibble decode order against the pair-permuted activations, the
+swizzle, the LDS image of a piece, the staging area of the activations with ITS swizzle, the fragment reads, the nibble decode order against the pair-permuted activations, the
 MFMA operand / accumulator layouts (those of csrc/gemv_lds.hip, which the GPU suite pins), the K split over the waves of a
 block with passes, the partial-tile reduction and the final store map.  It follows the kernel's expressions line by line and
 compares the result with x @ dequant(W)^T; tests/test_gemv_batch_model.py runs it on ragged shapes."""
 import numpy as np
 
 
-def plan(M, K, N, gw_req=0, rd_req=0, blocks_cap=256):
-    """plan_batch() of csrc/gemv_batch.hip"""
+def xs_f(m):
+    return ((m & 3) << 2) | ((m >> 2) & 3)
+
+
+def plan(M, K, N, form=0, rd_req=0, blocks_cap=256):
+    """plan_batch() of csrc/gemv_batch.hip (form: 0 auto, 1 the activations through the LDS staging area, 2 direct fragment loads)"""
     MI = 2 if M > 16 else 1
     G = K // 128
-    GW = gw_req if gw_req in (4, 8) else (8 if (MI == 1 and G >= 64) else 4)
-    if MI * GW > 8:
-        GW = 4
+    GW = 4
     wk = 1
     while wk < 8 and wk * GW < G:
         wk *= 2
@@ -24,25 +26,32 @@ def plan(M, K, N, gw_req=0, rd_req=0, blocks_cap=256):
     blocks = min(want, blocks_cap)  # (the launcher: 256 = one block per CU; the model lowers it to reach several tiles per owner)
     owners = blocks * wt
     tb, tr = tiles // owners, tiles % owners
-    return dict(MI=MI, GW=GW, wk=wk, wt=wt, passes=passes, blocks=blocks, tiles_base=tb, tiles_rem=tr, tiles_max=tb + (1 if tr else 0),
-                RD=rd_req or 2, G=G)
+    tiles_max = tb + (1 if tr else 0)
+    ystage = wt * tiles_max * MI * 1024
+    plain = 2 * MI * 1024 if wk > 1 else 0
+    staged = max(M * 1024, plain)
+    piece_b = 16 * GW * 64 + 1024 + 256
+    xs = form != 2 and ystage + 8 * staged + 8 * piece_b <= 160 * 1024
+    if form == 1 and not xs:
+        return None
+    return dict(MI=MI, GW=GW, wk=wk, wt=wt, passes=passes, blocks=blocks, tiles_base=tb, tiles_rem=tr, tiles_max=tiles_max,
+                RD=rd_req or 2, G=G, XS=xs)
 
 
-def decode_word(ww, z, s):
-    """B fragment of one packed word: 8 halfs in the register order (n0, n4, n1, n5, n2, n6, n3, n7), (w - z) * s in fp16"""
+def decode_word(ww, z):
+    """B fragment of one packed word: 8 halfs in the register order (n0, n4, n1, n5, n2, n6, n3, n7), the exact integers w - z"""
     nib = [(ww >> (4 * i)) & 15 for i in range(8)]
     order = [0, 4, 1, 5, 2, 6, 3, 7]
-    d = np.array([nib[i] - z for i in order], dtype=np.float16)  # exact
-    return (d * np.float16(s)).astype(np.float16)
+    return np.array([nib[i] - z for i in order], dtype=np.float16)
 
 
-def run(x, qweight, qzeros, scales, gw_req=0, rd_req=0, blocks_cap=None):
+def run(x, qweight, qzeros, scales, form=0, rd_req=0, blocks_cap=None):
     M, K = x.shape
     N, KW = qweight.shape
     ZW = qzeros.shape[1]
     SW = scales.shape[1]
-    p = plan(M, K, N, gw_req, rd_req, blocks_cap or 256)
-    MI, GW, wk, wt, RD, G = p["MI"], p["GW"], p["wk"], p["wt"], p["RD"], p["G"]
+    p = plan(M, K, N, form, rd_req, blocks_cap or 256)
+    MI, GW, wk, wt, RD, G, XS = p["MI"], p["GW"], p["wk"], p["wt"], p["RD"], p["G"], p["XS"]
     PIECE_W = 16 * GW * 64
     PIECE_B = PIECE_W + 1024 + 256
     CPR, RPI = 4 * GW, 64 // (4 * GW)
@@ -98,14 +107,27 @@ def run(x, qweight, qzeros, scales, gw_req=0, rd_req=0, blocks_cap=None):
             wki = info[wave][0]
             g0 = (ps * wk + wki) * GW
             out = np.zeros((MI, GW, 4, 64, 8), dtype=np.float16)
+            stage = None
+            if XS:  # one 1-KiB DMA per batch row: lane l of row m fetches chunk (l & 48) | ((l & 15) ^ f(m)) into chunk slot l
+                xb = xh.view(np.uint8).reshape(M, K * 2)
+                stage = np.zeros((M, 1024), dtype=np.uint8)
+                for m in range(M):
+                    for lane in range(64):
+                        j = (lane & 48) | ((lane & 15) ^ xs_f(m))
+                        byte = min(256 * g0 + 16 * j, K * 2 - 16)
+                        stage[m, 16 * lane:16 * lane + 16] = xb[m, byte:byte + 16]
             for mi in range(MI):
                 for u in range(GW):
                     for c in range(4):
                         for lane in range(64):
                             n, kq = lane & 15, lane >> 4
                             m = min(16 * mi + n, M - 1)
-                            kk = min(128 * (g0 + u) + 32 * kq + 8 * c, K - 8)
-                            d = xh[m, kk:kk + 8]
+                            if XS:
+                                pos = 16 * u + ((4 * kq + c) ^ xs_f(m))
+                                d = stage[m, 16 * pos:16 * pos + 16].view(np.float16)
+                            else:
+                                kk = min(128 * (g0 + u) + 32 * kq + 8 * c, K - 8)
+                                d = xh[m, kk:kk + 8]
                             valid = (16 * mi + n < M) and (g0 + u < G)
                             if valid:
                                 out[mi, u, c, lane] = d[[0, 4, 1, 5, 2, 6, 3, 7]]
@@ -130,28 +152,30 @@ def run(x, qweight, qzeros, scales, gw_req=0, rd_req=0, blocks_cap=None):
                     acc = np.zeros((MI, 16, 16), dtype=np.float32)  # D[m][n]
                     for uu in range(GW):
                         bfr = np.zeros((4, 64, 8), dtype=np.float16)
+                        sc_lane = np.zeros(64, dtype=np.float32)
                         for lane in range(64):
                             n, kq = lane & 15, lane >> 4
                             zw = int(np.frombuffer(bytes(slot[PIECE_W + 1024 + 4 * lane:PIECE_W + 1024 + 4 * lane + 4]), dtype=np.uint32)[0])
                             sq = np.frombuffer(bytes(slot[PIECE_W + 16 * lane:PIECE_W + 16 * lane + 16]), dtype=np.float16)
                             q = 4 * uu + kq
-                            pos = (q & 16) | ((q ^ n) & 15)
-                            off = n * (CPR * 16) + pos * 16
+                            off = n * 256 + (((q ^ n) & 15) * 16)
                             wq = np.frombuffer(bytes(slot[off:off + 16]), dtype=np.uint32)
                             gi = (g0 & 7) + uu
                             z = (zw >> (4 * gi)) & 15
-                            if GW == 8:
-                                s = sq[uu]
-                            else:
-                                s = sq[(4 if (g0 & 4) else 0) + uu]
+                            sc_lane[lane] = np.float32(sq[(4 if (g0 & 4) else 0) + uu])
                             for c in range(4):
-                                bfr[c, lane] = decode_word(int(wq[c]), z, s)
+                                bfr[c, lane] = decode_word(int(wq[c]), z)
+                        gacc = np.zeros((MI, 16, 16), dtype=np.float32)
                         for c in range(4):
                             # v_mfma_f32_16x16x32_f16: D[i][j] += sum_{kq, e} A[lane (i, kq)][e] * B[lane (j, kq)][e]
                             Bm = bfr[c].astype(np.float32).reshape(4, 16, 8)  # [kq][j][e]
                             for mi in range(MI):
                                 Am = A[wave][mi, uu, c].astype(np.float32).reshape(4, 16, 8)  # [kq][i][e]
-                                acc[mi] += np.einsum("kie,kje->ij", Am, Bm)
+                                gacc[mi] += np.einsum("kie,kje->ij", Am, Bm)
+                        # lane (n, kq) scales ITS accumulator elements D[4 kq + r][n] with the scale of row n (the same in all four kq)
+                        sc_n = sc_lane[:16]
+                        assert all(np.array_equal(sc_lane[16 * k:16 * k + 16], sc_n) for k in range(4))
+                        acc += gacc * sc_n[None, None, :]
                     request(wave, u + RD)
                     units[wave] = u + 1
                     pbuf[wave] = acc
@@ -209,16 +233,16 @@ def random_case(M, K, N, seed=0):
 if __name__ == "__main__":
     import sys
 
-    cases = [(5, 512, 40, 0, 0), (8, 1024, 72, 0, 0), (16, 1280, 33, 4, 0), (20, 768, 48, 0, 0), (32, 1152, 100, 0, 0), (7, 2432, 24, 8, 0),
-             (9, 4224, 20, 4, 0), (6, 1024, 200, 0, 1), (17, 4224, 88, 0, 2), (12, 8320, 56, 8, 1)]
+    cases = [(5, 512, 40, 0, 0), (8, 1024, 72, 1, 0), (16, 1280, 33, 2, 0), (20, 768, 48, 0, 0), (32, 1152, 100, 0, 0), (7, 2432, 24, 2, 0),
+             (9, 4224, 20, 1, 0), (6, 1024, 200, 0, 1), (17, 4224, 88, 0, 2), (12, 8320, 56, 1, 1)]
     bad = 0
     for M, K, N, gw, cap in cases:
         x, qw, qz, sc = random_case(M, K, N, seed=M + K + N)
-        y = run(x, qw, qz, sc, gw_req=gw, blocks_cap=cap).astype(np.float32)
+        y = run(x, qw, qz, sc, form=gw, blocks_cap=cap).astype(np.float32)
         ref = reference(x, qw, qz, sc)
         err = np.abs(y - ref).max()
         tol = 2e-3 * np.abs(ref).max() + 1e-3
         ok = err <= tol
         bad += not ok
-        print(f"M={M} K={K} N={N} gw={gw} plan={plan(M, K, N, gw, 0, cap or 256)} max err {err:.4g} (max |ref| {np.abs(ref).max():.3g}) {'ok' if ok else 'MISMATCH'}")
+        print(f"M={M} K={K} N={N} form={gw} plan={plan(M, K, N, gw, 0, cap or 256)} max err {err:.4g} (max |ref| {np.abs(ref).max():.3g}) {'ok' if ok else 'MISMATCH'}")
     sys.exit(1 if bad else 0)

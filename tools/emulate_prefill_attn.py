@@ -1,11 +1,11 @@
-"""CPU desk-check of prefill_attn.hip's index algebra (runs here, no GPU): a numpy model of ONE block that follows the kernel's
+"""CPU desk-check of csrc/prefill_attn.hip's index algebra (runs here, no GPU): a numpy model of ONE block that follows the kernel's
 expressions line by line -- the thread -> (row, chunk) staging maps, both LDS swizzles, the v_perm transposition of V, the
 fragment addresses, the k-slot order shared by P and V^T, the lane -> (query, d) ownership of the accumulators, the output
 addresses -- on top of the v_mfma_f32_16x16x32_f16 operand layout the GEMM kernels of csrc/ are built on (and validated on
 the GPU with): A lane (j, kb) = row j, k 8 kb + i; B lane (j, kb) = column j, k 8 kb + i; C lane (j, kb), e = row 4 kb + e,
 column j.  What it cannot check: instruction semantics, hazards, timing.
 
-    python tools/experimental/prefill_attention/emulate.py          # exit status 0 = every case within tolerance"""
+    python tools/emulate_prefill_attn.py          # exit status 0 = every case within tolerance"""
 import sys
 
 import numpy as np

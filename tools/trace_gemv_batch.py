@@ -56,8 +56,8 @@ def child(name):
     gen = torch.Generator(device=dev).manual_seed(3)
     st = torch.cuda.Stream(device=dev)
     BATCH = 5
-    cases = [(4096, 11008, 8, 4, 1), (4096, 11008, 8, 4, 3), (4096, 11008, 16, 4, 1), (4096, 11008, 32, 4, 1), (4096, 11008, 8, 8, 1)]
-    for K, N, M, gw, rd in cases:
+    cases = [(4096, 11008, 8, 1, 1), (4096, 11008, 8, 1, 2), (4096, 11008, 8, 2, 1), (4096, 11008, 12, 1, 1), (4096, 11008, 16, 2, 1), (4096, 11008, 32, 2, 1)]
+    for K, N, M, gw, rd in cases:  # gw: the activations' form (1 = LDS staging area, 2 = direct fragment loads)
         nsets = 28
         mats = [bench.rand_packed_nk(K, N, 128, dev, gen) for _ in range(nsets)]
         x = torch.randn((M, K), device=dev, generator=gen).half()
@@ -68,7 +68,7 @@ def child(name):
                 ops.gemv_forward(x, qw, sc, qz, 128, flags=fl)
 
         us = bench.graph_time(f, st, reps=10, min_seconds=0.1) / len(mats)
-        print(f"[{name}] K={K} N={N} M={M} gw={gw} rd={rd}: {us:.2f} us", flush=True)
+        print(f"[{name}] K={K} N={N} M={M} form={'xs' if gw == 1 else 'direct'} rd={rd}: {us:.2f} us", flush=True)
         if name == "trace":
             L.awq_debug_set_trace_batch.argtypes = [ctypes.c_void_p]
             trace = torch.zeros(256 * 8 * 12, dtype=torch.int64, device=dev)
@@ -88,7 +88,7 @@ def child(name):
             def q(a):
                 a = a[~np.isnan(a)]
                 return " ".join(f"{v:6.2f}" for v in np.percentile(a, [0, 10, 50, 90, 100])) + f"   n={a.size}" if a.size else "(none)"
-            names = ["wave start", "A + ring requested", "A landed", "A permuted", "piece 0 landed", "piece 0 consumed + next requested",
+            names = ["wave start", "A + ring requested", "-", "A in registers", "piece 0 landed", "piece 0 consumed + next requested",
                      "piece 1 landed", "piece 1 consumed", "piece 2 landed", "piece 2 consumed", "stream done", "end (y stored)"]
             print(f"   {t.shape[0]} waves, absolute us since the first wave started (p0 p10 p50 p90 p100):")
             for i, nm in enumerate(names):
