@@ -27,7 +27,9 @@
 //    path walks 32 cache lines per instruction): XS form -- each batch row's 1 KiB of the wave's K range arrives by ONE coalesced
 //    LDS-DMA instruction into a wave-private staging area (swizzled on the global side), then 16 MI ds_read_b128 put the fragments
 //    into registers; no barrier (the wave reads only what it requested itself).  The staging area is dead afterwards and holds the
-//    partial-tile buffers.  When M KiB x 8 waves do not fit beside the ring (M > 12 or so) the direct form stays.
+//    partial-tile buffers.  The area holds eight rows per wave (64 KB per block beside a two-deep ring); more rows arrive in CHUNKS of
+//    eight, each requested once the previous one has been read (lanes of the other half keep what they hold).  The direct form stays
+//    selectable (flag) for A/B runs.
 //  * Decode: nibbles stay in place under the exponents 2^10 / 2^6 (five VALU per word), four packed subtracts of (bias + z): the
 //    EXACT integers w - z in fp16; products and the fp32 accumulation in v_mfma_f32_16x16x32_f16 are exact per term; the group's
 //    scale multiplies the group's fp32 sum (4 MI fused multiply-adds per group instead of four packed multiplies per word: the first
@@ -64,6 +66,7 @@ struct BatchParams {
     int passes;      // ceil(G / (wk * GW))
     int tiles_base, tiles_rem, tiles_max;  // tiles per owner: base (+1 for the first rem owners)
     int ring_off, pbuf_off, pbuf_pitch, ystage_off;  // LDS byte offsets; pbuf_pitch: bytes per wave (XS: the wave's staging area)
+    int xs_rows;     // XS: batch rows the staging area holds at a time (min(M, 8): more rows arrive in chunks of eight)
     unsigned long long* trace;             // debug builds only (tools/trace_gemv_batch.py)
 };
 
@@ -94,6 +97,20 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
                    "+v"(X[o + 13]), "+v"(X[o + 14]), "+v"(X[o + 15])                                                               \
                  : "n"(cnt))
 
+// ds_read_b128 into the lanes of `mask` only (the other lanes keep what the register holds): the second half-chunk of the staged
+// activations merges into the fragment registers without a temporary (a select needs both copies live: register spills at MI 2).
+// The reads are invisible to hipcc's lgkmcnt bookkeeping: AWQ_BT_LGKM16 waits and names the registers.
+#define AWQ_BT_LDS_READ16_MASKED(dst, addr, OFF, mask, save)                                                                        \
+    asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %3\n\tds_read_b128 %0, %2 offset:" #OFF "\n\ts_mov_b64 exec, %1"      \
+                 : "+v"(dst), "=&s"(save)                                                                                           \
+                 : "v"(addr), "s"(mask)                                                                                             \
+                 : "scc")  /* s_and_b64 writes SCC: undeclared, a compare hipcc had made BEFORE the statement decided a branch after it */
+#define AWQ_BT_LGKM16(X, o)                                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                             \
+                 : "+v"(X[o + 0]), "+v"(X[o + 1]), "+v"(X[o + 2]), "+v"(X[o + 3]), "+v"(X[o + 4]), "+v"(X[o + 5]), "+v"(X[o + 6]),  \
+                   "+v"(X[o + 7]), "+v"(X[o + 8]), "+v"(X[o + 9]), "+v"(X[o + 10]), "+v"(X[o + 11]), "+v"(X[o + 12]),               \
+                   "+v"(X[o + 13]), "+v"(X[o + 14]), "+v"(X[o + 15]))
+
 AWQ_DEV float4_t mfma16(u32x4 a, u32x4 b, float4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
 }
@@ -103,11 +120,16 @@ AWQ_DEV float4_t mfma16(u32x4 a, u32x4 b, float4_t c) {
 // (rows {0-3, 12-15} of one kq with rows {4-11} of the next) then hit sixteen different 16-byte columns
 AWQ_DEV int xs_f(int m) { return ((m & 3) << 2) | ((m >> 2) & 3); }
 
-// MI: 16-row batch tiles (1 | 2); RD: pieces in flight per wave; XS: the activations reach the registers through a wave-private
-// LDS staging area (coalesced LDS-DMA) instead of 16-byte fragment loads
+// MI: 16-row batch tiles (1 | 2); RD: ring slots per wave -- 1 | 3: that many pieces in flight, re-requested after a piece has been
+// consumed; 2 (LAZY, the default): the NEXT piece is requested the moment a piece has landed, i.e. its flight overlaps the consumption
+// of the current one while no wave ever holds more than one request in the memory system's queues (measured: with two or three
+// pieces per wave requested up front every request takes 2.5 us instead of 1.2 -- the queues, not the latency, set the pace -- and the
+// waves start later: profiles/r05_gemv_batch_trace_v3.txt); XS: the activations reach the registers through a wave-private LDS
+// staging area (coalesced LDS-DMA) instead of 16-byte fragment loads
 template <int MI, int RD, bool XS>
 __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     constexpr int NA = MI * GW * 4;  // A fragments (16 bytes each) per lane
+    constexpr bool LAZY = RD == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,49 +176,10 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
         }
     };
 
-    // ---- activations of pass ps -> A fragments in registers (pair-permuted), zero for batch rows >= M and groups >= G
+    // ---- activations of pass ps -> A fragments in registers (pair-permuted), zero for batch rows >= M and groups >= G.
+    //      `first_piece`: the ring's first request goes out right behind the first chunk of activations (pass 0 only).
     u32x4 afr[NA];
-    auto request_a = [&](int ps) {
-        const int g0 = (ps * p.wk + wki) * GW;
-        if constexpr (XS) {  // one coalesced 1-KiB instruction per batch row (the wave's 512 k of it), swizzled on the global side
-            for (int m = 0; m < M; ++m) {
-                const int j = (lane & 48) | ((lane & 15) ^ xs_f(m));
-                const int byte = min(256 * g0 + 16 * j, p.K * 2 - 16);
-                AWQ_BT_DMA16((uint32_t)(m * p.K * 2 + byte), p.x, lds0 + (uint32_t)(xs_w + m * 1024));
-            }
-        } else {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int u = 0; u < GW; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {  // (lanes of batch rows >= M repeat row M - 1's addresses: no more lines per instruction)
-                        const int m = min(16 * mi + n, M - 1);
-                        const int kk = min(128 * (g0 + u) + 32 * kq + 8 * c, p.K - 8);
-                        AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (AWQ_BT_DBG & 1) ? 0u : (uint32_t)((m * p.K + kk) * 2), p.x);
-                    }
-        }
-    };
-    auto collect_a = [&](int ps, auto cnt_c) __attribute__((always_inline)) {  // wait (cnt newer requests may be pending), then fragments
-        constexpr int CNT = decltype(cnt_c)::value;
-        const int g0 = (ps * p.wk + wki) * GW;
-        if constexpr (XS) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int m = min(16 * mi + n, M - 1);
-                const unsigned char* row = smem + xs_w + m * 1024;
-                const int f = xs_f(m);
-#pragma unroll
-                for (int u = 0; u < GW; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) afr[(mi * GW + u) * 4 + c] = *reinterpret_cast<const u32x4*>(row + 16 * (16 * u + ((4 * kq + c) ^ f)));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area is dead from here (it becomes the partial-tile buffers)
-        } else {
-            AWQ_BT_WAIT16(afr, 0, CNT);
-            if constexpr (NA > 16) AWQ_BT_WAIT16(afr, 16, CNT);
-        }
+    auto permute_a = [&](int g0) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -215,13 +198,94 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 }
             }
     };
-
-    request_a(0);
+    auto load_a = [&](int ps, auto first_piece_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_piece_c)::value;  // pass 0: nothing older is in flight, the ring starts here
+        const int g0 = (ps * p.wk + wki) * GW;
+        if constexpr (XS) {
+            // chunks of eight batch rows through the staging area (rows 16 mi + 8 half ..): one coalesced 1-KiB instruction per row (the
+            // wave's 512 k of it), swizzled on the global side; a chunk is requested once the previous one has been read
 #pragma unroll
-    for (int d = 0; d < RD; ++d) request(d);
-    BT_STAMP(1);
-    collect_a(0, std::integral_constant<int, LDM * RD>{});  // everything older than the ring requests: the activations
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    // (straight-line on purpose: a wave-uniform skip of an absent chunk made hipcc keep two copies of the fragment registers;
+                    //  an absent chunk requests nothing, reads stale bytes and merges nothing)
+                    const int r0 = 16 * mi + 8 * half;
+                    const int r1 = max(min(r0 + 8, M), r0 + 1);
+                    const bool present = r0 < M;
+                    for (int m = r0; m < r1 && present; ++m) {
+                        const int j = (lane & 48) | ((lane & 15) ^ xs_f(m));
+                        const int byte = min(256 * g0 + 16 * j, p.K * 2 - 16);
+                        AWQ_BT_DMA16((uint32_t)(m * p.K * 2 + byte), p.x, lds0 + (uint32_t)(xs_w + (m - r0) * 1024));
+                    }
+                    if (FIRST && mi == 0 && half == 0) {
+                        request(0);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM) : "memory");  // the chunk is older than the piece
+                    } else if (present) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    const int m = min(max(16 * mi + n, r0), r1 - 1);  // (lanes of the other half / of rows >= M read some row of the chunk)
+                    const int f = xs_f(m);
+                    {
+                        if (half == 0) {  // every lane takes what it reads (lanes 8-15: overwritten by the second half, or zeroed below)
+                            const unsigned char* row = smem + xs_w + (m - r0) * 1024;
+#pragma unroll
+                            for (int u = 0; u < GW; ++u)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    afr[(mi * GW + u) * 4 + c] = *reinterpret_cast<const u32x4*>(row + 16 * (16 * u + ((4 * kq + c) ^ f)));
+                        } else {  // lanes 8-15 of every 16 only (none if the chunk is absent)
+                            const unsigned long long mask = present ? 0xFF00FF00FF00FF00ull : 0ull;
+                            unsigned long long save;  // (an SGPR pair each statement uses as scratch)
+                            const uint32_t rb = lds0 + (uint32_t)(xs_w + (m - r0) * 1024);
+                            uint32_t ad[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) ad[c] = rb + 16u * (uint32_t)((4 * kq + c) ^ f);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 0) * 4 + c], ad[c], 0, mask, save);
+                                AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 1) * 4 + c], ad[c], 256, mask, save);
+                                AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 2) * 4 + c], ad[c], 512, mask, save);
+                                AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 3) * 4 + c], ad[c], 768, mask, save);
+                            }
+                            AWQ_BT_LGKM16(afr, mi * 16);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk has been read: the next one may land on it
+                }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int u = 0; u < GW; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {  // (lanes of batch rows >= M repeat row M - 1's addresses: no more lines per instruction)
+                        const int m = min(16 * mi + n, M - 1);
+                        const int kk = min(128 * (g0 + u) + 32 * kq + 8 * c, p.K - 8);
+                        AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (AWQ_BT_DBG & 1) ? 0u : (uint32_t)((m * p.K + kk) * 2), p.x);
+                    }
+            if constexpr (FIRST) {
+                request(0);
+                AWQ_BT_WAIT16(afr, 0, LDM);
+                if constexpr (NA > 16) AWQ_BT_WAIT16(afr, 16, LDM);
+            } else {
+                AWQ_BT_WAIT16(afr, 0, 0);
+                if constexpr (NA > 16) AWQ_BT_WAIT16(afr, 16, 0);
+            }
+        }
+        permute_a(g0);
+    };
+
+    // the activations, the ring's first piece right behind them; the other RD - 1 pieces once the fragments are in registers
+    // (their requests then issue in the shadow of the first piece's flight: profiles/r05_gemv_batch_trace_v2.txt -- issued up
+    // front they delayed every wave's start by ~1 us at RD 2)
+    load_a(0, std::true_type{});
     BT_STAMP(3);
+    if constexpr (!LAZY) {
+#pragma unroll
+        for (int d = 1; d < RD; ++d) request(d);
+    }
+    BT_STAMP(1);
 
     // ---- stream
     float4_t* ystage = reinterpret_cast<float4_t*>(smem + p.ystage_off);  // [wt][tiles_max][MI][64 lanes]
@@ -232,8 +296,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             if constexpr (XS) {
                 if (p.wk > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // nobody still reads the partial tiles the staging overwrites
             }
-            request_a(ps);
-            collect_a(ps, std::integral_constant<int, 0>{});
+            load_a(ps, std::false_type{});
         }
         const int g0 = (ps * p.wk + wki) * GW;
         for (int tl = 0; tl < p.tiles_max; ++tl, ++it) {
@@ -242,7 +305,12 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi] = float4_t{0.f, 0.f, 0.f, 0.f};
             if (live) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM * (RD - 1)) : "memory");
+                if constexpr (LAZY) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only this piece was in flight
+                    request(u + 1);  // (its slot was read out before the previous iteration ended)
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM * (RD - 1)) : "memory");
+                }
 #ifdef AWQ_GEMV_TRACE
                 if (u < 3) ts[4 + 2 * u] = wall_clock64();
 #endif
@@ -285,7 +353,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                         for (int r = 0; r < 4; ++r) acc[mi][r] = __builtin_fmaf(sc, gacc[mi][r], acc[mi][r]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the slot has returned before it is overwritten
-                request(u + RD);
+                if constexpr (!LAZY) request(u + RD);
 #ifdef AWQ_GEMV_TRACE
                 if (u < 3) ts[5 + 2 * u] = wall_clock64();
 #endif
@@ -345,7 +413,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 }
 
 struct BatchPlan {
-    int MI, RD, XS, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max;
+    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max;
     size_t ring, pbuf_pitch, ystage;
 };
 
@@ -369,12 +437,16 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     b.tiles_rem = tiles % owners;
     b.tiles_max = b.tiles_base + (b.tiles_rem ? 1 : 0);
     b.ystage = (size_t)b.wt * b.tiles_max * b.MI * 1024;
-    const size_t plain = wk > 1 ? (size_t)2 * b.MI * 1024 : 0, staged = (size_t)M * 1024 > plain ? (size_t)M * 1024 : plain;
+    const size_t plain = wk > 1 ? (size_t)2 * b.MI * 1024 : 0;
     const size_t budget = 160 * 1024;
-    // XS when the staging area (M KiB per wave, the partial-tile buffers live in it afterwards) fits beside at least one ring slot per wave
+    // XS: the staging area holds min(M, 8) batch rows per wave (more rows arrive in chunks of eight); the partial-tile buffers live
+    // in it afterwards
+    const int rows = M < 8 ? M : 8;
+    const size_t staged = (size_t)rows * 1024 > plain ? (size_t)rows * 1024 : plain;
     const bool xs = form != 2 && b.ystage + 8 * staged + (size_t)8 * PIECE_B <= budget;
     if (form == 1 && !xs) return false;
     b.XS = xs ? 1 : 0;
+    b.xs_rows = rows;
     b.pbuf_pitch = xs ? staged : plain;
     const size_t fixed = b.ystage + 8 * b.pbuf_pitch;
     int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : 2;
@@ -421,6 +493,7 @@ int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint1
     p.ring_off = 0;
     p.pbuf_off = (int)b.ring;
     p.pbuf_pitch = (int)b.pbuf_pitch;
+    p.xs_rows = b.xs_rows;
     p.ystage_off = (int)(b.ring + 8 * b.pbuf_pitch);
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_batch_trace;

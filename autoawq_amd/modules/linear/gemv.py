@@ -33,9 +33,10 @@ def dequant_matmul_nk(x2d, wt):
 
 
 # Up to this many rows the call runs the decode / batched-decode kernels on the layout's own buffers (round 5: csrc/gemv_batch.hip takes any
-# M in launches of <= 32 rows, each streaming the matrix once; the reference switches to its batched kernel at 8 rows: gemv.py:168).
+# M in launches of <= 32 rows, each streaming the matrix once -- three launches still beat the repack route at 4096 x 11008: 37 vs 50 us,
+# profiles/r05_prefill_routes.txt, r05_gemv_batch_sweep_final.txt; the reference switches to its batched kernel at 8 rows: gemv.py:168).
 # Above it: PREFILL_IMPL.
-PREFILL_MIN_ROWS = 129
+PREFILL_MIN_ROWS = 97
 
 
 class WQLinear_GEMV(nn.Module):

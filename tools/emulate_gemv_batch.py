@@ -29,7 +29,7 @@ def plan(M, K, N, form=0, rd_req=0, blocks_cap=256):
     tiles_max = tb + (1 if tr else 0)
     ystage = wt * tiles_max * MI * 1024
     plain = 2 * MI * 1024 if wk > 1 else 0
-    staged = max(M * 1024, plain)
+    staged = max(min(M, 8) * 1024, plain)
     piece_b = 16 * GW * 64 + 1024 + 256
     xs = form != 2 and ystage + 8 * staged + 8 * piece_b <= 160 * 1024
     if form == 1 and not xs:
@@ -107,15 +107,32 @@ def run(x, qweight, qzeros, scales, form=0, rd_req=0, blocks_cap=None):
             wki = info[wave][0]
             g0 = (ps * wk + wki) * GW
             out = np.zeros((MI, GW, 4, 64, 8), dtype=np.float16)
-            stage = None
-            if XS:  # one 1-KiB DMA per batch row: lane l of row m fetches chunk (l & 48) | ((l & 15) ^ f(m)) into chunk slot l
+            if XS:
+                # chunks of eight batch rows (rows 16 mi + 8 half ..) through an 8-row staging area: lane l of local row m - r0 fetches
+                # chunk (l & 48) | ((l & 15) ^ f(m)) into chunk slot l; half 0: every lane takes what it reads, half 1: lanes 8-15 only
                 xb = xh.view(np.uint8).reshape(M, K * 2)
-                stage = np.zeros((M, 1024), dtype=np.uint8)
-                for m in range(M):
-                    for lane in range(64):
-                        j = (lane & 48) | ((lane & 15) ^ xs_f(m))
-                        byte = min(256 * g0 + 16 * j, K * 2 - 16)
-                        stage[m, 16 * lane:16 * lane + 16] = xb[m, byte:byte + 16]
+                raw = np.zeros((MI, GW, 4, 64, 8), dtype=np.float16)
+                for mi in range(MI):
+                    for half in range(2):
+                        r0 = 16 * mi + 8 * half
+                        if r0 >= M:
+                            continue
+                        r1 = min(r0 + 8, M)
+                        stage = np.zeros((8, 1024), dtype=np.uint8)
+                        for m in range(r0, r1):
+                            for lane in range(64):
+                                j = (lane & 48) | ((lane & 15) ^ xs_f(m))
+                                byte = min(256 * g0 + 16 * j, K * 2 - 16)
+                                stage[m - r0, 16 * lane:16 * lane + 16] = xb[m, byte:byte + 16]
+                        for lane in range(64):
+                            n, kq = lane & 15, lane >> 4
+                            if half == 1 and n < 8:
+                                continue
+                            m = min(max(16 * mi + n, r0), r1 - 1)
+                            for u in range(GW):
+                                for c in range(4):
+                                    pos = 16 * u + ((4 * kq + c) ^ xs_f(m))
+                                    raw[mi, u, c, lane] = stage[m - r0, 16 * pos:16 * pos + 16].view(np.float16)
             for mi in range(MI):
                 for u in range(GW):
                     for c in range(4):
@@ -123,8 +140,7 @@ def run(x, qweight, qzeros, scales, form=0, rd_req=0, blocks_cap=None):
                             n, kq = lane & 15, lane >> 4
                             m = min(16 * mi + n, M - 1)
                             if XS:
-                                pos = 16 * u + ((4 * kq + c) ^ xs_f(m))
-                                d = stage[m, 16 * pos:16 * pos + 16].view(np.float16)
+                                d = raw[mi, u, c, lane]
                             else:
                                 kk = min(128 * (g0 + u) + 32 * kq + 8 * c, K - 8)
                                 d = xh[m, kk:kk + 8]
