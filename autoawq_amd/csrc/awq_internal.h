@@ -111,6 +111,10 @@ int awq_launch_gemv_lds(const uint16_t* x, const int32_t* qweight, const uint16_
 bool awq_gemv_batch_supports(int M, int K, int N, int g);
 int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
                           int M, int K, int N, int g, int ZW, int form, int depth, hipStream_t st);
+// the same kernel on the GEMVFast layout's buffers (N % 16 == 0)
+bool awq_gemv_batch_fast_supports(int M, int K, int N, int g);
+int awq_launch_gemv_batch_fast(const uint16_t* x, const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros, uint16_t* y,
+                               int M, int K, int N, int g, int group_rows, int depth, hipStream_t st);
 // GEMV layout, prefill-sized batches: the register-decoded MFMA GEMM reading the layout's own buffers (gemm_regb.hip, NK form)
 bool awq_gemm_regb_nk_supports(int M, int K, int N, int g, int ZW);
 int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,

@@ -485,6 +485,23 @@ int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint1
     if (M == 0 || N == 0) return AWQ_OK;
     if (!x || !qweight || !scales || !qzeros || !y) return AWQ_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales) || !aligned16(qzeros)) return AWQ_ERR_BAD_ALIGNMENT;
+    // round 5: from five rows the batched kernel (gemv_batch.hip, GEMVFast form: any M in launches of <= 32 rows); AWQ_GEMM_FLAG_KERNEL:
+    // 0 = auto, 1 = the 16-row kernel (gemv_fast.hip, M <= 16), AWQ_GEMV_KERNEL_BATCH = the batched kernel
+    const uint32_t kern = AWQ_GEMM_FLAG_KERNEL(flags);
+    const bool batch_ok = awq_gemv_batch_fast_supports((int)(M > 32 ? 32 : M), (int)K, (int)N, (int)group_size);
+    if (kern == AWQ_GEMV_KERNEL_BATCH || (kern == 0 && M >= 5 && batch_ok)) {
+        if (!batch_ok) return AWQ_ERR_UNSUPPORTED;
+        g_last_kernel = "gemv_batch_fast";
+        const int64_t nchunk = (M + 31) / 32, rows = (M + nchunk - 1) / nchunk;
+        for (int64_t m0 = 0; m0 < M; m0 += rows) {
+            const int mm = (int)(M - m0 < rows ? M - m0 : rows);
+            const int rc = awq_launch_gemv_batch_fast(x + m0 * K, qweight, scales, qzeros, y + m0 * N, mm, (int)K, (int)N, (int)group_size,
+                                                      (int)group_rows, (int)AWQ_GEMM_FLAG_SPLITK(flags), static_cast<hipStream_t>(stream));
+            if (rc != AWQ_OK) return rc;
+        }
+        return AWQ_OK;
+    }
+    if (M > 16) return AWQ_ERR_UNSUPPORTED;  // the 16-row kernel (the host wrapper chunks)
     if (!awq_gemv_fast_supports((int)M, (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
     g_last_kernel = "gemv_fast";
     return awq_launch_gemv_fast(x, qweight, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size, (int)group_rows,

@@ -67,6 +67,7 @@ struct BatchParams {
     int tiles_base, tiles_rem, tiles_max;  // tiles per owner: base (+1 for the first rem owners)
     int ring_off, pbuf_off, pbuf_pitch, ystage_off;  // LDS byte offsets; pbuf_pitch: bytes per wave (XS: the wave's staging area)
     int xs_rows;     // XS: batch rows the staging area holds at a time (min(M, 8): more rows arrive in chunks of eight)
+    int GP;          // FAST (GEMVFast layout): rows of scales / qzeros [GP, N]
     unsigned long long* trace;             // debug builds only (tools/trace_gemv_batch.py)
 };
 
@@ -126,8 +127,16 @@ AWQ_DEV int xs_f(int m) { return ((m & 3) << 2) | ((m >> 2) & 3); }
 // pieces per wave requested up front every request takes 2.5 us instead of 1.2 -- the queues, not the latency, set the pace -- and the
 // waves start later: profiles/r05_gemv_batch_trace_v3.txt); XS: the activations reach the registers through a wave-private LDS
 // staging area (coalesced LDS-DMA) instead of 16-byte fragment loads
-template <int MI, int RD, bool XS>
+// FAST: the GEMVFast layout's buffers (awq/modules/linear/gemv_fast.py:26-65): qweight int16 [N/4, K] -- element [r, 64 b + 16 i + 8 h + t],
+// nibble j = w[4 r + i, 64 b + 32 h + 8 j + t] -- scales / qzeros fp16 [GP, N] with qzeros = -(s z); effective weight w s + qzeros.  A
+// tile's 16 rows are four int16 rows whose 512 k of the wave are 1 KiB contiguous each (one DMA instruction per int16 row); a 16-byte
+// chunk (i, h) of a 64-k block holds, dword d, the nibble pairs (8 j + 2 d, 8 j + 2 d + 1): lane kq takes the chunk of (block kq / 2,
+// half kq % 2) of its row, step c its dword c -- so the A fragment of step c is dword c of each of the lane's four activation chunks,
+// no permute.  Nibbles decode to 16 + w (exponent 2^4), the group folds y += s (acc - 16 sx) + qzeros sx with sx = sum of x over the
+// group (one ones-MFMA chain per pass, parked in LDS), the arithmetic of csrc/gemv_fast.hip.
+template <int MI, int RD, bool XS, bool FAST = false>
 __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
+    static_assert(!FAST || XS, "the GEMVFast form keeps its group sums in the staging area");
     constexpr int NA = MI * GW * 4;  // A fragments (16 bytes each) per lane
     constexpr bool LAZY = RD == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -159,6 +168,24 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
         const int g0 = (ps * p.wk + wki) * GW;
         const int row0 = live ? (t0 + tl) * 16 : 0;
         const uint32_t slot = lds0 + (uint32_t)(ring + (u % RD) * PIECE_B);
+        if constexpr (FAST) {
+            const int rb2 = p.K * 2;  // bytes of an int16 row
+#pragma unroll
+            for (int i = 0; i < GW; ++i) {  // int16 row i of the tile: its 1 KiB of this wave's K range, chunk slots permuted for the reads
+                constexpr int T[4] = {0, 2, 3, 1};
+                const int kqq = ((lane >> 2) & 3) ^ T[i];
+                const int off = 256 * (lane >> 4) + 128 * (kqq >> 1) + 32 * (lane & 3) + 16 * (kqq & 1);
+                const int byte = min(256 * g0 + off, rb2 - 16);
+                const uint32_t voff = live ? (uint32_t)(min((row0 >> 2) + i, (p.N >> 2) - 1) * rb2 + byte) : 0u;
+                AWQ_BT_DMA16(voff, p.qweight, slot + 1024u * i);
+            }
+            // scales / qzeros of groups g0 .. g0 + 3 for the tile's 16 rows: 32 bytes per group, lane l: group (l >> 3) & 3, dword l & 7
+            const int gr = min(g0 + ((lane >> 3) & 3), p.GP - 1);
+            const uint32_t vsz = (uint32_t)(((gr * p.N + min(row0, p.N - 16)) * 2) + 4 * (lane & 7));
+            AWQ_BT_DMA4(vsz, p.scales, slot + (uint32_t)PIECE_W);
+            AWQ_BT_DMA4(vsz, p.qzeros, slot + (uint32_t)(PIECE_W + 1024));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < GW; ++i) {
             const int r = i * 4 + (lane >> 4);  // row of the tile (four rows of 256 bytes per instruction)
@@ -190,6 +217,13 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 for (int c = 0; c < 4; ++c) {
                     const u32x4 d = afr[(mi * GW + u) * 4 + c];
                     u32x4 v;
+                    if constexpr (FAST) {  // natural order; invalid rows / groups: zeros
+                        const uint32_t sid = valid ? 0x03020100u : 0x0C0C0C0Cu;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_perm(d[e], d[e], sid);
+                        afr[(mi * GW + u) * 4 + c] = v;
+                        continue;
+                    }
                     v[0] = __builtin_amdgcn_perm(d[2], d[0], slo);  // (x0, x4)  bias 1024
                     v[1] = __builtin_amdgcn_perm(d[2], d[0], shi);  // (x1, x5)  bias 64
                     v[2] = __builtin_amdgcn_perm(d[3], d[1], slo);  // (x2, x6)  bias 1024
@@ -274,6 +308,24 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             }
         }
         permute_a(g0);
+        if constexpr (FAST) {
+            // sx[mi][u][m = 4 kq + r] = sum of x over group g0 + u: a ones-MFMA chain (every column of D is the row sum); lane n == 0 of
+            // each kq parks it in the (now dead) staging area behind the partial-tile buffers
+            const u32x4 ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int u = 0; u < GW; ++u) {
+                    float4_t sx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const u32x4 a = {afr[(mi * GW + u) * 4 + 0][c], afr[(mi * GW + u) * 4 + 1][c], afr[(mi * GW + u) * 4 + 2][c], afr[(mi * GW + u) * 4 + 3][c]};
+                        sx = mfma16(a, ones, sx);
+                    }
+                    if (n == 0) *reinterpret_cast<float4_t*>(smem + xs_w + 4096 + ((mi * GW + u) * 4 + kq) * 16) = sx;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     };
 
     // the activations, the ring's first piece right behind them; the other RD - 1 pieces once the fragments are in registers
@@ -320,7 +372,43 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 u32x4 wq[GW];
 #pragma unroll
                 for (int uu = 0; uu < GW; ++uu) wq[uu] = *reinterpret_cast<const u32x4*>(slot + n * 256 + (((4 * uu + kq) ^ n) & 15) * 16);
-                if constexpr (AWQ_BT_DBG & 2) {
+                if constexpr (FAST) {
+                    const int r4 = n >> 2, i4 = n & 3;
+                    constexpr int T[4] = {0, 2, 3, 1};
+                    const int tq = (r4 == 0 ? T[0] : r4 == 1 ? T[1] : r4 == 2 ? T[2] : T[3]) ^ kq;
+                    u32x4 wf[GW];
+#pragma unroll
+                    for (int uu = 0; uu < GW; ++uu) wf[uu] = *reinterpret_cast<const u32x4*>(slot + 1024 * r4 + 16 * (16 * uu + 4 * tq + i4));
+#pragma unroll
+                    for (int uu = 0; uu < GW; ++uu) {
+                        const uint32_t sw2 = *reinterpret_cast<const uint32_t*>(slot + PIECE_W + 32 * uu + 4 * (n >> 1));
+                        const uint32_t zw2 = *reinterpret_cast<const uint32_t*>(slot + PIECE_W + 1024 + 32 * uu + 4 * (n >> 1));
+                        const float sc = (float)u2h2(sw2)[n & 1];
+                        const float zc = __builtin_fmaf(-16.f, sc, (float)u2h2(zw2)[n & 1]);
+                        float4_t gacc[MI];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) gacc[mi] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t q = wf[uu][c];
+                            // nibble j of both int16 -> the pair (16 + w[8 j + 2 c], 16 + w[8 j + 2 c + 1]) under the exponent 2^4
+                            const u32x4 b = {and_or(q << 6, 0x03C003C0u, 0x4C004C00u), and_or(q << 2, 0x03C003C0u, 0x4C004C00u),
+                                             and_or(q >> 2, 0x03C003C0u, 0x4C004C00u), and_or(q >> 6, 0x03C003C0u, 0x4C004C00u)};
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) {
+                                const u32x4 a = {afr[(mi * GW + uu) * 4 + 0][c], afr[(mi * GW + uu) * 4 + 1][c], afr[(mi * GW + uu) * 4 + 2][c],
+                                                 afr[(mi * GW + uu) * 4 + 3][c]};
+                                gacc[mi] = mfma16(a, b, gacc[mi]);
+                            }
+                        }
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            const float4_t sx = *reinterpret_cast<const float4_t*>(smem + xs_w + 4096 + ((mi * GW + uu) * 4 + kq) * 16);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[mi][r] = __builtin_fmaf(sc, gacc[mi][r], __builtin_fmaf(zc, sx[r], acc[mi][r]));
+                        }
+                    }
+                } else if constexpr (AWQ_BT_DBG & 2) {
 #pragma unroll
                     for (int uu = 0; uu < GW; ++uu) acc[0] += __builtin_bit_cast(float4_t, wq[uu]) + __builtin_bit_cast(float4_t, sq) + (float)zw;
                 } else
@@ -418,8 +506,9 @@ struct BatchPlan {
 };
 
 // form: 0 = auto, 1 = activations through the LDS staging area (XS), 2 = direct fragment loads
-bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out) {
+bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out, bool fast = false) {
     if (M < 1 || M > 32 || N < 1 || K < 128 || K % 128 || g != 128) return false;
+    if (fast && (N % 16 || form == 2)) return false;  // GEMVFast: whole 4-row bundles, staged form only
     if ((int64_t)N * K / 2 >= ((int64_t)1 << 31) || (int64_t)M * K * 2 >= ((int64_t)1 << 31)) return false;  // 32-bit lane offsets
     BatchPlan b;
     b.MI = M > 16 ? 2 : 1;
@@ -442,9 +531,10 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     // XS: the staging area holds min(M, 8) batch rows per wave (more rows arrive in chunks of eight); the partial-tile buffers live
     // in it afterwards
     const int rows = M < 8 ? M : 8;
-    const size_t staged = (size_t)rows * 1024 > plain ? (size_t)rows * 1024 : plain;
+    size_t staged = (size_t)rows * 1024 > plain ? (size_t)rows * 1024 : plain;
+    if (fast && staged < (size_t)4096 + 256 * b.MI) staged = (size_t)4096 + 256 * b.MI;  // (the group sums sit behind the partial-tile buffers)
     const bool xs = form != 2 && b.ystage + 8 * staged + (size_t)8 * PIECE_B <= budget;
-    if (form == 1 && !xs) return false;
+    if ((form == 1 || fast) && !xs) return false;
     b.XS = xs ? 1 : 0;
     b.xs_rows = rows;
     b.pbuf_pitch = xs ? staged : plain;
@@ -472,13 +562,11 @@ bool awq_gemv_batch_supports(int M, int K, int N, int g) {
     return plan_batch(M, K, N, g, 0, 0, &b);
 }
 
-// form: how the activations reach the registers (0 = auto, 1 = LDS staging area, 2 = direct fragment loads); depth: pieces in flight
-// per wave (1 .. 3, 0 = auto)
-int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
-                          int M, int K, int N, int g, int ZW, int form, int depth, hipStream_t st) {
+namespace {
+int launch_batch(const void* x, const void* qweight, const void* scales, const void* qzeros, void* y, int M, int K, int N, int g, int ZW, int GP,
+                 int form, int depth, bool fast, hipStream_t st) {
     BatchPlan b;
-    if (!plan_batch(M, K, N, g, form, depth, &b)) return AWQ_ERR_UNSUPPORTED;
-    if (ZW * 8 < K / 128) return AWQ_ERR_BAD_SHAPE;
+    if (!plan_batch(M, K, N, g, form, depth, &b, fast)) return AWQ_ERR_UNSUPPORTED;
     BatchParams p;
     p.qweight = reinterpret_cast<const uint32_t*>(qweight);
     p.qzeros = reinterpret_cast<const uint32_t*>(qzeros);
@@ -486,7 +574,7 @@ int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint1
     p.x = reinterpret_cast<const half_t*>(x);
     p.y = reinterpret_cast<half_t*>(y);
     p.M = M; p.K = K; p.N = N;
-    p.KW = K / 8; p.ZW = ZW; p.SW = 8 * ZW;
+    p.KW = K / 8; p.ZW = ZW; p.SW = 8 * ZW; p.GP = GP;
     p.G = K / 128;
     p.wk = b.wk; p.wt = b.wt; p.passes = b.passes;
     p.tiles_base = b.tiles_base; p.tiles_rem = b.tiles_rem; p.tiles_max = b.tiles_max;
@@ -501,15 +589,39 @@ int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint1
     p.trace = nullptr;
 #endif
     const size_t lds = b.ring + 8 * b.pbuf_pitch + b.ystage;
-#define AWQ_BT_CASE(MIV, RDV, XSV)                                                                                                   \
-    if (b.MI == MIV && b.RD == RDV && b.XS == XSV) {                                                                                 \
-        static std::atomic<unsigned long long> opted{0};                                                                             \
-        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_batch_kernel<MIV, RDV, (XSV != 0)>), opted)) return AWQ_ERR_LAUNCH; \
-        hipLaunchKernelGGL((awq_gemv_batch_kernel<MIV, RDV, (XSV != 0)>), dim3((unsigned)b.blocks), dim3(512), lds, st, p);          \
-        return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;                                                            \
+#define AWQ_BT_CASE(MIV, RDV, XSV, FASTV)                                                                                               \
+    if (b.MI == MIV && b.RD == RDV && b.XS == XSV && fast == FASTV) {                                                                   \
+        static std::atomic<unsigned long long> opted{0};                                                                                \
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_batch_kernel<MIV, RDV, (XSV != 0), FASTV>), opted)) return AWQ_ERR_LAUNCH; \
+        hipLaunchKernelGGL((awq_gemv_batch_kernel<MIV, RDV, (XSV != 0), FASTV>), dim3((unsigned)b.blocks), dim3(512), lds, st, p);      \
+        return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;                                                               \
     }
-    AWQ_BT_CASE(1, 1, 0) AWQ_BT_CASE(1, 2, 0) AWQ_BT_CASE(1, 3, 0) AWQ_BT_CASE(2, 1, 0) AWQ_BT_CASE(2, 2, 0) AWQ_BT_CASE(2, 3, 0)
-    AWQ_BT_CASE(1, 1, 1) AWQ_BT_CASE(1, 2, 1) AWQ_BT_CASE(1, 3, 1) AWQ_BT_CASE(2, 1, 1) AWQ_BT_CASE(2, 2, 1) AWQ_BT_CASE(2, 3, 1)
+    AWQ_BT_CASE(1, 1, 0, false) AWQ_BT_CASE(1, 2, 0, false) AWQ_BT_CASE(1, 3, 0, false) AWQ_BT_CASE(2, 1, 0, false) AWQ_BT_CASE(2, 2, 0, false)
+    AWQ_BT_CASE(2, 3, 0, false) AWQ_BT_CASE(1, 1, 1, false) AWQ_BT_CASE(1, 2, 1, false) AWQ_BT_CASE(1, 3, 1, false) AWQ_BT_CASE(2, 1, 1, false)
+    AWQ_BT_CASE(2, 2, 1, false) AWQ_BT_CASE(2, 3, 1, false)
+    AWQ_BT_CASE(1, 1, 1, true) AWQ_BT_CASE(1, 2, 1, true) AWQ_BT_CASE(2, 1, 1, true) AWQ_BT_CASE(2, 2, 1, true)
 #undef AWQ_BT_CASE
     return AWQ_ERR_UNSUPPORTED;
+}
+}  // namespace
+
+// form: how the activations reach the registers (0 = auto, 1 = LDS staging area, 2 = direct fragment loads); depth: ring slots per wave
+// (1 | 3: that many pieces in flight; 2: the next piece is requested when a piece lands; 0 = auto)
+int awq_launch_gemv_batch(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* y,
+                          int M, int K, int N, int g, int ZW, int form, int depth, hipStream_t st) {
+    if (ZW * 8 < K / 128) return AWQ_ERR_BAD_SHAPE;
+    return launch_batch(x, qweight, scales, qzeros, y, M, K, N, g, ZW, 0, form, depth, false, st);
+}
+
+bool awq_gemv_batch_fast_supports(int M, int K, int N, int g) {
+    BatchPlan b;
+    return plan_batch(M, K, N, g, 0, 0, &b, true);
+}
+
+// the same kernel on the GEMVFast layout's buffers (qweight int16 [N/4, K], scales / qzeros fp16 [group_rows, N]); depth 1 | 2
+int awq_launch_gemv_batch_fast(const uint16_t* x, const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros, uint16_t* y,
+                               int M, int K, int N, int g, int group_rows, int depth, hipStream_t st) {
+    if (group_rows < K / 128) return AWQ_ERR_BAD_SHAPE;
+    if (depth > 2) depth = 2;
+    return launch_batch(x, qweight, scales, qzeros, y, M, K, N, g, 0, group_rows, 0, depth, true, st);
 }

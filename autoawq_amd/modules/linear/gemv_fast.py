@@ -17,7 +17,9 @@ from ... import _lib, ops
 from ...utils.packing import calculate_zeros_width, pack_intweight_fast, quantize_int_weights_nk
 from .gemv import dequant_matmul_nk
 
-PREFILL_MIN_ROWS = 17
+# up to this many rows: the decode / batched-decode kernels (round 5: csrc/gemv_batch.hip in its GEMVFast form, launches of <= 32 rows, group
+# size 128; other group sizes: 16 rows, csrc/gemv_fast.hip); above: dequantise + dense GEMM
+PREFILL_MIN_ROWS = 97
 
 
 class WQLinear_GEMVFast(torch.nn.Module):
@@ -75,7 +77,8 @@ class WQLinear_GEMVFast(torch.nn.Module):
         if in_dtype != torch.float16:
             inputs = inputs.half()
         out = None
-        if inputs.shape[0] < PREFILL_MIN_ROWS and self.out_features % 16 == 0:
+        rows = inputs.shape[0]
+        if (rows <= 16 or (rows < PREFILL_MIN_ROWS and self.group_size == 128 and self.in_features % 128 == 0)) and self.out_features % 16 == 0:
             try:
                 out = ops.gemv_fast_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
             except _lib.AwqHipError as e:  # a shape the decode kernel does not take (K % 128, unusual group sizes)

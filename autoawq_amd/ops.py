@@ -494,6 +494,15 @@ def gemv_fast_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     if M == 0:
         return y
     L = _lib.lib()
+    kern = flags & 0xF
+    if (kern == GEMV_KERNEL_BATCH or (kern == 0 and M >= 5)):
+        # round 5: the batched kernel in its GEMVFast form takes ANY M in one call (launches of <= 32 rows inside the library); shapes it
+        # refuses (group sizes other than 128) fall through to the 16-row kernel in chunks
+        with torch.cuda.device(x2d.device):
+            rc = L.awq_gemv_fast_forward(_ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), M, K, N, group_size, GP, flags, _stream())
+        if rc != _lib.ERR_UNSUPPORTED or kern == GEMV_KERNEL_BATCH:
+            _lib.check(rc, "awq_gemv_fast_forward")
+            return y
     chunk = 16
     while chunk > 1 and L.awq_gemv_fast_lds_bytes_c(chunk, K, group_size) > 160 * 1024:
         chunk //= 2

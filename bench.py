@@ -209,10 +209,10 @@ def leg_gemm_bs(dev, ops):
     out["bs8"] = out["by_batch"]["8"]
     del sets
     torch.cuda.empty_cache()
-    # the same matrix shape in the WQLinear_GEMV format (awq_gemv_forward: row-streaming kernel at M <= 2, 16-row MFMA tiles to 16)
+    # the same matrix shape in the WQLinear_GEMV format (awq_gemv_forward: row-streaming kernel to 4 rows, the batched kernel from 5)
     sets = [rand_packed_nk(K, N, GROUP, dev, gen) for _ in range(nsets)]
     out["gemv_layout_by_batch"] = {}
-    for M in (1, 2, 4, 8, 16, 32, 64):  # (from 17 rows: 16-row chunks of the decode kernels -- the layout's own buffers, no GEMM-layout copy)
+    for M in (1, 2, 4, 5, 8, 12, 16, 24, 32, 48, 64, 96):  # (round 5: from five rows csrc/gemv_batch.hip, launches of <= 32 rows on the layout's own buffers)
         x = torch.randn((M, K), device=dev, generator=gen).half()
 
         def fn2():
@@ -224,6 +224,7 @@ def leg_gemm_bs(dev, ops):
         out["gemv_layout_by_batch"][str(M)] = {"us": us, "kernel": ops.last_kernel(),
                                                "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                             "frac": by / us / 1e3 / HBM_PEAK_GBS, "bytes_per_launch": by}}
+    out["gemv_layout_bs8"] = out["gemv_layout_by_batch"]["8"]  # north_star's "bs=8 ... 4096x11008" on the default decode layout
     del sets
     torch.cuda.empty_cache()
     return out
@@ -294,14 +295,32 @@ def leg_gemm_prefill(dev, ops):
     rel_nk = float((an - bn).abs().max() / bn.abs().max())
     assert rel_nk < 5e-3, f"GEMV-layout prefill kernel disagrees with dequantise + GEMM: {rel_nk}"
     nk_by_m = {str(m): 2.0 * m * K * N / timeit(lambda: ops.gemv_forward(x[:m], nq, ns, nz, GROUP, flags=pre)) / 1e6 for m in (4096, 8192)}
+    # round 5, the module's default route: the packed nibbles transposed into a temporary of the call (csrc/repack.hip) + the fused MFMA
+    # GEMM above on it -- two hand-written launches, no vendor GEMM, nothing resident
+    us_rp = timeit(lambda: ops.gemv_prefill_repack(x, nq, ns, nz, GROUP))
+    us_rk = timeit(lambda: ops.repack_gemv_to_gemm(nq, ns, nz, GROUP), reps=20)
+    rp_by_m = {str(m): 2.0 * m * K * N / timeit(lambda: ops.gemv_prefill_repack(x[:m], nq, ns, nz, GROUP)) / 1e6 for m in (256, 1024, 4096)}
+    ar = ops.gemv_prefill_repack(x[:2048], nq, ns, nz, GROUP).float()
+    rel_rp = float((ar - bn).abs().max() / bn.abs().max())
+    assert rel_rp < 5e-3, f"repack prefill route disagrees with dequantise + GEMM: {rel_rp}"
+    from autoawq_amd import WQLinear_GEMV
+
+    modv = WQLinear_GEMV(4, GROUP, K, N, False, dev)
+    modv.qweight, modv.qzeros, modv.scales = nq, nz, ns
+    us_mv = timeit(lambda: modv(x))
 
     return {"shape": f"{K}x{N} g{GROUP}, M={M} (bs 8 x seq 2048)", "flops": fl,
             "gemv_layout": {"fused_nk": {"us": us_nk, "kernel": nk_kernel, "roofline": roof(us_nk), "tflops_other_token_counts": nk_by_m,
                                          "vs_dequant_plus_gemm_max_rel": rel_nk},
                             "two_pass": {"us": us_nk2, "roofline": roof(us_nk2)},
-                            "what": "WQLinear_GEMV buffers (qweight [N, K/8]), no second copy of the weights: the module's default route "
-                                    "(awq_dequantize_weights_gemv into a temporary + a dense fp16 GEMM) and the opt-in fused kernel "
-                                    "(AWQ_GEMV_KERNEL_PREFILL: gemm_regb.hip, N-major form)"},
+                            "repack": {"us": us_rp, "roofline": roof(us_rp), "repack_kernel_us": us_rk,
+                                       "repack_kernel_gbs": K * N / us_rk / 1e3, "tflops_other_token_counts": rp_by_m,
+                                       "vs_dequant_plus_gemm_max_rel": rel_rp},
+                            "module": {"us": us_mv, "roofline": roof(us_mv), "route": modv.PREFILL_IMPL},
+                            "what": "WQLinear_GEMV buffers (qweight [N, K/8]), no second copy of the weights: the module's default route since "
+                                    "round 5 = `repack` (csrc/repack.hip transposes the packed nibbles into a temporary, then the fused MFMA GEMM: "
+                                    "hand-written end to end); `two_pass` (awq_dequantize_weights_gemv + a dense vendor GEMM) and `fused_nk` "
+                                    "(AWQ_GEMV_KERNEL_PREFILL: gemm_regb.hip, N-major form) are opt-in"},
             "fused_mfma": {"us": us_f, "kernel": kernel, "roofline": roof(us_f)},
             "fused_lds_tiled_r01": {"us": us_t, "roofline": roof(us_t)}, "two_pass": {"us": us_2, "roofline": roof(us_2)},
             "module": {"us": us_m, "roofline": roof(us_m),

@@ -225,8 +225,10 @@ AWQ_EXPORT int awq_repack_gemv_to_gemm(const int32_t* qweight, const uint16_t* s
 
 /* Replaces awq_v2_ext.gemv_forward_cuda_decode(x, qweight, scales, qzeros, m, n, k, group_size) and, for
  * small M, awq_v2_ext.gemm_forward_cuda_prefill (gemv_fast.py:185-208).  y [M, N] = x [M, K] @ W^T with
- * W = w*s + qzeros; 1 <= M <= 16 per call (host wrapper chunks), N % 16 == 0, K % 128 == 0.
- * group_rows = rows of scales / qzeros (8*ZW). */
+ * W = w*s + qzeros; N % 16 == 0, K % 128 == 0.  group_rows = rows of scales / qzeros (8*ZW).  AUTO (AWQ_GEMM_FLAG_KERNEL 0): from
+ * M = 5 the batched kernel (gemv_batch.hip in its GEMVFast form, group_size 128: ANY M in one call, launches of <= 32 rows;
+ * also AWQ_GEMV_KERNEL_BATCH explicitly, _SPLITK = ring slots 1 | 2); below that, or with AWQ_GEMM_FLAG_KERNEL = 1, the 16-row kernel
+ * (gemv_fast.hip: 1 <= M <= 16 per call, the host wrapper chunks). */
 AWQ_EXPORT int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint16_t* scales,
                                      const uint16_t* qzeros, uint16_t* y, int64_t M, int64_t K, int64_t N,
                                      int64_t group_size, int64_t group_rows, uint32_t flags, void* stream);

@@ -1122,14 +1122,46 @@ def test_gemvfast_layout_vs_oracle(ops, oracle, K, N, g, M):
     assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
     y32, _ = oracle.matmul(x.numpy(), W)
     wsig = oracle.weight_rounding_sigma(x.numpy(), W)
-    for flags in (0, ops.gemm_flags(waves=4, unit=8), ops.gemm_flags(waves=16, unit=4)):
+    # AUTO: from five rows at group size 128 the batched kernel (round 5); kernel=1 forces the 16-row kernel (csrc/gemv_fast.hip)
+    for flags in (0, ops.gemm_flags(kernel=1, waves=4, unit=8), ops.gemm_flags(kernel=1, waves=16, unit=4)):
         y = ops.gemv_fast_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=flags)
-        assert ops.last_kernel() == "gemv_fast"
+        assert ops.last_kernel() == ("gemv_batch_fast" if (flags == 0 and M >= 5 and g == 128 and N % 16 == 0) else "gemv_fast"), ops.last_kernel()
         assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemvfast K{K} N{N} g{g} M{M}", wsigma=wsig)
     e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
     ks = (torch.arange(M, device="cuda") * 29 + 11) % K
     e[torch.arange(M, device="cuda"), ks] = 1.0
     assert torch.equal(ops.gemv_fast_forward(e, qw.cuda(), sc.cuda(), qz.cuda(), g), Wt.t()[ks])
+
+
+@pytest.mark.parametrize("K,N", [(4096, 11008), (4096, 4096), (11008, 4096), (8192, 1280), (1024, 8192), (256, 16), (4224, 208)])
+def test_gemvfast_batch_kernel_vs_oracle(ops, oracle, K, N):
+    """csrc/gemv_batch.hip in its GEMVFast form (round 5: the batched kernel on qweight int16 [N/4, K], scales / qzeros fp16 [GP, N]; the
+    reference runs awq_v2_ext.gemm_forward_cuda_prefill there, gemv_fast.py:203-206): 7B and 70B-shard shapes, one and several passes
+    over K, few tiles, every ring form, batches 5 .. 96 (chunked above 32); against the oracle's W = fp16(w s + qzeros) and fp32 product;
+    one-hot rows select rows of the bit-exact W^T; bitwise reproducible."""
+    g = 128
+    qw, sc, qz, xall = gemvfast_case(K, N, g, 96, seed=K + 3 * N)
+    W = oracle.dequant_gemvfast(qw.numpy(), sc.numpy(), qz.numpy(), g)
+    qwc, scc, qzc, xc = qw.cuda(), sc.cuda(), qz.cuda(), xall.cuda()
+    Wt = ops.dequantize_weights_gemv_fast(qwc, scc, qzc, g)
+    y32_all, _ = oracle.matmul(xall.numpy(), W)
+    wsig_all = oracle.weight_rounding_sigma(xall.numpy(), W)
+    bt = ops.gemm_flags(kernel=GEMV_KERNEL_BATCH)
+    for M in ([5, 8, 12, 16, 17, 31, 32, 33, 64, 96] if K * N <= 4096 * 11008 else [5, 16, 32, 64]):
+        x = xc[96 - M:]
+        y32, wsig = y32_all[96 - M:], wsig_all[96 - M:]
+        for f in ([0, ops.gemm_flags(splitk=1), ops.gemm_flags(splitk=2)] if M in (5, 16, 17, 32) else [0]):
+            y = ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)
+            assert ops.last_kernel() == "gemv_batch_fast"
+            assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"batch-fast K{K} N{N} M{M} f{f:x}", wsigma=wsig)
+            assert torch.equal(y, ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)), "not bitwise reproducible"
+        assert torch.equal(ops.gemv_fast_forward(x, qwc, scc, qzc, g), ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt))  # AUTO takes it
+    for M in (5, 16, 20):
+        e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+        ks = (torch.arange(M, device="cuda") * 977 + K - 5) % K
+        e[torch.arange(M, device="cuda"), ks] = 1.0
+        assert torch.equal(ops.gemv_fast_forward(e, qwc, scc, qzc, g, flags=bt), Wt.t()[ks]), "one-hot rows must select rows of W"
+        assert int(ops.gemv_fast_forward(torch.zeros_like(e), qwc, scc, qzc, g, flags=bt).abs().max()) == 0
 
 
 def test_gemvfast_module_forward(ops, oracle):
