@@ -227,6 +227,23 @@ def leg_gemm_bs(dev, ops):
     out["gemv_layout_bs8"] = out["gemv_layout_by_batch"]["8"]  # north_star's "bs=8 ... 4096x11008" on the default decode layout
     del sets
     torch.cuda.empty_cache()
+    # ... and in the WQLinear_GEMVFast format (round 5: the batched kernel reads this layout too)
+    sets = [rand_packed_nk(K, N, GROUP, dev, gen, fast=True) for _ in range(nsets)]
+    out["gemvfast_layout_by_batch"] = {}
+    for M in (1, 8, 32, 64):
+        x = torch.randn((M, K), device=dev, generator=gen).half()
+
+        def fn3():
+            for qw, qz, sc in sets:
+                ops.gemv_fast_forward(x, qw, sc, qz, GROUP)
+
+        us = graph_time(fn3, st, reps=5) / nsets
+        by = algorithmic_bytes(K, N, M, GROUP) + (K // GROUP) * N * 2 - (K // GROUP) * (N // 8) * 4  # fp16 zero terms instead of packed nibbles
+        out["gemvfast_layout_by_batch"][str(M)] = {"us": us, "kernel": ops.last_kernel(),
+                                                   "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                "frac": by / us / 1e3 / HBM_PEAK_GBS, "bytes_per_launch": by}}
+    del sets
+    torch.cuda.empty_cache()
     return out
 
 
