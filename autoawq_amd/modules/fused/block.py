@@ -173,7 +173,7 @@ class LlamaLikeBlock(nn.Module):
 # The other block families of awq/modules/fused/block.py (round 4): the same constructors and dataflows over this package's
 # QuantAttentionFused (whose feature surface -- ALiBi, logit soft-capping, q / k norms, custom attention shapes -- round 3 built and
 # pinned).  They run the plain module path (separate norm / attention / MLP launches); the five-launch folded decode path is
-# LlamaLikeBlock's.  Not built: CohereBlock (block.py:264-320) -- it asks for the INTERLEAVED rotary form (`is_neox=False`), which
+# LlamaLikeBlock's.  Not built (and no class of that name is shipped: round 5): CohereBlock (block.py:264-320) -- it asks for the INTERLEAVED rotary form (`is_neox=False`), which
 # awq_rope_kv_append does not implement -- and Phi-3's `rope_scaling` (long-rope factors): both raise instead of computing
 # something else.
 
@@ -301,10 +301,3 @@ class FalconDecoderLayer(nn.Module):
             attn_in = mlp_in = self.input_layernorm(hidden_states)
         attn_output, _, _ = self.attn.forward(hidden_states=attn_in)
         return _add(hidden_states, attn_output) + self.mlp.forward(mlp_in)
-
-
-class CohereBlock(nn.Module):
-    """awq/modules/fused/block.py:264-320 is NOT built: it needs the interleaved rotary form (`is_neox=False`)."""
-
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("CohereBlock needs interleaved RoPE (is_neox=False), which awq_rope_kv_append does not implement")
