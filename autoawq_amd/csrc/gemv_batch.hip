@@ -131,8 +131,8 @@ AWQ_DEV int xs_f(int m) { return ((m & 3) << 2) | ((m >> 2) & 3); }
 // nibble j = w[4 r + i, 64 b + 32 h + 8 j + t] -- scales / qzeros fp16 [GP, N] with qzeros = -(s z); effective weight w s + qzeros.  A
 // tile's 16 rows are four int16 rows whose 512 k of the wave are 1 KiB contiguous each (one DMA instruction per int16 row); a 16-byte
 // chunk (i, h) of a 64-k block holds, dword d, the nibble pairs (8 j + 2 d, 8 j + 2 d + 1): lane kq takes the chunk of (block kq / 2,
-// half kq % 2) of its row, step c its dword c -- so the A fragment of step c is dword c of each of the lane's four activation chunks,
-// no permute.  Nibbles decode to 16 + w (exponent 2^4), the group folds y += s (acc - 16 sx) + qzeros sx with sx = sum of x over the
+// half kq % 2) of its row, step c its dword c -- so the A fragment of step c is dword c of each of the lane's four activation chunks:
+// one 4 x 4 dword transpose per pass, no pair permute.  Nibbles decode to 16 + w (exponent 2^4), the group folds y += s (acc - 16 sx) + qzeros sx with sx = sum of x over the
 // group (one ones-MFMA chain per pass, parked in LDS), the arithmetic of csrc/gemv_fast.hip.
 template <int MI, int RD, bool XS, bool FAST = false>
 __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
@@ -213,17 +213,26 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             for (int u = 0; u < GW; ++u) {
                 const bool valid = (16 * mi + n < M) && (g0 + u < p.G);
                 const uint32_t slo = valid ? 0x05040100u : 0x0C0C0C0Cu, shi = valid ? 0x07060302u : 0x0C0C0C0Cu;  // 0x0C: the constant 0
+                if constexpr (FAST) {
+                    // natural pair order, but step c wants dword c of each of the lane's four chunks: a 4 x 4 dword transpose, ONCE per pass
+                    // (assembled per MFMA it cost four copies each and spilled at MI 2); invalid rows / groups: zeros
+                    const uint32_t sid = valid ? 0x03020100u : 0x0C0C0C0Cu;
+                    const u32x4 d0 = afr[(mi * GW + u) * 4 + 0], d1 = afr[(mi * GW + u) * 4 + 1], d2 = afr[(mi * GW + u) * 4 + 2], d3 = afr[(mi * GW + u) * 4 + 3];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        u32x4 v;
+                        v[0] = __builtin_amdgcn_perm(d0[c], d0[c], sid);
+                        v[1] = __builtin_amdgcn_perm(d1[c], d1[c], sid);
+                        v[2] = __builtin_amdgcn_perm(d2[c], d2[c], sid);
+                        v[3] = __builtin_amdgcn_perm(d3[c], d3[c], sid);
+                        afr[(mi * GW + u) * 4 + c] = v;
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const u32x4 d = afr[(mi * GW + u) * 4 + c];
                     u32x4 v;
-                    if constexpr (FAST) {  // natural order; invalid rows / groups: zeros
-                        const uint32_t sid = valid ? 0x03020100u : 0x0C0C0C0Cu;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_perm(d[e], d[e], sid);
-                        afr[(mi * GW + u) * 4 + c] = v;
-                        continue;
-                    }
                     v[0] = __builtin_amdgcn_perm(d[2], d[0], slo);  // (x0, x4)  bias 1024
                     v[1] = __builtin_amdgcn_perm(d[2], d[0], shi);  // (x1, x5)  bias 64
                     v[2] = __builtin_amdgcn_perm(d[3], d[1], slo);  // (x2, x6)  bias 1024
@@ -319,8 +328,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                     float4_t sx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const u32x4 a = {afr[(mi * GW + u) * 4 + 0][c], afr[(mi * GW + u) * 4 + 1][c], afr[(mi * GW + u) * 4 + 2][c], afr[(mi * GW + u) * 4 + 3][c]};
-                        sx = mfma16(a, ones, sx);
+                        sx = mfma16(afr[(mi * GW + u) * 4 + c], ones, sx);
                     }
                     if (n == 0) *reinterpret_cast<float4_t*>(smem + xs_w + 4096 + ((mi * GW + u) * 4 + kq) * 16) = sx;
                 }
@@ -395,11 +403,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                             const u32x4 b = {and_or(q << 6, 0x03C003C0u, 0x4C004C00u), and_or(q << 2, 0x03C003C0u, 0x4C004C00u),
                                              and_or(q >> 2, 0x03C003C0u, 0x4C004C00u), and_or(q >> 6, 0x03C003C0u, 0x4C004C00u)};
 #pragma unroll
-                            for (int mi = 0; mi < MI; ++mi) {
-                                const u32x4 a = {afr[(mi * GW + uu) * 4 + 0][c], afr[(mi * GW + uu) * 4 + 1][c], afr[(mi * GW + uu) * 4 + 2][c],
-                                                 afr[(mi * GW + uu) * 4 + 3][c]};
-                                gacc[mi] = mfma16(a, b, gacc[mi]);
-                            }
+                            for (int mi = 0; mi < MI; ++mi) gacc[mi] = mfma16(afr[(mi * GW + uu) * 4 + c], b, gacc[mi]);
                         }
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {

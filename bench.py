@@ -779,7 +779,7 @@ def main():
                          "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "
                                  "HIP-event-timed replay of the captured stream / launches, i.e. it contains the "
                                  "dispatch gap exactly as rocprofv3's back-to-back kernel durations do "
-                                 "(profiles/r04_bench_kernel_trace_stats.txt)"},
+                                 "(profiles/r05_bench_kernel_trace_stats.txt)"},
         }
         if capture_note:
             out["config"]["capture_note"] = capture_note

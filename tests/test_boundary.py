@@ -294,6 +294,25 @@ def test_hand_counted_waits_of_the_register_decoded_kernels_hold_in_the_generate
         assert kernels >= least and visits > 0, (name, kernels, visits)
 
 
+def test_counted_wait_kernels_use_no_scratch():
+    """The kernels whose vector-memory waits are counted by hand must not touch scratch memory: a spill is a vector-memory operation hipcc
+    places where it likes -- it would sit in the same in-order queue and break every count after it (and it is slow: round 5's first
+    GEMVFast form of gemv_batch spilled 600-800 bytes per lane at MI = 2 and ran 2.8x slower than the GEMV form).  hipcc's own resource
+    report, per instantiation."""
+    import re
+    import subprocess
+
+    from autoawq_amd.csrc import build as hip_build
+
+    for f in ("gemv_batch.hip", "gemv_rows.hip", "gemv_lds.hip", "gemm_regb.hip", "gemm_skinny.hip", "prefill_attn.hip"):
+        cmd = [hip_build.HIPCC] + hip_build.FLAGS + hip_build.EXTRA.get(f, []) + ["--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c",
+                                                                                  os.path.join(ROOT, "autoawq_amd", "csrc", f), "-o", os.devnull]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sizes = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+        assert sizes and max(sizes) == 0, (f, sizes)
+
+
 def test_auto_dispatch_table_host_only():
     """awq_gemm_auto_kernel is a host-only query (no launch, no GPU): which kernel awq_gemm_forward's AUTO dispatch takes
     for the BASELINE shapes, by token count -- the table DESIGN.md section 1 (row a4/a5) describes."""
