@@ -378,7 +378,11 @@ int awq_gemv_auto_kernel(int64_t M, int64_t K, int64_t N, int64_t group_size) {
     // round 5: from five rows the batched kernel (gemv_batch.hip: activations in registers, the K range split over the waves of a
     // block, weights by LDS-DMA) -- up to 32 rows per launch, any M in one call (balanced chunks); it replaces gemv_lds / gemv_nk
     // wherever it takes the shape (group_size 128): 4096 x 11008, M = 8: see profiles/r05_*; AWQ_GEMV_KERNEL_PREFILL is explicit only
-    if (M >= 5 && awq_gemv_batch_supports((int)(M > 32 ? 32 : M), k, n, g)) return (int)AWQ_GEMV_KERNEL_BATCH;
+    // ... and already at four rows while K > 2048, at three where the row-streaming kernel is not the choice (K > 6144): it costs the
+    // same at 1 .. 5 rows while gemv_rows / gemv_nk grow by ~1 us per row (profiles/r05_sweep_small_batch.txt, M = 4: 9.1 vs 10.3 us at
+    // 4096 x 11008, 14.4 vs 15.3 at 4096 x 22016, 12.7 vs 17.6 at 8192 x 7168; level at K = 11008; behind at K = 1024)
+    if ((M >= 5 || (M == 4 && K > 2048) || (M == 3 && K > 6144)) && awq_gemv_batch_supports((int)(M > 32 ? 32 : M), k, n, g))
+        return (int)AWQ_GEMV_KERNEL_BATCH;
     if (M > 16) return -1;  // the older decode kernels serve 16 rows per call (the host wrapper chunks)
     // round 4: batch 2 at every K and batches 3 .. 4 while K <= 6144 also run the row-streaming kernel -- it is ahead of the
     // 16-row tile kernel there on all four 7B shapes (profiles/r03_gemv_rows_sweep.txt: M = 2 4.65 / 7.05 / 10.77 / 8.57 us vs
@@ -489,7 +493,11 @@ int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint1
     // 0 = auto, 1 = the 16-row kernel (gemv_fast.hip, M <= 16), AWQ_GEMV_KERNEL_BATCH = the batched kernel
     const uint32_t kern = AWQ_GEMM_FLAG_KERNEL(flags);
     const bool batch_ok = awq_gemv_batch_fast_supports((int)(M > 32 ? 32 : M), (int)K, (int)N, (int)group_size);
-    if (kern == AWQ_GEMV_KERNEL_BATCH || (kern == 0 && M >= 5 && batch_ok)) {
+    // below five rows AUTO takes it where ONE pass of eight waves covers K (2048 < K <= 4096): there it is ahead of the 16-row kernel at
+    // every M (profiles/r05_sweep_small_batch.txt, M = 1: 5.4 / 9.3 / 9.6 / 15.0 us vs 6.2 / 9.7 / 10.1 / 16.3 at N = 4096 / 11008 /
+    // 12288 / 22016), behind it at K = 1024 (fewer waves per tile) and from K = 8192 (two passes)
+    const bool small_ok = K > 2048 && K <= 4096;
+    if (kern == AWQ_GEMV_KERNEL_BATCH || (kern == 0 && (M >= 5 || small_ok) && batch_ok)) {
         if (!batch_ok) return AWQ_ERR_UNSUPPORTED;
         g_last_kernel = "gemv_batch_fast";
         const int64_t nchunk = (M + 31) / 32, rows = (M + nchunk - 1) / nchunk;

@@ -556,7 +556,11 @@ def leg_by_layout(dev, ops, layers, skip):
             by += sum((l["K"] // GROUP) * l["N"] * 3 // 2 for layer in model for l in layer)
         outs = [None] * sum(len(l) for l in model)
         us = graph_time(lambda: run_step(model, outs, ops, None), st, reps=20, min_seconds=0.3)
-        out[layout] = {"tok_s": 1e6 / us, "ms_per_step": us / 1e3, "kernel": ops.last_kernel(),
+        kernels = {}
+        for lin in model[0]:  # (one eager call per Linear of a layer, after the timed region: which kernel AUTO took at each shape)
+            forward_lin(ops, lin, lin["x"])
+            kernels[f'{lin["K"]}x{lin["N"]}'] = ops.last_kernel()
+        out[layout] = {"tok_s": 1e6 / us, "ms_per_step": us / 1e3, "kernel": "/".join(sorted(set(kernels.values()))), "kernel_by_shape": kernels,
                        "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS}}
         del model, outs
         torch.cuda.empty_cache()

@@ -239,7 +239,7 @@ def test_hand_counted_asm_loads_are_hazard_safe():
 
 
 def test_gemv_layout_auto_dispatch_table_host_only():
-    """awq_gemv_auto_kernel (host only): the row-streaming kernel at batches 1 - 2 (3 - 4 while K <= 6144), from five rows the
+    """awq_gemv_auto_kernel (host only): the row-streaming kernel at batches 1 - 2 (3 while K <= 6144, 4 while K <= 2048), from there the
     batched kernel (round 5, group size 128), the 16-row tile kernel otherwise -- DESIGN.md 3.0 / 3.0c."""
     from autoawq_amd import _lib
 
@@ -248,8 +248,10 @@ def test_gemv_layout_auto_dispatch_table_host_only():
     for K, N in [(4096, 4096), (4096, 12288), (4096, 22016), (11008, 4096), (8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192)]:
         assert q(1, K, N) == ROWS, (K, N)
     assert q(2, 4096, 12288) == ROWS and q(2, 11008, 4096) == ROWS   # batch 2: ahead of the tile kernel on every 7B shape (r03 sweep)
-    assert q(3, 4096, 22016) == ROWS and q(4, 4096, 11008) == ROWS and q(4, 11008, 4096) == TILE and q(3, 8192, 1280) == TILE
-    BATCH = 5  # round 5: csrc/gemv_batch.hip from five rows at group size 128, any M in one call
+    BATCH = 5  # round 5: csrc/gemv_batch.hip from five rows at group size 128, any M in one call; four rows while K > 2048, three while K > 6144
+    assert q(3, 4096, 22016) == ROWS and q(4, 1024, 8192) == ROWS and q(4, 2048, 4096) == ROWS and q(3, 3584, 8192) == ROWS
+    assert q(4, 4096, 11008) == BATCH and q(4, 11008, 4096) == BATCH and q(3, 8192, 1280) == BATCH and q(3, 11008, 4096) == BATCH
+    assert q(4, 4096, 11008, 64) == TILE and q(3, 8192, 1280, 64) == TILE and q(4, 4096, 4096, 4096) == ROWS  # other group sizes: as before
     assert q(8, 4096, 11008) == BATCH and q(8, 4096, 22016) == BATCH and q(16, 4096, 11008) == BATCH and q(8, 4096, 4096) == BATCH
     assert q(5, 11008, 4096) == BATCH and q(32, 8192, 1280) == BATCH and q(64, 4096, 11008) == BATCH and q(100, 3584, 8192) == BATCH
     assert q(8, 4096, 11008, 64) == TILE and q(17, 4096, 11008, 64) == -1  # other group sizes: the 16-row kernels (the wrapper chunks)

@@ -490,12 +490,13 @@ GEMV_KERNEL_TILE16, GEMV_KERNEL_ROWS = 1, 2  # AWQ_GEMV_KERNEL_* of include/awq_
 def gemv_rows_takes(M, K, g):
     """AUTO dispatch of awq_gemv_forward (capi.hip awq_gemv_auto_kernel): the row-streaming kernel at batches 1 and 2, and at
     batches 3 .. 4 while K <= 6144 (round 4; profiles/r03_gemv_rows_sweep.txt)"""
-    return g % 128 == 0 and K % g == 0 and K >= 128 and (M <= 2 or (M <= 4 and K <= 6144))
+    return g % 128 == 0 and K % g == 0 and K >= 128 and (M <= 2 or (M <= 4 and K <= 6144)) and not gemv_batch_takes(M, K, g)
 
 
 def gemv_batch_takes(M, K, g):
-    """AUTO dispatch of awq_gemv_forward from five rows (round 5): csrc/gemv_batch.hip wherever it takes the shape"""
-    return g == 128 and M >= 5 and K % 128 == 0 and K >= 128
+    """AUTO dispatch of awq_gemv_forward from five rows (round 5): csrc/gemv_batch.hip wherever it takes the shape; four rows while
+    K > 2048 and three while K > 6144 too (profiles/r05_sweep_small_batch.txt)"""
+    return g == 128 and (M >= 5 or (M == 4 and K > 2048) or (M == 3 and K > 6144)) and K % 128 == 0 and K >= 128
 
 
 @pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (11008, 4096, 128), (4096, 11008, 128), (1024, 72, 64),
@@ -736,15 +737,15 @@ def test_gemv_batch_kernel_vs_oracle(ops, oracle, K, N):
     """csrc/gemv_batch.hip (GEMV layout, round 5: activations as MFMA A fragments in registers, a tile's K range split over the
     eight waves of one block, weights by LDS-DMA): the four 7B and the four 70B-shard shapes, ragged N, one and several passes
     over K (11008: two / three, 14336, 16512: three / five), few tiles (N = 16, 72, 200: idle owners at the barriers), every batch
-    5 .. 64 at the benched shape and a ragged sample elsewhere (17, 33 ...: two 16-row tiles with a ragged second one, balanced
+    1 .. 64 at the benched shape and a ragged sample elsewhere (17, 33 ...: two 16-row tiles with a ragged second one, balanced
     chunks above 32), both ways the activations reach the registers (LDS staging area | direct fragment loads) and every ring depth;
     against the CPU oracle (the
     reference's dequantised fp16 weights, fp32 product), bitwise reproducible, one-hot rows select rows of the bit-exact W, zero
     in -> zero out, f(2x) == 2 f(x)."""
     g = 128
-    all_m = list(range(5, 65)) if (K, N) == (4096, 11008) else [5, 8, 12, 13, 16, 17, 24, 31, 32, 33, 48, 64]
+    all_m = list(range(1, 65)) if (K, N) == (4096, 11008) else [1, 3, 4, 5, 8, 12, 13, 16, 17, 24, 31, 32, 33, 48, 64]
     if K * N > 4096 * 12288:
-        all_m = [5, 16, 17, 32, 64]
+        all_m = [4, 5, 16, 17, 32, 64]
     qw, qz, sc, xall = gemv_case(K, N, g, 64, seed=K + 7 * N)
     W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
     qwc, qzc, scc, xc = qw.cuda(), qz.cuda(), sc.cuda(), xall.cuda()
@@ -768,8 +769,11 @@ def test_gemv_batch_kernel_vs_oracle(ops, oracle, K, N):
             assert ops.last_kernel() == "gemv_batch"
             assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"batch K{K} N{N} M{M} f{f:x}", wsigma=wsig)
             assert torch.equal(y, ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt | f)), "not bitwise reproducible"
-        ya = ops.gemv_forward(x, qwc, scc, qzc, g)  # AUTO takes it from five rows
-        assert ops.last_kernel() == "gemv_batch" and torch.equal(ya, ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt))
+        ya = ops.gemv_forward(x, qwc, scc, qzc, g)  # AUTO takes it from five rows (four while K > 2048, three while K > 6144)
+        if gemv_batch_takes(M, K, g):
+            assert ops.last_kernel() == "gemv_batch" and torch.equal(ya, ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt))
+        else:
+            assert ops.last_kernel() in ("gemv_rows", "gemv_nk"), ops.last_kernel()
     for M in (5, 16, 20, 64):
         e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
         ks = (torch.arange(M, device="cuda") * 977 + K - 5) % K
@@ -1125,7 +1129,9 @@ def test_gemvfast_layout_vs_oracle(ops, oracle, K, N, g, M):
     # AUTO: from five rows at group size 128 the batched kernel (round 5); kernel=1 forces the 16-row kernel (csrc/gemv_fast.hip)
     for flags in (0, ops.gemm_flags(kernel=1, waves=4, unit=8), ops.gemm_flags(kernel=1, waves=16, unit=4)):
         y = ops.gemv_fast_forward(x.cuda(), qw.cuda(), sc.cuda(), qz.cuda(), g, flags=flags)
-        assert ops.last_kernel() == ("gemv_batch_fast" if (flags == 0 and M >= 5 and g == 128 and N % 16 == 0) else "gemv_fast"), ops.last_kernel()
+        # (below five rows AUTO takes the batched kernel where one pass of eight waves covers K: profiles/r05_sweep_small_batch.txt)
+        batch = flags == 0 and (M >= 5 or 2048 < K <= 4096) and g == 128 and N % 16 == 0
+        assert ops.last_kernel() == ("gemv_batch_fast" if batch else "gemv_fast"), ops.last_kernel()
         assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"gemvfast K{K} N{N} g{g} M{M}", wsigma=wsig)
     e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
     ks = (torch.arange(M, device="cuda") * 29 + 11) % K
@@ -1147,15 +1153,19 @@ def test_gemvfast_batch_kernel_vs_oracle(ops, oracle, K, N):
     y32_all, _ = oracle.matmul(xall.numpy(), W)
     wsig_all = oracle.weight_rounding_sigma(xall.numpy(), W)
     bt = ops.gemm_flags(kernel=GEMV_KERNEL_BATCH)
-    for M in ([5, 8, 12, 16, 17, 31, 32, 33, 64, 96] if K * N <= 4096 * 11008 else [5, 16, 32, 64]):
+    for M in ([1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 32, 33, 64, 96] if K * N <= 4096 * 11008 else [1, 4, 5, 16, 32, 64]):
         x = xc[96 - M:]
         y32, wsig = y32_all[96 - M:], wsig_all[96 - M:]
-        for f in ([0, ops.gemm_flags(splitk=1), ops.gemm_flags(splitk=2)] if M in (5, 16, 17, 32) else [0]):
+        for f in ([0, ops.gemm_flags(splitk=1), ops.gemm_flags(splitk=2)] if M in (1, 5, 16, 17, 32) else [0]):
             y = ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)
             assert ops.last_kernel() == "gemv_batch_fast"
             assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"batch-fast K{K} N{N} M{M} f{f:x}", wsigma=wsig)
             assert torch.equal(y, ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)), "not bitwise reproducible"
-        assert torch.equal(ops.gemv_fast_forward(x, qwc, scc, qzc, g), ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt))  # AUTO takes it
+        ya = ops.gemv_fast_forward(x, qwc, scc, qzc, g)
+        if M >= 5 or 2048 < K <= 4096:  # AUTO takes it
+            assert ops.last_kernel() == "gemv_batch_fast" and torch.equal(ya, y)
+        else:
+            assert ops.last_kernel() == "gemv_fast"
     for M in (5, 16, 20):
         e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
         ks = (torch.arange(M, device="cuda") * 977 + K - 5) % K
