@@ -50,8 +50,8 @@ def fuse_llama(hf_model, max_seq_len=2048, decode_layout="auto"):
               the reference itself recommends for batch 1 (README.md:96-97) and the one the row-streaming decode kernel reads
               (bs = 1: 0.50 of the HBM roofline against 0.37 on the GEMM layout).  Checkpoints that already are "gemv" or
               "gemv_fast" are left as they are.  What happened is DECLARED on the result: `.checkpoint_layout`,
-              `.decode_layout`.  A GEMV-layout module serves every batch size from its OWN buffers: up to 4 rows the row-streaming kernel,
-              5 .. 128 rows the batched-decode kernel (csrc/gemv_batch.hip), above that a temporary GEMM-layout transpose of the
+              `.decode_layout`.  A GEMV-layout module serves every batch size from its OWN buffers: up to 2 - 4 rows (by K) the row-streaming kernel,
+              from there to 96 rows the batched-decode kernel (csrc/gemv_batch.hip), above that a temporary GEMM-layout transpose of the
               packed words (csrc/repack.hip, freed after the call) under the fused MFMA GEMM -- no second resident copy;
       "gemv"  repack whatever the checkpoint's layout is;
       None    keep the checkpoint's layout (the reference's ExLlama repack at load time is the same kind of declared option:

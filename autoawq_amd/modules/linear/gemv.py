@@ -9,7 +9,7 @@ Drop-in contract kept (reference awq/modules/linear/gemv.py:27-197):
   * forward (:156-186): any leading dims, any float dtype (computed in fp16, cast back), bias added
     AFTER the cast back, in the input dtype (:183-185).
 What differs by design: the arithmetic runs in libawq_hip.so on the module's own buffers at every batch
-size (csrc/gemv_rows.hip up to 4 rows, csrc/gemv_batch.hip from 5 rows in launches of <= 32 -- gemv_lds.hip / gemv_nk.hip for the
+size (csrc/gemv_rows.hip up to 2 - 4 rows, csrc/gemv_batch.hip from there (5 rows; 4 while K > 2048; 3 while K > 6144) in launches of <= 32 -- gemv_lds.hip / gemv_nk.hip for the
 group sizes it does not take; from PREFILL_MIN_ROWS rows PREFILL_IMPL); there is no CPU path -- a non-HIP tensor raises.
 """
 import torch
