@@ -480,7 +480,8 @@ def fused_topk(gating_output, topk, renormalize):
 
 def gemv_fast_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     """GEMVFast layout (qweight int16 [N/4, K], scales / qzeros fp16 [8*ZW, N]): y [M, N] fp16
-    (awq_gemv_fast_forward), M processed in chunks of <= 16 rows."""
+    (awq_gemv_fast_forward).  AUTO: the batched kernel (csrc/gemv_batch.hip, GEMVFast form) from five rows -- at every batch size while
+    2048 < K <= 4096 -- in one call; otherwise the 16-row kernel (csrc/gemv_fast.hip) in chunks of <= 16 rows."""
     _require_gpu(x2d, qweight, scales, qzeros)
     if x2d.dtype != torch.float16:
         raise _lib.AwqHipError("gemv_fast_forward expects fp16 activations")
