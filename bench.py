@@ -212,7 +212,7 @@ def leg_gemm_bs(dev, ops):
     # the same matrix shape in the WQLinear_GEMV format (awq_gemv_forward: row-streaming kernel to 4 rows, the batched kernel from 5)
     sets = [rand_packed_nk(K, N, GROUP, dev, gen) for _ in range(nsets)]
     out["gemv_layout_by_batch"] = {}
-    for M in (1, 2, 4, 5, 8, 12, 16, 24, 32, 48, 64, 96):  # (round 5: from five rows csrc/gemv_batch.hip, launches of <= 32 rows on the layout's own buffers)
+    for M in (1, 2, 4, 5, 8, 12, 16, 24, 32, 48, 64, 96):  # (round 5: from four rows at this shape csrc/gemv_batch.hip, launches of <= 32 rows on the layout's own buffers)
         x = torch.randn((M, K), device=dev, generator=gen).half()
 
         def fn2():
