@@ -35,7 +35,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); measured-achievable copy is 6290
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0    # measured-achievable copy rate (the same guide's chip table)
 MFMA_PEAK_TF = 2500.0    # dense fp16 / bf16 MFMA (same file); AMD's 5 PF headline includes 2:1 sparsity
 GROUP = 128
 MODELS = {  # hidden, intermediate, layers, heads, kv heads
@@ -773,6 +774,8 @@ def main():
                        "algorithmic_bytes_per_step_all_ranks": bytes_all, "kernel": ops.last_kernel()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         # the fraction of the measured-achievable copy rate beside the fraction of the spec peak
+                         "achievable_copy_gbs": HBM_COPY_GBS, "frac_of_achievable_copy": achieved / HBM_COPY_GBS,
                          # HBM bytes per launch need the TCC fabric counters of a separate rocprofv3 --pmc pass
                          # (MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950): not measurable from inside this process
                          "traffic": traffic, "traffic_note": traffic_note,
