@@ -84,6 +84,8 @@ SIGNATURES = {
     "awq_gemv_fast_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                       c_int64, c_int64, c_uint32, c_void_p]),
     "awq_gemv_fast_lds_bytes_c": (c_size_t, [c_int64, c_int64, c_int64]),
+    "awq_gemv_fast_prefill": (c_int, [c_void_p] * 6 + [c_int64] * 5 + [c_uint32, c_void_p]),
+    "awq_repack_gemvfast_to_gemm": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "awq_dequantize_weights_gemv_fast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                                  c_void_p]),
     "awq_gemm_workspace_status": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_int32)]),

@@ -6,7 +6,7 @@ before importing `awq` makes the unmodified reference WQLinear_GEMVFast run on t
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 from .utils.packing import calculate_zeros_width
 
 
@@ -37,9 +37,13 @@ def gemm_forward_cuda_prefill(x, qweight, scales, qzeros):
     K, N = x.shape[-1], qweight.shape[0] * 4
     x2 = x.reshape(-1, K)
     g = infer_group_size(K, scales.shape[0])
-    if x2.shape[0] <= 64 and N % 16 == 0:
-        out = ops.gemv_fast_forward(x2, qweight, scales, qzeros, g)
-    else:  # prefill: dequantise this layout's own buffers into a temporary + a dense fp16 GEMM (the reference's two-pass route;
-        # the same w * s + qzeros weights the decode kernel uses -- no repack, nothing cached: ADVICE r03)
+    if (x2.shape[0] <= 64 or (x2.shape[0] <= 96 and g == 128 and K % 128 == 0)) and N % 16 == 0:
+        return ops.gemv_fast_forward(x2, qweight, scales, qzeros, g).reshape(x.shape[:-1] + (N,))
+    try:  # prefill: the words transposed into a temporary + the fused MFMA GEMM with this layout's arithmetic (two hand-written launches)
+        out = ops.gemv_fast_prefill(x2.half(), qweight, scales, qzeros, g)
+    except _lib.AwqHipError as e:
+        if e.code != _lib.ERR_UNSUPPORTED:
+            raise
+        # shapes the fused kernel refuses (K % 64, group sizes below 64, N % 8): dequantise into a temporary + a dense fp16 GEMM
         out = torch.matmul(x2.half(), ops.dequantize_weights_gemv_fast(qweight, scales, qzeros, g).t())
     return out.reshape(x.shape[:-1] + (N,))

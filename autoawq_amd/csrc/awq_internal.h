@@ -119,6 +119,9 @@ int awq_launch_gemv_batch_fast(const uint16_t* x, const int16_t* qweight, const 
 bool awq_gemm_regb_nk_supports(int M, int K, int N, int g, int ZW);
 int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                             const uint16_t* bias, uint16_t* y, int M, int K, int N, int g, int ZW, int bm, hipStream_t st);
+// GEMM-layout words + the GEMVFast format's scales / fp16 zero terms [>= K/g, N] (gemm_regb.hip, FZ form: W = fp16(w s + qzeros))
+int awq_launch_gemm_regb_fz(const uint16_t* x, const int32_t* qweight_kn, const uint16_t* scales, const uint16_t* qzeros_f16, uint16_t* y,
+                            int M, int K, int N, int g, int bm, hipStream_t st);
 // MoE prefill: the same kernel over a token list sorted by expert (device-side row offsets), GEMM-layout expert stacks
 int awq_launch_gemm_regb_grouped(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                                  uint16_t* y, const int32_t* seg, int P, int E, int K, int N, int g, int bm, hipStream_t st);

@@ -517,6 +517,26 @@ int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint1
                                 static_cast<hipStream_t>(stream));
 }
 
+// Prefill-sized batches on the GEMVFast layout: the packed words are transposed into the caller's temporary (repack.hip), then the
+// register-decoded MFMA GEMM runs on it with the format's own scales / fp16 zero terms (gemm_regb.hip, FZ form).  Two launches.
+int awq_gemv_fast_prefill(const uint16_t* x, const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros, uint16_t* y,
+                          int32_t* qweight_tmp, int64_t M, int64_t K, int64_t N, int64_t group_size, int64_t group_rows, uint32_t flags,
+                          void* stream) {
+    if (K <= 0 || N < 0 || group_size <= 0 || K % group_size || N % 4 || K % 64) return AWQ_ERR_BAD_SHAPE;
+    if (group_rows < K / group_size) return AWQ_ERR_BAD_SHAPE;
+    if (M < 0 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    if (M == 0 || N == 0) return AWQ_OK;
+    if (!x || !qweight || !scales || !qzeros || !y || !qweight_tmp) return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales) || !aligned16(qzeros) || !aligned16(y) || !aligned16(qweight_tmp))
+        return AWQ_ERR_BAD_ALIGNMENT;
+    if (N % 8 || !awq_gemm_regb_supports((int)M, (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
+    int rc = awq_repack_gemvfast_to_gemm(qweight, qweight_tmp, K, N, stream);
+    if (rc != AWQ_OK) return rc;
+    g_last_kernel = "repack_fast+gemm_regb_fz";
+    return awq_launch_gemm_regb_fz(x, qweight_tmp, scales, qzeros, y, (int)M, (int)K, (int)N, (int)group_size,
+                                   AWQ_GEMM_FLAG_NLOG(flags) == 2 ? 256 : 0, static_cast<hipStream_t>(stream));
+}
+
 size_t awq_gemv_fast_lds_bytes_c(int64_t M, int64_t K, int64_t group_size) {
     return awq_gemv_fast_lds_bytes((int)M, (int)K, (int)group_size, 8);
 }

@@ -79,8 +79,13 @@ constexpr int PM = 8, PN = 4;  // tile patch per XCD round
 // once, 2 = activations fetched once, 4 = no barrier, 8 = no decode arithmetic, 16 = every output row stored into rows 0..127 (stores issued, nothing reaches HBM)
 // GROUPED: the M tiles are dealt over the experts of a sorted token list (device-side row offsets `seg`): virtual tile `mt` walks
 // expert 0's ceil(rows / BM) tiles, then expert 1's, ...; a block past the last expert's tiles exits.
-template <int WGM, int DBG = 0, bool NK = false, bool GROUPED = false>  // waves along M: BM = 128 * WGM; NK: the GEMV layout's buffers (header)
+// FZ (round 6, GEMM-layout words only): the GEMVFast format's arithmetic -- `qzeros` is the fp16 tensor -(s z) [K/g, N] of
+// awq/modules/linear/gemv_fast.py:175-181 (same orientation as `scales`) and a weight is fp16(w s + qzeros), ONE packed fma per
+// register pair instead of subtract + multiply.  The words come from awq_repack_gemvfast_to_gemm (repack.hip): the prefill route
+// of WQLinear_GEMVFast (gemv_fast.py:203-206 runs awq_v2_ext.gemm_forward_cuda_prefill there).
+template <int WGM, int DBG = 0, bool NK = false, bool GROUPED = false, bool FZ = false>  // waves along M: BM = 128 * WGM; NK: the GEMV layout's buffers (header)
 __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams p) {
+    static_assert(!FZ || (!NK && !GROUPED), "the GEMVFast arithmetic exists for the plain GEMM-layout form");
     constexpr int BM = 128 * WGM;
     constexpr int A_BUF = BM * BK * 2;            // bytes of one activation K step
     constexpr int PIECES = BM * 8 / 64 / (4 * WGM);  // 1 KiB DMA pieces per wave per K step (= 4)
@@ -149,6 +154,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         uint32_t w[2][8];
         uint32_t z;
         u32x2 s;
+        u32x2 zf;  // FZ: the four columns' fp16 zero terms -(s z)
     };
     struct BRegsNK {
         u32x2 w[4];      // column c: words 2 kb (K sub-step 0) and 2 kb + 1 (sub-step 1) of this step
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
     };
     const u32x4 wsrd = srd(p.qweight, NK ? (uint32_t)p.N * (uint32_t)p.KW * 4u : (uint32_t)p.K * row_bytes);
-    const u32x4 zsrd = srd(p.qzeros, NK ? (uint32_t)p.N * (uint32_t)p.ZW * 4u : (uint32_t)(p.K / p.g) * row_bytes);
+    const u32x4 zsrd = srd(p.qzeros, NK ? (uint32_t)p.N * (uint32_t)p.ZW * 4u : (FZ ? (uint32_t)(p.K / p.g) * (uint32_t)p.N * 2u : (uint32_t)(p.K / p.g) * row_bytes));
     const u32x4 ssrd = srd(p.scales, NK ? (uint32_t)p.N * (uint32_t)p.SW * 2u : (uint32_t)(p.K / p.g) * (uint32_t)p.N * 2u);
     const u32x4 xsrd = srd(p.x, (uint32_t)((int64_t)p.M * p.K * 2));
 // Eight weight words / the group's zero word and scales in ONE asm statement each, opened by s_nop 4: an SGPR written by
@@ -180,6 +186,10 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %5, %6, %7 offen"                        \
                  : "=&v"(Z), "=&v"(S2)                                                                                        \
                  : "v"(zvoff), "s"(zrs), "s"(zso), "v"(svoff), "s"(srs), "s"(sso))
+#define AWQ_BLOADZFS(Z2, S2, zrs, svoff, srs, sso)                                                                            \
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %2, %3, %5 offen\n\tbuffer_load_dwordx2 %1, %2, %4, %5 offen"                       \
+                 : "=&v"(Z2), "=&v"(S2)                                                                                       \
+                 : "v"(svoff), "s"(zrs), "s"(srs), "s"(sso))
 #define AWQ_BLOAD1(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff))
 #define AWQ_BLOAD2(dst, voff, rs, soff) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff))
 // NK form: four dwordx2 weight loads, then four zero words and four scales, each group behind one s_nop 4 (same hazard)
@@ -220,7 +230,11 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         }
         const uint32_t grp = __umulhi(k0, g_magic);
         const uint32_t zo = grp * row_bytes, so2 = grp * (uint32_t)p.N * 2u;
-        AWQ_BLOADZS(R.z, R.s, z_voff, zsrd, zo, s_voff, ssrd, so2);
+        if constexpr (FZ) {
+            AWQ_BLOADZFS(R.zf, R.s, zsrd, s_voff, ssrd, so2);  // zero terms and scales: the same offsets in two tensors
+        } else {
+            AWQ_BLOADZS(R.z, R.s, z_voff, zsrd, zo, s_voff, ssrd, so2);
+        }
         }
     };
     // everything up to and including R's requests has returned once at most NEWER later operations are outstanding
@@ -230,6 +244,12 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
             asm volatile("s_waitcnt vmcnt(%12)"
                          : "+v"(R.w[0]), "+v"(R.w[1]), "+v"(R.w[2]), "+v"(R.w[3]), "+v"(R.z[0]), "+v"(R.z[1]), "+v"(R.z[2]), "+v"(R.z[3]),
                            "+v"(R.s[0]), "+v"(R.s[1]), "+v"(R.s[2]), "+v"(R.s[3])
+                         : "n"(NEWER));
+        } else if constexpr (FZ) {
+            asm volatile("s_waitcnt vmcnt(%18)"
+                         : "+v"(R.w[0][0]), "+v"(R.w[0][1]), "+v"(R.w[0][2]), "+v"(R.w[0][3]), "+v"(R.w[0][4]), "+v"(R.w[0][5]),
+                           "+v"(R.w[0][6]), "+v"(R.w[0][7]), "+v"(R.w[1][0]), "+v"(R.w[1][1]), "+v"(R.w[1][2]), "+v"(R.w[1][3]),
+                           "+v"(R.w[1][4]), "+v"(R.w[1][5]), "+v"(R.w[1][6]), "+v"(R.w[1][7]), "+v"(R.zf), "+v"(R.s)
                          : "n"(NEWER));
         } else {
             asm volatile("s_waitcnt vmcnt(%18)"
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
 #define AWQ_LDS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(dst) : "v"(addr))
 
     auto compute = [&](BRegs& R, int buf, auto&& issue_next) {
-        half2_t zm[4], sd[4];
+        half2_t zm[4], sd[4], zd[4];
         issue_next();  // next step's requests first (their round trip is the longest thing in the step), then wait for R
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -312,6 +332,19 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
                         sd[c] = u2h2(__builtin_amdgcn_perm(R.s[c], R.s[c], 0x01000100u));  // (s, s)
                     }
                 }
+            } else if (FZ && kk == 0) {
+                // GEMVFast arithmetic: zm = the exponent biases of the two nibble positions, zd = the columns' zero terms -(s z)
+                zm[0] = zm[1] = u2h2(0x64006400u);
+                zm[2] = zm[3] = u2h2(0x54005400u);
+                const half2_t s01 = u2h2(R.s[0]), s23 = u2h2(R.s[1]), z01 = u2h2(R.zf[0]), z23 = u2h2(R.zf[1]);
+                sd[0] = __builtin_shufflevector(s01, s01, 0, 0);
+                sd[1] = __builtin_shufflevector(s01, s01, 1, 1);
+                sd[2] = __builtin_shufflevector(s23, s23, 0, 0);
+                sd[3] = __builtin_shufflevector(s23, s23, 1, 1);
+                zd[0] = __builtin_shufflevector(z01, z01, 0, 0);
+                zd[1] = __builtin_shufflevector(z01, z01, 1, 1);
+                zd[2] = __builtin_shufflevector(z23, z23, 0, 0);
+                zd[3] = __builtin_shufflevector(z23, z23, 1, 1);
             } else if (kk == 0) {
                 // zero points and scales of this step's group, duplicated into both halves: columns 4 ph + {0, 1, 2, 3}
                 //   c = 0: byte ph low nibble, c = 1: byte ph+2 low, c = 2: byte ph high, c = 3: byte ph+2 high
@@ -349,6 +382,13 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
                 const uint32_t p1 = __builtin_amdgcn_perm(R.w[kk][2 * rp + 1], R.w[kk][2 * rp], sel1);
                 if constexpr (DBG & 8) {
                     bf[0][rp] = p0; bf[1][rp] = p1; bf[2][rp] = p0 ^ h22u(zm[0]); bf[3][rp] = p1 ^ h22u(sd[0]);
+                    continue;
+                }
+                if constexpr (FZ) {  // w exact (the subtract), then ONE rounding of w s + qzeros: == fp16 of the fp32 fma (w s is exact there)
+                    bf[0][rp] = h22u(__builtin_elementwise_fma(u2h2(and_or(p0, 0x000F000Fu, 0x64006400u)) - zm[0], sd[0], zd[0]));
+                    bf[1][rp] = h22u(__builtin_elementwise_fma(u2h2(and_or(p1, 0x000F000Fu, 0x64006400u)) - zm[1], sd[1], zd[1]));
+                    bf[2][rp] = h22u(__builtin_elementwise_fma(u2h2(and_or(p0, 0x00F000F0u, 0x54005400u)) - zm[2], sd[2], zd[2]));
+                    bf[3][rp] = h22u(__builtin_elementwise_fma(u2h2(and_or(p1, 0x00F000F0u, 0x54005400u)) - zm[3], sd[3], zd[3]));
                     continue;
                 }
                 bf[0][rp] = h22u((u2h2(and_or(p0, 0x000F000Fu, 0x64006400u)) - zm[0]) * sd[0]);
@@ -501,6 +541,39 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
         hipLaunchKernelGGL((awq_gemm_regb_kernel<2>), dim3(grid), dim3(512), lds, a.stream, p);
     } else {
         hipLaunchKernelGGL((awq_gemm_regb_kernel<1>), dim3(grid), dim3(256), lds, a.stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
+
+// ---- the FZ form: GEMM-layout words (a repacked temporary) with the GEMVFast format's scales / fp16 zero terms [>= K/g, N]
+int awq_launch_gemm_regb_fz(const uint16_t* x, const int32_t* qweight_kn, const uint16_t* scales, const uint16_t* qzeros_f16, uint16_t* y,
+                            int M, int K, int N, int g, int bm, hipStream_t st) {
+    if (!awq_gemm_regb_supports(M, K, N, g)) return AWQ_ERR_UNSUPPORTED;
+    if (bm == 0) bm = 128;
+    if (bm != 128 && bm != 256) return AWQ_ERR_UNSUPPORTED;
+    RegbParams p;
+    p.qweight = reinterpret_cast<const uint32_t*>(qweight_kn);
+    p.qzeros = reinterpret_cast<const uint32_t*>(qzeros_f16);
+    p.scales = reinterpret_cast<const half_t*>(scales);
+    p.x = reinterpret_cast<const half_t*>(x);
+    p.bias = nullptr;
+    p.y = reinterpret_cast<half_t*>(y);
+    p.M = M; p.K = K; p.N = N; p.g = g;
+    p.KW = p.ZW = p.SW = 0;
+    p.seg = nullptr; p.E = 0; p.w_stride = p.z_stride = p.s_stride = 0;
+    p.tiles_m = (M + bm - 1) / bm;
+    p.tiles_n = (N + BN - 1) / BN;
+    p.pm = PM; p.pn = PN;
+    p.mp = (p.tiles_m + p.pm - 1) / p.pm;
+    p.patches = p.mp * ((p.tiles_n + p.pn - 1) / p.pn);
+    const int grid = ((p.patches + 7) / 8) * 8 * (p.pm * p.pn);
+    const size_t lds = (size_t)NBUF * bm * BK * 2;
+    if (bm == 256) {
+        static std::atomic<unsigned long long> opted{0};
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 0, false, false, true>), opted)) return AWQ_ERR_LAUNCH;
+        hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 0, false, false, true>), dim3(grid), dim3(512), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((awq_gemm_regb_kernel<1, 0, false, false, true>), dim3(grid), dim3(256), lds, st, p);
     }
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

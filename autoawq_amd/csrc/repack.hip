@@ -87,7 +87,72 @@ __global__ __launch_bounds__(512) void awq_repack_nk_kernel(RepackParams p) {
     }
 }
 
+// ---- GEMVFast words -> GEMM-layout words (round 6): the prefill route of WQLinear_GEMVFast (awq/modules/linear/gemv_fast.py:203-206
+// runs awq_v2_ext.gemm_forward_cuda_prefill on this layout).  in: qweight int16 [N/4, K], element [r, 64 b + 16 i + 8 h + t] nibble j =
+// w[4 r + i, 64 b + 32 h + 8 j + t] (gemv_fast.py:26-65); out: qweight int32 [K, N/8] in the AWQ nibble order.  The
+// format's scales and fp16 zero terms are [>= K/g, N] already: gemm_regb's FZ form reads them as they are.  Pure nibble moves.
+// Tile = 256 output columns (64 int16 rows) x 256 k (512-byte read runs, 128-byte write runs) through LDS.
+constexpr int FT_R = 64, FT_K = 256, FT_PITCH = FT_K + 8;  // int16 elements; 33 KB
+
+struct RepackFastParams {
+    const uint16_t* qw_in;
+    uint32_t* qw_out;
+    int K, N, NW, R4;  // NW = N / 8 words per output row, R4 = N / 4 input rows
+    int nt, kt;
+};
+
+__global__ __launch_bounds__(512) void awq_repack_fast_kernel(RepackFastParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t tile[FT_R * FT_PITCH];
+    const int tid = threadIdx.x;
+    const int tn = blockIdx.x % p.nt, tk = blockIdx.x / p.nt;
+    const int r0 = tn * FT_R, k0 = tk * FT_K;
+    // ---- in: 64 rows x 256 int16 = 64 x 32 chunks of 16 bytes; 32 consecutive threads read one row's 512 bytes
+#pragma unroll
+    for (int i = 0; i < FT_R * (FT_K / 8) / 512; ++i) {
+        const int e = i * 512 + tid, r = e >> 5, ch = e & 31;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < p.R4 && k0 + 8 * ch < p.K) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.qw_in + (size_t)(r0 + r) * p.K + k0 + 8 * ch));
+        *reinterpret_cast<u32x4*>(&tile[r * FT_PITCH + 8 * ch]) = v;
+    }
+    __syncthreads();
+    // ---- out: item (b, h, t, c): the eight int16 elements (rows 2c, 2c + 1; i = 0..3) at 64 b + 16 i + 8 h + t hold, in nibble j, the
+    // weights of columns 8c .. 8c + 7 at k = 64 b + 32 h + 8 j + t -> four output words (j = 0..3), word column c
+#pragma unroll
+    for (int it = 0; it < (FT_K / 64) * 2 * 8 * (FT_R / 2) / 512; ++it) {
+        const int e = it * 512 + tid, c = e & 31, rest = e >> 5, t = rest & 7, h = (rest >> 3) & 1, b = rest >> 4;
+        uint32_t in[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) in[q] = tile[(2 * c + (q >> 2)) * FT_PITCH + 64 * b + 16 * (q & 3) + 8 * h + t];
+        const int cw = (r0 >> 1) + c;
+        if (cw < p.NW) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 64 * b + 32 * h + 8 * j + t;
+                // nibble i of the output word = column 8c + ORDER[i], ORDER = 0,2,4,6,1,3,5,7
+                const uint32_t o = ((in[0] >> (4 * j)) & 15u) | (((in[2] >> (4 * j)) & 15u) << 4) | (((in[4] >> (4 * j)) & 15u) << 8) |
+                                   (((in[6] >> (4 * j)) & 15u) << 12) | (((in[1] >> (4 * j)) & 15u) << 16) | (((in[3] >> (4 * j)) & 15u) << 20) |
+                                   (((in[5] >> (4 * j)) & 15u) << 24) | (((in[7] >> (4 * j)) & 15u) << 28);
+                if (k < p.K) p.qw_out[(size_t)k * p.NW + cw] = o;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+int awq_repack_gemvfast_to_gemm(const int16_t* qweight, int32_t* qweight_out, int64_t K, int64_t N, void* stream) {
+    if (K <= 0 || N <= 0 || K % 64 || N % 8 || K > INT32_MAX || N > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
+    if (!qweight || !qweight_out) return AWQ_ERR_NULL;
+    if (((uintptr_t)qweight & 15) || ((uintptr_t)qweight_out & 3)) return AWQ_ERR_BAD_ALIGNMENT;
+    RepackFastParams p;
+    p.qw_in = reinterpret_cast<const uint16_t*>(qweight);
+    p.qw_out = reinterpret_cast<uint32_t*>(qweight_out);
+    p.K = (int)K; p.N = (int)N; p.NW = (int)(N / 8); p.R4 = (int)(N / 4);
+    p.nt = (p.R4 + FT_R - 1) / FT_R;
+    p.kt = (p.K + FT_K - 1) / FT_K;
+    hipLaunchKernelGGL(awq_repack_fast_kernel, dim3((unsigned)(p.nt * p.kt)), dim3(512), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}
 
 int awq_repack_gemv_to_gemm(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, int32_t* qweight_out, uint16_t* scales_out,
                             int32_t* qzeros_out, int64_t K, int64_t N, int64_t group_size, int64_t zeros_width, void* stream) {

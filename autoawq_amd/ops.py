@@ -516,6 +516,41 @@ def gemv_fast_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     return y
 
 
+def gemv_fast_prefill(x2d, qweight, scales, qzeros, group_size, flags=0):
+    """GEMVFast layout, prefill-sized token counts: y [M, N] = x @ W^T, W = fp16(w * s + qzeros), by TWO hand-written launches
+    (awq_gemv_fast_prefill: the packed words transposed into a temporary of the call, then the register-decoded MFMA GEMM with this
+    format's scales / fp16 zero terms) -- the role of awq_v2_ext.gemm_forward_cuda_prefill (awq/modules/linear/gemv_fast.py:203-206).
+    Raises AwqHipError with code ERR_UNSUPPORTED for shapes the fused kernel does not take (K % 64, group_size % 64, N % 8)."""
+    _require_gpu(x2d, qweight, scales, qzeros)
+    if x2d.dtype != torch.float16:
+        raise _lib.AwqHipError("gemv_fast_prefill expects fp16 activations")
+    x2d, qweight, scales, qzeros = x2d.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    M, K = x2d.shape
+    N, GP = qweight.shape[0] * 4, scales.shape[0]
+    if qweight.shape[1] != K or scales.shape != (GP, N) or qzeros.shape != (GP, N):
+        raise _lib.AwqHipError(f"gemv_fast_prefill: shape mismatch x{tuple(x2d.shape)} qweight{tuple(qweight.shape)} scales{tuple(scales.shape)}")
+    y = torch.empty((M, N), dtype=torch.float16, device=x2d.device)
+    if M == 0:
+        return y
+    tmp = torch.empty((K, max(N // 8, 1)), dtype=torch.int32, device=x2d.device)  # GEMM-layout words of the same integers: a temporary of the call
+    with torch.cuda.device(x2d.device):
+        rc = _lib.lib().awq_gemv_fast_prefill(_ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), _ptr(tmp), M, K, N, group_size, GP,
+                                              flags, _stream())
+    _lib.check(rc, "awq_gemv_fast_prefill")
+    return y
+
+
+def repack_gemvfast_to_gemm(qweight):
+    """GEMVFast words int16 [N/4, K] -> GEMM-layout words int32 [K, N/8] (awq_repack_gemvfast_to_gemm), bit-exact"""
+    _require_gpu(qweight)
+    qweight = qweight.contiguous()
+    N, K = qweight.shape[0] * 4, qweight.shape[1]
+    out = torch.empty((K, N // 8), dtype=torch.int32, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        _lib.check(_lib.lib().awq_repack_gemvfast_to_gemm(_ptr(qweight), _ptr(out), K, N, _stream()), "awq_repack_gemvfast_to_gemm")
+    return out
+
+
 def dequantize_weights_gemv_fast(qweight, scales, qzeros, group_size):
     """GEMVFast-layout buffers -> fp16 W^T [N, K] (awq_dequantize_weights_gemv_fast)."""
     _require_gpu(qweight, scales, qzeros)

@@ -233,6 +233,16 @@ AWQ_EXPORT int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, 
                                      const uint16_t* qzeros, uint16_t* y, int64_t M, int64_t K, int64_t N,
                                      int64_t group_size, int64_t group_rows, uint32_t flags, void* stream);
 AWQ_EXPORT size_t awq_gemv_fast_lds_bytes_c(int64_t M, int64_t K, int64_t group_size);
+/* Replaces awq_v2_ext.gemm_forward_cuda_prefill(x, qweight, scales, qzeros) for prefill-sized token counts
+ * (awq/modules/linear/gemv_fast.py:203-206): y [M, N] = x [M, K] @ W^T, W = fp16(w*s + qzeros).  Two hand-written launches, no
+ * vendor GEMM: awq_repack_gemvfast_to_gemm transposes the packed words into `qweight_tmp` (caller-owned, K*N/2 bytes, 16-byte
+ * aligned, a temporary of the call), then the register-decoded MFMA GEMM (gemm_regb.hip) runs on it with this format's own scales
+ * and fp16 zero terms.  K % 64 == 0, group_size % 64 == 0, N % 8 == 0; flags: AWQ_GEMM_FLAG_NLOG = 2 -> 256-row tiles. */
+AWQ_EXPORT int awq_gemv_fast_prefill(const uint16_t* x, const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros,
+                                     uint16_t* y, int32_t* qweight_tmp, int64_t M, int64_t K, int64_t N, int64_t group_size,
+                                     int64_t group_rows, uint32_t flags, void* stream);
+/* GEMVFast words int16 [N/4, K] -> GEMM-layout words int32 [K, N/8] (AWQ nibble order) of the same integers; bit-exact. */
+AWQ_EXPORT int awq_repack_gemvfast_to_gemm(const int16_t* qweight, int32_t* qweight_out, int64_t K, int64_t N, void* stream);
 /* out [N, K] fp16 = dequantised W^T (W = fp16 of the fp32 fma w*s + qzeros). */
 AWQ_EXPORT int awq_dequantize_weights_gemv_fast(const int16_t* qweight, const uint16_t* scales,
                                                 const uint16_t* qzeros, uint16_t* out, int64_t K, int64_t N,

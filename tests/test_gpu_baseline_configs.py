@@ -93,6 +93,76 @@ def test_regb_prefill_kernel_directly_at_config3_shape(ops, oracle, K, N, bm):
     assert torch.equal(y, ops.gemm_forward(dx, dq, ds, dz, db, flags=ops.gemm_flags(ops.KERNEL_REGB, nlog=bm))), "not reproducible"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,N,M", [(4096, 11008, 16384), (11008, 4096, 2048), (4096, 12288, 130), (4096, 4096, 97), (1024, 200, 300),
+                                   (512, 64, 70), (3584, 8192, 257), (8192, 1280, 128)])
+@pytest.mark.parametrize("bm", [1, 2])
+def test_gemvfast_layout_prefill_route_vs_oracle(ops, oracle, K, N, M, bm):
+    """Round 6: the prefill route of WQLinear_GEMVFast (the reference runs awq_v2_ext.gemm_forward_cuda_prefill there,
+    awq/modules/linear/gemv_fast.py:203-206) as TWO hand-written launches -- csrc/repack.hip (GEMVFast words -> GEMM-layout words,
+    bit-exact against utils/convert.py's torch unpack) + csrc/gemm_regb.hip in its FZ form (W = fp16(w s + qzeros), this format's own
+    scales / fp16 zero terms).  BASELINE configs[2]'s shape at M = 16384, the transposed shape, ragged M / N, 70B shard shapes: sampled
+    rows against the CPU oracle (oracle.dequant_gemvfast: unpinned in the reference itself -- the arithmetic lives in autoawq-kernels),
+    every output against the fp32 product of the bit-exact dequantised weights, one-hot rows return rows of W bit for bit, bitwise
+    reproducible; the module and the awq_v2_ext shim take this route by default and no torch.matmul is reached."""
+    from test_gpu_parity import gemvfast_case
+    from autoawq_amd.utils.convert import _unpack_fast, _unpack_rows
+
+    g = 128
+    qw, sc, qz, _ = gemvfast_case(K, N, g, 1, seed=K + 7 * N + M)
+    gen = torch.Generator().manual_seed(K + M + bm)
+    x = torch.randn((M, K), generator=gen).half()
+    dq, ds, dz, dx = qw.cuda(), sc.cuda(), qz.cuda(), x.cuda()
+    # the repack alone: the integers of the GEMM-layout words == the integers of the GEMVFast words, transposed
+    kn = ops.repack_gemvfast_to_gemm(dq)
+    assert kn.shape == (K, N // 8) and kn.dtype == torch.int32
+    assert torch.equal(_unpack_rows(kn.cpu(), [0, 2, 4, 6, 1, 3, 5, 7]), _unpack_fast(qw).t().contiguous()), "repack is not bit-exact"
+    fl = ops.gemm_flags(nlog=bm)
+    y = ops.gemv_fast_prefill(dx, dq, ds, dz, g, flags=fl)
+    assert ops.last_kernel() == "repack_fast+gemm_regb_fz" and y.shape == (M, N)
+    W = oracle.dequant_gemvfast(qw.numpy(), sc.numpy(), qz.numpy(), g)  # [K, N] fp16
+    rows = torch.randperm(M, generator=gen)[:min(M, 96)].sort().values
+    rows[0], rows[-1] = 0, M - 1
+    y32, _ = oracle.matmul(x[rows].numpy(), W)
+    assert_product_close(y[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"gemvfast prefill bm{bm} {K}x{N} M{M}")
+    Wt = ops.dequantize_weights_gemv_fast(dq, ds, dz, g)
+    assert np.array_equal(Wt.cpu().numpy().view(np.uint16), np.ascontiguousarray(W.T).view(np.uint16))
+    Wf = Wt.float().t().contiguous()
+    for m0 in range(0, M, 2048):
+        ref = dx[m0:m0 + 2048].float() @ Wf
+        err = (y[m0:m0 + 2048].float() - ref).abs()
+        tol = 2e-3 * ref.abs() + 2e-3 * ref.abs().mean()
+        assert bool((err <= tol).all()), (K, N, bm, m0, float(err.max()))
+    assert torch.equal(y, ops.gemv_fast_prefill(dx, dq, ds, dz, g, flags=fl)), "not reproducible"
+    rowsel = min(M, 256)
+    e = torch.zeros((rowsel, K), dtype=torch.float16, device="cuda")
+    ks = (torch.arange(rowsel, device="cuda") * 61 + 17) % K
+    e[torch.arange(rowsel, device="cuda"), ks] = 1.0
+    assert torch.equal(ops.gemv_fast_prefill(e, dq, ds, dz, g, flags=fl), Wt.t()[ks]), "one-hot rows must select rows of W"
+    if bm == 1 and M <= 4096 and N % 16 == 0:
+        import autoawq_amd.modules.linear.gemv as gemv_mod
+        from autoawq_amd import WQLinear_GEMVFast, awq_v2_ext
+
+        mod = WQLinear_GEMVFast(4, g, K, N, False, "cuda")
+        mod.qweight, mod.qzeros, mod.scales = dq, dz, ds
+        assert mod.PREFILL_IMPL == "fused"
+        called = []
+        orig = gemv_mod.dequant_matmul_nk
+        import autoawq_amd.modules.linear.gemv_fast as fast_mod
+        fast_mod.dequant_matmul_nk = lambda *a, **k: (called.append(1), orig(*a, **k))[1]
+        try:
+            ym = mod(dx.view(1, M, K))[0]
+        finally:
+            fast_mod.dequant_matmul_nk = orig
+        assert not called, "the default prefill route of WQLinear_GEMVFast reached the dequantise + vendor GEMM route"
+        assert torch.equal(ym, ops.gemv_fast_prefill(dx, dq, ds, dz, g)) or ops.last_kernel() in ("gemv_batch_fast", "repack_fast+gemm_regb_fz")
+        assert_product_close(ym[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module default {K}x{N} M{M}")
+        ys = awq_v2_ext.gemm_forward_cuda_prefill(dx.view(1, M, K), dq, ds, dz)[0]
+        assert_product_close(ys[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"awq_v2_ext shim {K}x{N} M{M}")
+        mod.PREFILL_IMPL = "two_pass"
+        assert_product_close(mod(dx.view(1, M, K))[0][rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module two_pass {K}x{N} M{M}")
+
+
 @pytest.mark.parametrize("K,N,M", [(4096, 11008, 16384), (11008, 4096, 4096), (4096, 4096, 17), (4096, 12288, 130), (1024, 200, 300),
                                    (512, 64, 70), (3584, 8192, 257), (8192, 1280, 64)])
 @pytest.mark.parametrize("bm", [1, 2])
