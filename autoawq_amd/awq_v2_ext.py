@@ -39,11 +39,15 @@ def gemm_forward_cuda_prefill(x, qweight, scales, qzeros):
     g = infer_group_size(K, scales.shape[0])
     if (x2.shape[0] <= 64 or (x2.shape[0] <= 96 and g == 128 and K % 128 == 0)) and N % 16 == 0:
         return ops.gemv_fast_forward(x2, qweight, scales, qzeros, g).reshape(x.shape[:-1] + (N,))
-    try:  # prefill: the words transposed into a temporary + the fused MFMA GEMM with this layout's arithmetic (two hand-written launches)
-        out = ops.gemv_fast_prefill(x2.half(), qweight, scales, qzeros, g)
-    except _lib.AwqHipError as e:
-        if e.code != _lib.ERR_UNSUPPORTED:
-            raise
-        # shapes the fused kernel refuses (K % 64, group sizes below 64, N % 8): dequantise into a temporary + a dense fp16 GEMM
+    from .modules.linear.gemv import prefill_route
+
+    out = None
+    if prefill_route(x2.shape[0], K, N) == "hand":
+        try:  # the words transposed into a temporary + the fused MFMA GEMM with this layout's arithmetic (two hand-written launches)
+            out = ops.gemv_fast_prefill(x2.half(), qweight, scales, qzeros, g)
+        except _lib.AwqHipError as e:  # shapes the fused kernel refuses (K % 64, group sizes below 64, N % 8)
+            if e.code != _lib.ERR_UNSUPPORTED:
+                raise
+    if out is None:  # dequantise into a temporary + a dense fp16 GEMM (the reference's two-pass route, gemm.py:48-54)
         out = torch.matmul(x2.half(), ops.dequantize_weights_gemv_fast(qweight, scales, qzeros, g).t())
     return out.reshape(x.shape[:-1] + (N,))

@@ -39,8 +39,25 @@ def dequant_matmul_nk(x2d, wt):
 PREFILL_MIN_ROWS = 97
 
 
+def prefill_min_rows(in_features):
+    """Rows from which a call leaves the batched-decode kernel (launches of <= 32 rows): 97 while one pass of a block covers K
+    (K <= 4096: three launches still beat every prefill route at 4096 x 11008), 65 beyond (several passes per launch: at 11008 x 4096
+    96 rows cost ~65 us against ~55 for the prefill routes -- profiles/r06_prefill_routes.txt)."""
+    return PREFILL_MIN_ROWS if in_features <= 4096 else 65
+
+
+def prefill_route(rows, in_features, out_features):
+    """The "auto" prefill route, by measurement on MI355X (profiles/r06_prefill_routes.txt; ADVICE r05: the hand-written route as an
+    unconditional default cost up to 47 % at the down-projection shape): the hand-written pair (packed words transposed into a
+    temporary + the fused MFMA GEMM) where it is ahead of or within ~10 % of dequantise + dense fp16 GEMM -- from 3072 rows on
+    matrices at least as wide as they are tall (4096 x 11008: 379 vs 435 us at 4096 rows, 1325 vs 1201 at 16384) -- and the
+    reference's own two-pass route (awq/modules/linear/gemm.py:48-54) elsewhere (fewer rows: the fused kernel's K walk is latency-
+    bound, 104 us at 128 ... 512 rows against 51 ... 72; tall matrices: the vendor's GEMM runs at 0.60 of the MFMA peak there)."""
+    return "hand" if rows >= 3072 and out_features >= in_features else "two_pass"
+
+
 class WQLinear_GEMV(nn.Module):
-    PREFILL_IMPL = "repack"  # | "two_pass" | "fused" (see forward)
+    PREFILL_IMPL = "auto"  # | "repack" | "two_pass" | "fused" (see forward)
 
     def __init__(self, w_bit, group_size, in_features, out_features, bias, dev):
         super().__init__()
@@ -91,7 +108,8 @@ class WQLinear_GEMV(nn.Module):
             inputs = inputs.half()
         # Every batch size on this layout's OWN buffers (round 4: the second, GEMM-layout copy of every matrix that rounds 2-3
         # kept resident for prefill is gone).  Below PREFILL_MIN_ROWS rows: the decode / batched-decode kernels.  From there: PREFILL_IMPL --
-        #   "repack" (default, round 5)  transpose the packed nibbles into a TEMPORARY of the call (csrc/repack.hip, K N / 2 bytes) and run
+        #   "auto" (default, round 6)  `prefill_route`: "repack" where it measures ahead of / level with "two_pass", else "two_pass";
+        #   "repack" (round 5)    transpose the packed nibbles into a TEMPORARY of the call (csrc/repack.hip, K N / 2 bytes) and run
         #                         the fused MFMA GEMM on it (csrc/gemm_regb.hip): two hand-written launches, no vendor GEMM, no fp16
         #                         copy of the weights, bit-identical to what a GEMM-format checkpoint of the same weights computes;
         #   "two_pass"            dequantise (hand-written kernel, bit-exact) into an fp16 temporary + a dense fp16 GEMM: the reference's
@@ -100,15 +118,19 @@ class WQLinear_GEMV(nn.Module):
         #                         0.29 of the peak at M = 16384 and latency-bound below ~2000 rows (profiles/r04_bench_*.json).
         out = None
         rows = inputs.shape[0]
-        decode = rows <= 16 or (rows < PREFILL_MIN_ROWS and ops.gemv_auto_kernel(rows, self.in_features, self.out_features, self.group_size)
+        decode = rows <= 16 or (rows < prefill_min_rows(self.in_features) and
+                                ops.gemv_auto_kernel(rows, self.in_features, self.out_features, self.group_size)
                                 == ops.GEMV_KERNEL_BATCH)  # (the older decode kernels serve 16 rows per launch: not worth chunking)
-        if not decode and self.PREFILL_IMPL == "repack":
+        impl = self.PREFILL_IMPL
+        if impl == "auto":
+            impl = "repack" if prefill_route(rows, self.in_features, self.out_features) == "hand" else "two_pass"
+        if not decode and impl == "repack" and self.out_features % 8 == 0:  # (the GEMM layout packs eight columns per word)
             try:
                 out = ops.gemv_prefill_repack(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
             except _lib.AwqHipError as e:  # a shape the GEMM kernels refuse
                 if e.code != _lib.ERR_UNSUPPORTED:
                     raise
-        if not decode and self.PREFILL_IMPL == "fused":
+        if not decode and impl == "fused":
             try:
                 out = ops.gemv_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size,
                                        flags=ops.gemm_flags(kernel=ops.GEMV_KERNEL_PREFILL))

@@ -11,14 +11,15 @@ The reference picks its decode kernel for batch < 8 and one token, its prefill G
 rows run the batched decode kernel on the layout's own buffers (csrc/gemv_batch.hip, GEMVFast form; csrc/gemv_fast.hip for group
 sizes other than 128), and prefill-sized inputs the hand-written pair `awq_gemv_fast_prefill` (round 6): the packed words transposed
 into a temporary of the call (csrc/repack.hip) + the register-decoded MFMA GEMM with this format's own scales / fp16 zero terms
-(csrc/gemm_regb.hip, FZ form).  No vendor GEMM on the default path for group sizes that are multiples of 64; `PREFILL_IMPL =
-"two_pass"` (dequantise + dense fp16 GEMM, the reference's gemm.py:48-54 route) stays selectable and serves the other shapes.
+(csrc/gemm_regb.hip, FZ form) -- `PREFILL_IMPL = "fused"`.  The default, "auto", takes that pair where it measures ahead of or
+level with dequantise + dense fp16 GEMM (the reference's gemm.py:48-54 route, `"two_pass"`) and the two-pass route elsewhere
+(`gemv.prefill_route`, profiles/r06_prefill_routes.txt).
 """
 import torch
 
 from ... import _lib, ops
 from ...utils.packing import calculate_zeros_width, pack_intweight_fast, quantize_int_weights_nk
-from .gemv import dequant_matmul_nk
+from .gemv import dequant_matmul_nk, prefill_min_rows, prefill_route
 
 # up to this many rows: the decode / batched-decode kernels (round 5: csrc/gemv_batch.hip in its GEMVFast form, launches of <= 32 rows, group
 # size 128; other group sizes: 16 rows, csrc/gemv_fast.hip); above: dequantise + dense GEMM
@@ -26,7 +27,9 @@ PREFILL_MIN_ROWS = 97
 
 
 class WQLinear_GEMVFast(torch.nn.Module):
-    PREFILL_IMPL = "fused"  # "fused": repack + register-decoded MFMA GEMM (hand-written, default); "two_pass": dequantise + dense fp16 GEMM
+    # "auto" (default): `gemv.prefill_route` -- the hand-written pair where it measures ahead of / level with dequantise + dense fp16 GEMM
+    # (from 3072 rows on matrices at least as wide as tall), the two-pass route elsewhere; "fused" / "two_pass" force one
+    PREFILL_IMPL = "auto"
 
     def __init__(self, w_bit, group_size, in_features, out_features, bias, dev):
         super().__init__()
@@ -83,13 +86,16 @@ class WQLinear_GEMVFast(torch.nn.Module):
             inputs = inputs.half()
         out = None
         rows = inputs.shape[0]
-        if (rows <= 16 or (rows < PREFILL_MIN_ROWS and self.group_size == 128 and self.in_features % 128 == 0)) and self.out_features % 16 == 0:
+        if (rows <= 16 or (rows < prefill_min_rows(self.in_features) and self.group_size == 128 and self.in_features % 128 == 0)) and self.out_features % 16 == 0:
             try:
                 out = ops.gemv_fast_forward(inputs, self.qweight, self.scales, self.qzeros, self.group_size)
             except _lib.AwqHipError as e:  # a shape the decode kernel does not take (K % 128, unusual group sizes)
                 if e.code != _lib.ERR_UNSUPPORTED:
                     raise
-        if out is None and self.PREFILL_IMPL == "fused":
+        impl = self.PREFILL_IMPL
+        if impl == "auto":
+            impl = "fused" if prefill_route(rows, self.in_features, self.out_features) == "hand" else "two_pass"
+        if out is None and impl == "fused":
             # prefill-sized batches: two hand-written launches on THIS layout's buffers (round 6) -- the words transposed into a
             # temporary of the call, then the fused MFMA GEMM with the layout's w * s + qzeros arithmetic (the same effective weights
             # the decode kernel uses).  Nothing resident, no vendor GEMM.

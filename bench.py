@@ -19,7 +19,7 @@ Secondary objects on the same JSON line (N = 1, never `value`; each guarded so t
 depend on them): `sustained` (the same graph for >= 1 s), `per_shape` (the four Linear shapes of the headline one by
 one, each with its own roofline), `by_layout`, `gemm_bs` (configs[2]'s "bs=8 GEMM for 4096x11008": M = 1 .. 64, cold
 weights, GEMM and GEMV layouts), `gemm_prefill` (configs[2]: M = 8 x 2048 = 16384, fused MFMA kernel vs HIP dequant
-+ vendor GEMM, which one the module picks), `moe_bs4` (configs[4]), `decode_dependent` (the same Linears with TRUE
++ vendor GEMM, which one the module picks), `moe_bs4` (configs[4]), `decode_independent` (the headline's Linears with FIXED inputs: rounds 1-5's headline; since round 6 the headline itself has the TRUE
 data dependencies: each consumes the previous one's output), `whole_model` (the fused decoder), and `cpu_baseline`
 (the reference's CPU path restated in torch, per shape, M = 1 and 8, on this host's cores).
 """
@@ -44,7 +44,8 @@ MODELS = {  # hidden, intermediate, layers, heads, kv heads
     "70b": dict(hidden=8192, inter=28672, layers=80, heads=64, kv_heads=8, name="Llama-3-70B"),
 }
 HIDDEN, INTER, LAYERS = 4096, 11008, 32  # the headline model (kept as names for tools/ that import them)
-PMC_FILE = "r05_pmc_fetch_size.txt"      # rocprofv3 --pmc FETCH_SIZE pass of the headline command (tools/prof_r05.sh)
+PMC_FILE = "r06_pmc_fetch_size.txt"      # rocprofv3 --pmc FETCH_SIZE pass of the headline command (tools/prof_r06.sh)
+PMC_BS_FILE = "r06_pmc_gemm_bs.txt"      # the same counters for the batched-decode legs (tools/pmc_gemm_bs.py under rocprofv3)
 KERNEL_OF_LAYOUT = {"gemv": "awq_gemv_rows_kernel", "gemm": "awq_gemv_mfma_kernel", "gemvfast": "awq_gemv_fast_kernel"}
 
 
@@ -78,6 +79,21 @@ def pmc_traffic_per_launch():
         return None, (f"profiles/{PMC_FILE} was taken at kernel sources {m.group(1) if m else 'unrecorded'}, this tree is "
                       f"{kernel_fingerprint()}: {val / 1e6:.3f} MB per launch there, not reported as this build's traffic")
     return val, "kernel sources of the counter pass == this tree (" + m.group(1) + ")"
+
+
+def pmc_traffic_gemm_bs():
+    """{leg key: HBM bytes per call} of the batched-decode legs from the committed counter pass (profiles/PMC_BS_FILE: lines
+    `<layout> M=<m>: traffic <x> MB ...`), or {} when the file is missing / was taken from other kernel sources."""
+    import re
+
+    try:
+        txt = open(os.path.join(ROOT, "profiles", PMC_BS_FILE)).read()
+    except OSError:
+        return {}
+    m = re.search(r"kernel source fingerprint: ([0-9a-f]+)", txt)
+    if not m or m.group(1) != kernel_fingerprint():
+        return {}
+    return {(a, b): float(c) * 1e6 for a, b, c in re.findall(r"^(\w+) M=(\d+): traffic ([0-9.]+) MB", txt, re.M)}
 
 
 def algorithmic_bytes(K, N, M, g, bias=False):
@@ -138,21 +154,43 @@ def build_model(dev, rank, world, layers, seed=1234, layout="gemm", model="7b"):
     return net, shapes
 
 
-def run_step(model, outs, ops, allreduce):
-    """allreduce: None (one GPU), or a callable summing a [1, hidden] fp16 tensor over the ranks in place"""
+def run_step(model, outs, ops, allreduce, dependent=True):
+    """One decode step over the int4 Linears.  dependent (the HEADLINE since round 6): every Linear consumes the
+    previous one's output -- qkv -> o (reads the q columns) -> gate|up -> down (reads the first `inter` columns; a 128-link chain of
+    random matrices with the quadratic silu * up in it blows up numerically) -> the next layer's qkv -- which is what a decode step
+    is: one launch per Linear, each waiting for its producer (the slice a consumer takes is a view at batch 1, no copy launch).
+    dependent=False: every Linear on its own fixed input (rounds 1-5's headline, now the `decode_independent` leg).
+    allreduce: None (one GPU), or a callable summing a [1, hidden] fp16 tensor over the ranks in place."""
     i = 0
+    t = model[0][0]["x"]
     for layer in model:
         for lin in layer:
+            x = t[:, : lin["K"]] if dependent else lin["x"]
             if lin["layout"] == "gemm":
-                y = ops.gemm_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"])
+                y = ops.gemm_forward(x, lin["qw"], lin["sc"], lin["qz"])
             elif lin["layout"] == "gemv":
-                y = ops.gemv_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"], GROUP)
+                y = ops.gemv_forward(x, lin["qw"], lin["sc"], lin["qz"], GROUP)
             else:
-                y = ops.gemv_fast_forward(lin["x"], lin["qw"], lin["sc"], lin["qz"], GROUP)
+                y = ops.gemv_fast_forward(x, lin["qw"], lin["sc"], lin["qz"], GROUP)
             if lin["reduce"]:
                 allreduce(y)
             outs[i] = y
+            t = y
             i += 1
+
+
+def unit_gain(model, ops, world=1):
+    """Scale every Linear's scales so that its output has unit rms on a unit-rms input (random packed weights have a gain of ~10 per
+    link: fp16 would overflow after a few links of the dependent chain).  Row-parallel Linears (their outputs are summed over the
+    ranks) are scaled for a unit-rms SUM.  A GEMVFast Linear's zero terms -(s z) scale with its scales."""
+    for layer in model:
+        for lin in layer:
+            y = forward_lin(ops, lin, lin["x"])
+            rms = float(y.float().pow(2).mean().sqrt()) * (world ** 0.5 if lin["reduce"] else 1.0)
+            f = 1.0 / max(rms, 1e-6)
+            lin["sc"].mul_(f)
+            if lin["layout"] == "gemvfast":
+                lin["qz"].mul_(f)
 
 
 def graph_time(fn, stream, reps, warm=2, min_seconds=0.0):
@@ -207,6 +245,11 @@ def leg_gemm_bs(dev, ops):
         out["by_batch"][str(M)] = {"us": us, "kernel": ops.last_kernel(),
                                    "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac": by / us / 1e3 / HBM_PEAK_GBS, "bytes_per_launch": by}}
+    traffic = pmc_traffic_gemm_bs()  # HBM bytes per call from the committed FETCH_SIZE pass (null when taken at other kernel sources)
+    for M in (1, 8, 64):
+        r = out["by_batch"][str(M)]["roofline"]
+        r["traffic"] = traffic.get(("gemm", str(M)))
+        r["traffic_measured_in"] = "profiles/" + PMC_BS_FILE
     out["bs8"] = out["by_batch"]["8"]
     del sets
     torch.cuda.empty_cache()
@@ -225,6 +268,10 @@ def leg_gemm_bs(dev, ops):
         out["gemv_layout_by_batch"][str(M)] = {"us": us, "kernel": ops.last_kernel(),
                                                "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                             "frac": by / us / 1e3 / HBM_PEAK_GBS, "bytes_per_launch": by}}
+    for M in (1, 8, 64, 96):
+        r = out["gemv_layout_by_batch"][str(M)]["roofline"]
+        r["traffic"] = traffic.get(("gemv", str(M)))
+        r["traffic_measured_in"] = "profiles/" + PMC_BS_FILE
     out["gemv_layout_bs8"] = out["gemv_layout_by_batch"]["8"]  # north_star's "bs=8 ... 4096x11008" on the default decode layout
     del sets
     torch.cuda.empty_cache()
@@ -327,18 +374,52 @@ def leg_gemm_prefill(dev, ops):
     modv.qweight, modv.qzeros, modv.scales = nq, nz, ns
     us_mv = timeit(lambda: modv(x))
 
+    # round 6, the same matrix in the WQLinear_GEMVFast format: the words transposed into a temporary (csrc/repack.hip) + the fused MFMA
+    # GEMM in its FZ form (W = fp16(w s + qzeros), the format's own scales / fp16 zero terms) -- the role of
+    # awq_v2_ext.gemm_forward_cuda_prefill (awq/modules/linear/gemv_fast.py:203-206); beside it dequantise + vendor GEMM
+    from autoawq_amd import WQLinear_GEMVFast
+    from autoawq_amd.modules.linear.gemv import prefill_route
+
+    route_v = "repack" if prefill_route(M, K, N) == "hand" else "two_pass"
+    del nq, nz, ns, modv
+    torch.cuda.empty_cache()
+    fq, fz, fs = rand_packed_nk(K, N, GROUP, dev, gen, fast=True)
+    us_fz = timeit(lambda: ops.gemv_fast_prefill(x, fq, fs, fz, GROUP))
+    fz_kernel = ops.last_kernel()
+    us_fz2 = timeit(lambda: torch.matmul(x, ops.dequantize_weights_gemv_fast(fq, fs, fz, GROUP).t()))
+    us_frk = timeit(lambda: ops.repack_gemvfast_to_gemm(fq), reps=20)
+    af = ops.gemv_fast_prefill(x[:2048], fq, fs, fz, GROUP).float()
+    bf = torch.matmul(x[:2048], ops.dequantize_weights_gemv_fast(fq, fs, fz, GROUP).t()).float()
+    rel_fz = float((af - bf).abs().max() / bf.abs().max())
+    assert rel_fz < 5e-3, f"GEMVFast prefill route disagrees with dequantise + GEMM: {rel_fz}"
+    fz_by_m = {str(m): 2.0 * m * K * N / timeit(lambda: ops.gemv_fast_prefill(x[:m], fq, fs, fz, GROUP)) / 1e6 for m in (2048, 4096)}
+    modf = WQLinear_GEMVFast(4, GROUP, K, N, False, dev)
+    modf.qweight, modf.qzeros, modf.scales = fq, fz, fs
+    x3 = x.view(8, M // 8, K)
+    us_mf = timeit(lambda: modf(x3))
+
     return {"shape": f"{K}x{N} g{GROUP}, M={M} (bs 8 x seq 2048)", "flops": fl,
+            "gemvfast_layout": {"fused": {"us": us_fz, "kernel": fz_kernel, "roofline": roof(us_fz), "repack_kernel_us": us_frk,
+                                          "repack_kernel_gbs": K * N / us_frk / 1e3, "tflops_other_token_counts": fz_by_m,
+                                          "vs_dequant_plus_gemm_max_rel": rel_fz},
+                                "two_pass": {"us": us_fz2, "roofline": roof(us_fz2)},
+                                "module": {"us": us_mf, "roofline": roof(us_mf),
+                                           "route": modf.PREFILL_IMPL + " -> " + ("fused" if prefill_route(M, K, N) == "hand" else "two_pass")},
+                                "what": "WQLinear_GEMVFast buffers (qweight int16 [N/4, K], fp16 zero terms): `fused` = awq_gemv_fast_prefill, two "
+                                        "hand-written launches (round 6); `two_pass` = awq_dequantize_weights_gemv_fast + a dense vendor GEMM; the "
+                                        "module's `auto` takes the faster one by shape and token count (modules/linear/gemv.py::prefill_route)"},
             "gemv_layout": {"fused_nk": {"us": us_nk, "kernel": nk_kernel, "roofline": roof(us_nk), "tflops_other_token_counts": nk_by_m,
                                          "vs_dequant_plus_gemm_max_rel": rel_nk},
                             "two_pass": {"us": us_nk2, "roofline": roof(us_nk2)},
                             "repack": {"us": us_rp, "roofline": roof(us_rp), "repack_kernel_us": us_rk,
                                        "repack_kernel_gbs": K * N / us_rk / 1e3, "tflops_other_token_counts": rp_by_m,
                                        "vs_dequant_plus_gemm_max_rel": rel_rp},
-                            "module": {"us": us_mv, "roofline": roof(us_mv), "route": modv.PREFILL_IMPL},
-                            "what": "WQLinear_GEMV buffers (qweight [N, K/8]), no second copy of the weights: the module's default route since "
-                                    "round 5 = `repack` (csrc/repack.hip transposes the packed nibbles into a temporary, then the fused MFMA GEMM: "
-                                    "hand-written end to end); `two_pass` (awq_dequantize_weights_gemv + a dense vendor GEMM) and `fused_nk` "
-                                    "(AWQ_GEMV_KERNEL_PREFILL: gemm_regb.hip, N-major form) are opt-in"},
+                            "module": {"us": us_mv, "roofline": roof(us_mv), "route": "auto -> " + route_v},
+                            "what": "WQLinear_GEMV buffers (qweight [N, K/8]), no second copy of the weights: `repack` (csrc/repack.hip transposes "
+                                    "the packed nibbles into a temporary, then the fused MFMA GEMM: hand-written end to end), `two_pass` "
+                                    "(awq_dequantize_weights_gemv + a dense vendor GEMM), `fused_nk` (AWQ_GEMV_KERNEL_PREFILL: gemm_regb.hip, N-major "
+                                    "form); the module's default since round 6 is `auto`: the faster of repack / two_pass by shape and token count "
+                                    "(modules/linear/gemv.py::prefill_route, profiles/r06_prefill_routes.txt; ADVICE r05)"},
             "fused_mfma": {"us": us_f, "kernel": kernel, "roofline": roof(us_f)},
             "fused_lds_tiled_r01": {"us": us_t, "roofline": roof(us_t)}, "two_pass": {"us": us_2, "roofline": roof(us_2)},
             "module": {"us": us_m, "roofline": roof(us_m),
@@ -416,37 +497,19 @@ def forward_lin(ops, lin, x):
     return ops.gemv_fast_forward(x, lin["qw"], lin["sc"], lin["qz"], GROUP)
 
 
-def leg_decode_dependent(dev, ops, model, bytes_step):
-    """The headline Linears as ONE dependent chain: qkv -> o (reads q) -> gate|up -> down (reads the first 11008 columns;
-    a 128-link chain of random matrices with the quadratic silu * up in it blows up numerically) -> next qkv: one launch
-    per Linear, every launch consuming the previous one's output (the headline replays them with fixed inputs)."""
-    lins = [lin for layer in model for lin in layer]
-    x0 = lins[0]["x"]
-    x = x0
-    for lin in lins:  # unit gain per link, or fp16 overflows after a few layers
-        y = forward_lin(ops, lin, x[:, : lin["K"]].contiguous())
-        rms = float(y.float().pow(2).mean().sqrt())
-        lin["sc"].mul_(1.0 / max(rms, 1e-6))
-        x = forward_lin(ops, lin, x[:, : lin["K"]].contiguous())
-
-    def sequential():  # batch 1: the slice a consumer takes (q of qkv, the first 11008 of gate|up) is a view, no copy launch
-        t = x0
-        for l in lins:
-            t = forward_lin(ops, l, t[:, : l["K"]])
-        return t
-
+def leg_decode_independent(dev, ops, model, bytes_step):
+    """Rounds 1-5's headline as a secondary leg: the same 128 launches, every Linear on its own FIXED input (no launch waits for the
+    data of its predecessor; the launches still run one after the other on one stream)."""
+    nl = sum(len(l) for l in model)
+    outs = [None] * nl
     st = torch.cuda.Stream(device=dev)
-    us_seq = graph_time(sequential, st, reps=10, min_seconds=0.3)
-
-    def obj(us):
-        return {"ms_per_token": us / 1e3, "tok_s": 1e6 / us,
-                "roofline": {"bound": "hbm", "achieved": bytes_step / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": bytes_step / us / 1e3 / HBM_PEAK_GBS}}
-
-    return {"what": "the same 128 Linears with TRUE data dependencies (each consumes the previous one's output), one launch each",
-            "layout": lins[0]["layout"], "one_launch_per_linear": obj(us_seq), "links": len(lins),
-            "note": "round 2's persistent chain kernel (one launch for the whole token, GEMM layout) measured at parity with launches "
-                    "and left the product library: tools/experimental/README.md"}
+    us = graph_time(lambda: run_step(model, outs, ops, None, dependent=False), st, reps=10, min_seconds=0.3)
+    return {"what": "the headline's Linears with FIXED inputs per Linear (the headline of rounds 1-5): one launch each, no data dependency",
+            "layout": model[0][0]["layout"], "ms_per_token": us / 1e3, "tok_s": 1e6 / us, "links": nl,
+            "roofline": {"bound": "hbm", "achieved": bytes_step / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bytes_step / us / 1e3 / HBM_PEAK_GBS},
+            "note": "round 6's persistent engine (one launch for the whole dependent chain) is correct and 0.69 x the launches' rate: "
+                    "profiles/r06_engine_probe.txt, tools/experimental/engine/"}
 
 
 def leg_whole_model(dev):
@@ -514,6 +577,7 @@ def cpu_baseline(layers_total):
         return 4 * a[key] + 2 * b[key] + c[key]
 
     return {"value": 1.0 / (layer_s("linear_M1_s") * layers_total), "unit": "tok/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cores": ncpu, "threads": torch.get_num_threads(),  # os.cpu_count() of the GPU box, and the thread count used (the fastest tried)
             "thread_counts_tried_dequant_4096x4096_s": {str(k): v for k, v in tries.items()},
             "sample": f"the 3 distinct Linear shapes of 1 of {layers_total} layers, median of 3 (dequant) / 5 (matmul); a layer = 4 x "
                       f"{HIDDEN}x{HIDDEN} + 2 x {HIDDEN}x{INTER} + 1 x {INTER}x{HIDDEN} = {layer_s('linear_M1_s'):.2f} s; "
@@ -556,6 +620,7 @@ def leg_by_layout(dev, ops, layers, skip):
         if layout == "gemvfast":
             by += sum((l["K"] // GROUP) * l["N"] * 3 // 2 for layer in model for l in layer)
         outs = [None] * sum(len(l) for l in model)
+        unit_gain(model, ops)
         us = graph_time(lambda: run_step(model, outs, ops, None), st, reps=20, min_seconds=0.3)
         kernels = {}
         for lin in model[0]:  # (one eager call per Linear of a layer, after the timed region: which kernel AUTO took at each shape)
@@ -673,6 +738,7 @@ def main():
     if world > 1 and a.layout == "gemvfast":
         raise SystemExit("tensor-parallel shards are implemented for the GEMM and GEMV layouts")
     model, shapes = build_model(dev, rank, world, layers, layout=a.layout, model=a.model)
+    unit_gain(model, ops, world)  # (the headline is the DEPENDENT chain: unit gain per link keeps 128 links inside fp16)
     nl = sum(len(l) for l in model)
     outs = [None] * nl
     bytes_step = sum(algorithmic_bytes(l["K"], l["N"], 1, GROUP) for layer in model for l in layer)
@@ -767,6 +833,8 @@ def main():
             "config": {"workload": f"{cfg['name']}-shape AWQ int4 g128, GEMV bs=1 decode: {layers} layers x {{{shape_txt}}}"
                                    + (" per rank" if world > 1 else ""),
                        "layers": layers, "launches_per_step": launches, "hipgraph": used_graph, "layout": a.layout,
+                       "chain": "dependent: every Linear consumes its predecessor's output (qkv -> o -> gate|up -> down -> next qkv), unit "
+                                "gain per link; `decode_independent` has rounds 1-5's fixed-input form",
                        "layout_note": "packed tensors in the reference's WQLinear_" + {"gemm": "GEMM", "gemv": "GEMV", "gemvfast": "GEMVFast"}[a.layout] +
                                       " checkpoint format (awq/modules/linear/); utils/convert.py repacks between the three, bit-exactly",
                        "parallelism": f"tp{world}" if world > 1 else "single",
@@ -786,7 +854,7 @@ def main():
                          "note": "achieved = algorithmic bytes per launch / average launch duration; duration = "
                                  "HIP-event-timed replay of the captured stream / launches, i.e. it contains the "
                                  "dispatch gap exactly as rocprofv3's back-to-back kernel durations do "
-                                 "(profiles/r05_bench_kernel_trace_stats.txt)"},
+                                 "(profiles/r06_bench_kernel_trace_stats.txt)"},
         }
         if capture_note:
             out["config"]["capture_note"] = capture_note
@@ -798,7 +866,7 @@ def main():
         if full:
             del graph, outs
             legs = [("per_shape", lambda: leg_per_shape(dev, ops, model, shapes)),
-                    ("decode_dependent", lambda: leg_decode_dependent(dev, ops, model, bytes_step)),
+                    ("decode_independent", lambda: leg_decode_independent(dev, ops, model, bytes_step)),
                     ("by_layout", lambda: (model.clear(), torch.cuda.empty_cache(), leg_by_layout(dev, ops, layers, a.layout))[2]),
                     ("gemm_bs", lambda: leg_gemm_bs(dev, ops)), ("gemm_prefill", lambda: leg_gemm_prefill(dev, ops)),
                     ("prefill_attention", lambda: leg_prefill_attention(dev, ops)),

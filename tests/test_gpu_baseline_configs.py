@@ -145,7 +145,9 @@ def test_gemvfast_layout_prefill_route_vs_oracle(ops, oracle, K, N, M, bm):
 
         mod = WQLinear_GEMVFast(4, g, K, N, False, "cuda")
         mod.qweight, mod.qzeros, mod.scales = dq, dz, ds
-        assert mod.PREFILL_IMPL == "fused"
+        assert mod.PREFILL_IMPL == "auto"  # by measurement: gemv.prefill_route
+        assert_product_close(mod(dx.view(1, M, K))[0][rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module auto {K}x{N} M{M}")
+        mod.PREFILL_IMPL = "fused"
         called = []
         orig = gemv_mod.dequant_matmul_nk
         import autoawq_amd.modules.linear.gemv_fast as fast_mod
@@ -154,9 +156,9 @@ def test_gemvfast_layout_prefill_route_vs_oracle(ops, oracle, K, N, M, bm):
             ym = mod(dx.view(1, M, K))[0]
         finally:
             fast_mod.dequant_matmul_nk = orig
-        assert not called, "the default prefill route of WQLinear_GEMVFast reached the dequantise + vendor GEMM route"
+        assert not called, "the hand-written prefill route of WQLinear_GEMVFast reached the dequantise + vendor GEMM route"
         assert torch.equal(ym, ops.gemv_fast_prefill(dx, dq, ds, dz, g)) or ops.last_kernel() in ("gemv_batch_fast", "repack_fast+gemm_regb_fz")
-        assert_product_close(ym[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module default {K}x{N} M{M}")
+        assert_product_close(ym[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module fused {K}x{N} M{M}")
         ys = awq_v2_ext.gemm_forward_cuda_prefill(dx.view(1, M, K), dq, ds, dz)[0]
         assert_product_close(ys[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"awq_v2_ext shim {K}x{N} M{M}")
         mod.PREFILL_IMPL = "two_pass"
@@ -215,7 +217,9 @@ def test_gemv_layout_prefill_kernel_vs_oracle(ops, oracle, K, N, M, bm):
 
         # the module's routes: below PREFILL_MIN_ROWS the batched-decode kernel; from there "repack" (default: csrc/repack.hip + the
         # fused MFMA GEMM on the temporary), "two_pass" (dequantise + dense GEMM) or "fused" (this kernel)
-        assert mod.PREFILL_IMPL == "repack"
+        assert mod.PREFILL_IMPL == "auto"  # by measurement: gemv.prefill_route
+        assert_product_close(mod(dx)[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module auto {K}x{N} M{M}")
+        mod.PREFILL_IMPL = "repack"
         assert_product_close(mod(dx)[rows.cuda()].cpu().numpy().astype(np.float64), y32, f"module default {K}x{N} M{M}")
         assert ops.last_kernel() == "gemv_batch" if M < PREFILL_MIN_ROWS else ops.last_kernel() in ("gemm_regb", "gemm_tiled"), ops.last_kernel()
         mod.PREFILL_IMPL = "two_pass"
