@@ -152,6 +152,45 @@ def linear_gemm_exact(x, qweight, qzeros, scales, g, bias=None, chunk=2048):
     return y
 
 
+def matmul_exact_gemv(x, qweight, qzeros, scales, g, chunk=2048):
+    """Exact-arithmetic product on the GEMV layout (float64, no fp16 rounding of the dequantised weight): qweight [N, K/8] (nibble i
+    of word c = w[n, 8c + i]), qzeros [N, ZW] (nibble i of word c = z[n, group 8c + i]), scales [N, 8 ZW] -- the packer
+    awq/modules/linear/gemv.py:94-153.  Checker only (the default-path kernels are held to 1 ulp + 1e-4 rms of THIS,
+    not only to the 6-sigma-widened bound against the fp16-rounded weights)."""
+    x = _c(x, np.float16).astype(np.float64)
+    qweight, qzeros = _c(qweight, np.int32), _c(qzeros, np.int32)
+    sc = _c(scales, np.float16).astype(np.float32)
+    N, K = qweight.shape[0], qweight.shape[1] * 8
+    G = K // g
+    sh = (4 * np.arange(8, dtype=np.int32))[None, None, :]
+    y = np.empty((x.shape[0], N), np.float64)
+    for n0 in range(0, N, chunk):
+        n1 = min(N, n0 + chunk)
+        w = ((qweight[n0:n1, :, None] >> sh) & 15).reshape(n1 - n0, K).astype(np.int16)                 # [n, K]
+        z = ((qzeros[n0:n1, :, None] >> sh) & 15).reshape(n1 - n0, -1)[:, :G].astype(np.int16)          # [n, G]
+        d = (w - np.repeat(z, g, axis=1)).astype(np.float32)
+        W = d * np.repeat(sc[n0:n1, :G], g, axis=1)  # exact in fp32: 5-bit x 11-bit significands
+        y[:, n0:n1] = x @ W.astype(np.float64).T
+    return y
+
+
+def matmul_exact_gemvfast(x, qweight, scales, qzeros, g, chunk=2048):
+    """Exact-arithmetic product on the GEMVFast layout (float64): W = w * s + qzeros with NO rounding of the sum (the format stores
+    qzeros = fp16(-(s z)), awq/modules/linear/gemv_fast.py:175-181; that stored value is the exact operand).  Checker only."""
+    x = _c(x, np.float16).astype(np.float64)
+    w = unpack_gemvfast(qweight)  # [K, N] uint8
+    sc = _c(scales, np.float16).astype(np.float64)
+    qz = _c(qzeros, np.float16).astype(np.float64)
+    K, N = w.shape
+    G = K // g
+    y = np.empty((x.shape[0], N), np.float64)
+    for n0 in range(0, N, chunk):
+        n1 = min(N, n0 + chunk)
+        W = w[:, n0:n1].astype(np.float64) * np.repeat(sc[:G, n0:n1], g, axis=0) + np.repeat(qz[:G, n0:n1], g, axis=0)
+        y[:, n0:n1] = x @ W
+    return y
+
+
 def weight_rounding_sigma(x, W):
     """Std-dev bound of the product noise caused by the reference's own fp16 rounding of W:
     each W[k,n] carries an error <= ulp/2, ulp <= 2^-10 |W| (uniform: sigma = ulp/sqrt(12)), so

@@ -123,6 +123,22 @@ def product_tol(ref32):
     return 1e-3 * np.abs(ref32) + 1e-3 * rms
 
 
+def assert_close_to_exact(y, yex, what=""):
+    """|y - yex| <= 1 fp16 ulp of the output + 1e-4 rms(yex) + 1e-5 |yex|, `yex` = the exact-arithmetic product (float64, no fp16
+    rounding of the dequantised weights: oracle.linear_gemm_exact / matmul_exact_gemv / matmul_exact_gemvfast).  The bound the MFMA
+    kernels -- exact integer dot products, scale applied in fp32 -- are held to BESIDE the 6-sigma-widened bound against the
+    reference's fp16-rounded weights (the widened bound is never the only one on a default-path kernel)."""
+    y = np.asarray(y, np.float64)
+    yex = np.asarray(yex, np.float64)
+    rms = float(np.sqrt(np.mean(yex ** 2))) if yex.size else 0.0
+    ulp = np.maximum(np.abs(yex), 2.0 ** -14) * 2.0 ** -10
+    bad = np.abs(y - yex) > ulp + 1e-4 * rms + 1e-5 * np.abs(yex)
+    if bad.any():
+        idx = np.argwhere(bad)
+        where = ", ".join(f"{tuple(int(v) for v in i)}: {y[tuple(i)]:.5f} vs {yex[tuple(i)]:.5f}" for i in idx[:16])
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.size} off the exact product, max err {np.abs(y - yex).max()}; at {where}")
+
+
 def assert_product_close(y, ref32, what="", wsigma=None):
     """|y - ref| <= 1e-3*|ref| + 1e-3*rms(ref) + 1 fp16 ulp of the output (+ 6 sigma of the
     reference's own fp16 weight-rounding noise when `wsigma` is given: the oracle multiplies

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_product_close, golden
+from conftest import assert_close_to_exact, assert_product_close, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -551,10 +551,14 @@ def test_gemv_rows_kernel_vs_oracle(ops, oracle, K, N, g):
         ops.gemm_flags(waves=8, unit=1, splitk=1), ops.gemm_flags(waves=4, unit=2, splitk=2), ops.gemm_flags(waves=8, unit=2, splitk=3),
         ops.gemm_flags(waves=2, unit=1, splitk=1)]
     ran = 0
+    yex4 = oracle.matmul_exact_gemv(x4.numpy(), qw.numpy(), qz.numpy(), sc.numpy(), g)
     for M in (1, 2, 3, 4) if small else (1, 2):
         x = x4[:M].contiguous()
         y32, _ = oracle.matmul(x.numpy(), W)
         wsig = oracle.weight_rounding_sigma(x.numpy(), W)
+        # the default configuration (what every caller runs) also within 1 ulp + 1e-4 rms of the EXACT product: the 6-sigma widening
+        # below is never the only bound on the headline kernel
+        assert_close_to_exact(ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=rows).cpu().numpy(), yex4[:M], f"rows K{K} N{N} g{g} M{M} vs exact")
         for f in forced if (small or M == 1) else forced[:1]:
             try:
                 y = ops.gemv_forward(x.cuda(), qwc, scc, qzc, g, flags=rows | f)
@@ -752,10 +756,13 @@ def test_gemv_batch_kernel_vs_oracle(ops, oracle, K, N):
     Wt = ops.dequantize_weights_gemv(qwc, scc, qzc, g)
     y32_all, _ = oracle.matmul(xall.numpy(), W)
     wsig_all = oracle.weight_rounding_sigma(xall.numpy(), W)
+    yex_all = oracle.matmul_exact_gemv(xall.numpy(), qw.numpy(), qz.numpy(), sc.numpy(), g)
     bt = ops.gemm_flags(kernel=GEMV_KERNEL_BATCH)
     for M in all_m:
         x = xc[64 - M:]  # (a row offset: chunk boundaries of the 33 .. 64-row calls fall elsewhere for every M)
         y32, wsig = y32_all[64 - M:], wsig_all[64 - M:]
+        # beside the 6-sigma-widened bound below: the default form within 1 ulp + 1e-4 rms of the EXACT product
+        assert_close_to_exact(ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt).cpu().numpy(), yex_all[64 - M:], f"batch K{K} N{N} M{M} vs exact")
         # forced forms: activations through the LDS staging area (unit=1; refused where it does not fit: M > ~12) or by direct
         # fragment loads (unit=2), ring depths 1 .. 3
         variants = [0] if M not in (5, 8, 12, 16, 17, 32, 64) else [0, ops.gemm_flags(unit=1, splitk=1), ops.gemm_flags(unit=1, splitk=2),
@@ -844,7 +851,7 @@ def test_gemv_module_forward_semantics(ops, oracle):
 
 
 def product_tol_(ref32):
-    from conftest import product_tol
+    from conftest import assert_close_to_exact, product_tol
     return product_tol(ref32)
 
 
@@ -1152,10 +1159,13 @@ def test_gemvfast_batch_kernel_vs_oracle(ops, oracle, K, N):
     Wt = ops.dequantize_weights_gemv_fast(qwc, scc, qzc, g)
     y32_all, _ = oracle.matmul(xall.numpy(), W)
     wsig_all = oracle.weight_rounding_sigma(xall.numpy(), W)
+    yex_all = oracle.matmul_exact_gemvfast(xall.numpy(), qw.numpy(), sc.numpy(), qz.numpy(), g)  # (unpinned in the reference itself: autoawq-kernels)
     bt = ops.gemm_flags(kernel=GEMV_KERNEL_BATCH)
     for M in ([1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 32, 33, 64, 96] if K * N <= 4096 * 11008 else [1, 4, 5, 16, 32, 64]):
         x = xc[96 - M:]
         y32, wsig = y32_all[96 - M:], wsig_all[96 - M:]
+        # beside the 6-sigma-widened bound below: within 1 ulp + 1e-4 rms of the EXACT product w s + qzeros
+        assert_close_to_exact(ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt).cpu().numpy(), yex_all[96 - M:], f"batch-fast K{K} N{N} M{M} vs exact")
         for f in ([0, ops.gemm_flags(splitk=1), ops.gemm_flags(splitk=2)] if M in (1, 5, 16, 17, 32) else [0]):
             y = ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)
             assert ops.last_kernel() == "gemv_batch_fast"

@@ -152,3 +152,24 @@ def test_exact_product_and_weight_rounding_sigma(oracle):
     a, _ = oracle.linear_gemm(x, qw, qz, s, 128)
     b = oracle.linear_gemm_exact(x, qw, qz, s, 128)
     assert np.array_equal(a.astype(np.float64), b)
+
+
+@pytest.mark.parametrize("name", PACKED)
+def test_exact_products_of_the_gemv_and_gemvfast_layouts(oracle, name):
+    """matmul_exact_gemv on reference-packed GEMV buffers == linear_gemm_exact on the GEMM-layout buffers of the SAME integers
+    (bit for bit: the same float64 arithmetic on the same integers and scales); matmul_exact_gemvfast == x @ (w s + qzeros) from
+    the fixture's integer weights, and within the weight-rounding noise of the fp16-weight product (these
+    are the references the default-path GPU kernels are held to at 1 ulp + 1e-4 rms)."""
+    g = golden(name)
+    gs = int(g["group_size"])
+    a = oracle.linear_gemm_exact(g["x"], g["gemm_qweight"], g["gemm_qzeros"], g["gemm_scales"], gs)
+    b = oracle.matmul_exact_gemv(g["x"], g["gemv_qweight"], g["gemv_qzeros"], g["gemv_scales"], gs)
+    assert np.allclose(a, b, rtol=1e-12, atol=1e-12), np.abs(a - b).max()
+    G = g["w_int"].shape[0] // gs
+    Wf = g["w_int"].astype(np.float64) * np.repeat(g["fast_scales"][:G].astype(np.float64), gs, axis=0) \
+        + np.repeat(g["fast_qzeros"][:G].astype(np.float64), gs, axis=0)
+    c = oracle.matmul_exact_gemvfast(g["x"], g["fast_qweight"], g["fast_scales"], g["fast_qzeros"], gs)
+    assert np.allclose(c, g["x"].astype(np.float64) @ Wf, rtol=1e-12, atol=1e-12)
+    W16 = oracle.dequant_gemvfast(g["fast_qweight"], g["fast_scales"], g["fast_qzeros"], gs)
+    y32, _ = oracle.matmul(g["x"], W16)
+    assert (np.abs(c - y32) <= 6 * oracle.weight_rounding_sigma(g["x"], W16) + 1e-6 * np.abs(c) + 1e-9).all()
