@@ -23,6 +23,23 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+# ---- recording mode (tests/golden/make_route_a_calls.py sets RECORD to a list): the positional call forms of the reference, with
+# their inputs and the oracle-backed results, for tests/test_gpu_route_a_replay.py -- the reference tree does not exist on the GPU box
+RECORD = None
+
+
+def _recording(mname, fname, fn):
+    def wrapped(*args, **kwargs):
+        before = [a.detach().clone() if torch.is_tensor(a) else a for a in args]
+        ret = fn(*args, **kwargs)
+        after = {i: a.detach().clone() for i, a in enumerate(args)
+                 if torch.is_tensor(a) and (a.shape != before[i].shape or not torch.equal(a, before[i]))}
+        RECORD.append(dict(mod=mname, fn=fname, args=before, kwargs=dict(kwargs), ret=ret.detach().clone() if torch.is_tensor(ret) else ret,
+                           mutated=after))
+        return ret
+    return wrapped
+
+
 @pytest.fixture()
 def route_a(oracle, monkeypatch):
     """shims registered as `awq_ext` / `awq_v2_ext`, ops -> oracle, a fresh import of the reference package"""
@@ -103,6 +120,12 @@ def route_a(oracle, monkeypatch):
     saved = {k: v for k, v in sys.modules.items() if k == "awq" or k.startswith("awq.") or k in ("awq_ext", "awq_v2_ext")}
     for k in saved:
         del sys.modules[k]
+    if RECORD is not None:  # tests/golden/make_route_a_calls.py: every shim call, as the UNMODIFIED reference issues it, goes into the fixture file
+        for mod, mname in ((awq_ext, "awq_ext"), (awq_v2_ext, "awq_v2_ext")):
+            for fname in [n for n in dir(mod) if callable(getattr(mod, n)) and not n.startswith("_") and getattr(getattr(mod, n), "__module__", "") == mod.__name__]:
+                if fname in ("infer_group_size",):
+                    continue
+                monkeypatch.setattr(mod, fname, _recording(mname, fname, getattr(mod, fname)))
     monkeypatch.setitem(sys.modules, "awq_ext", awq_ext)
     monkeypatch.setitem(sys.modules, "awq_v2_ext", awq_v2_ext)
     monkeypatch.syspath_prepend(REF)
