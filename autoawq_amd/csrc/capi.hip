@@ -410,9 +410,13 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     }
     const int auto_k = kern == AWQ_GEMV_KERNEL_AUTO ? awq_gemv_auto_kernel(M, K, N, group_size) : -1;
     if (kern == AWQ_GEMV_KERNEL_BATCH || auto_k == (int)AWQ_GEMV_KERNEL_BATCH) {
-        if (!awq_gemv_batch_supports((int)(M > 32 ? 32 : M), (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
+        // one launch per <= 128 rows (round 6: up to four 32-row parts share a tile's weights inside a block); where the parts do not fit
+        // the LDS budget (very long tile lists per block) 32-row launches as before
+        int64_t cap = 128;
+        while (cap > 32 && !awq_gemv_batch_supports((int)(M > cap ? cap : M), (int)K, (int)N, (int)group_size)) cap /= 2;
+        if (!awq_gemv_batch_supports((int)(M > cap ? cap : M), (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
         g_last_kernel = "gemv_batch";
-        const int64_t nchunk = (M + 31) / 32, rows = (M + nchunk - 1) / nchunk;  // balanced chunks of at most 32 rows
+        const int64_t nchunk = (M + cap - 1) / cap, rows = (M + nchunk - 1) / nchunk;  // balanced chunks of at most `cap` rows
         for (int64_t m0 = 0; m0 < M; m0 += rows) {
             const int mm = (int)(M - m0 < rows ? M - m0 : rows);
             const int rc = awq_launch_gemv_batch(x + m0 * K, qweight, scales, qzeros, y + m0 * N, mm, (int)K, (int)N, (int)group_size,
@@ -492,7 +496,9 @@ int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint1
     // round 5: from five rows the batched kernel (gemv_batch.hip, GEMVFast form: any M in launches of <= 32 rows); AWQ_GEMM_FLAG_KERNEL:
     // 0 = auto, 1 = the 16-row kernel (gemv_fast.hip, M <= 16), AWQ_GEMV_KERNEL_BATCH = the batched kernel
     const uint32_t kern = AWQ_GEMM_FLAG_KERNEL(flags);
-    const bool batch_ok = awq_gemv_batch_fast_supports((int)(M > 32 ? 32 : M), (int)K, (int)N, (int)group_size);
+    int64_t fcap = 128;  // rows per launch (round 6: row parts, see gemv_batch.hip)
+    while (fcap > 32 && !awq_gemv_batch_fast_supports((int)(M > fcap ? fcap : M), (int)K, (int)N, (int)group_size)) fcap /= 2;
+    const bool batch_ok = awq_gemv_batch_fast_supports((int)(M > fcap ? fcap : M), (int)K, (int)N, (int)group_size);
     // below five rows AUTO takes it where ONE pass of eight waves covers K (2048 < K <= 4096): there it is ahead of the 16-row kernel at
     // every M (profiles/r05_sweep_small_batch.txt, M = 1: 5.4 / 9.3 / 9.6 / 15.0 us vs 6.2 / 9.7 / 10.1 / 16.3 at N = 4096 / 11008 /
     // 12288 / 22016), behind it at K = 1024 (fewer waves per tile) and from K = 8192 (two passes)
@@ -500,7 +506,7 @@ int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint1
     if (kern == AWQ_GEMV_KERNEL_BATCH || (kern == 0 && (M >= 5 || small_ok) && batch_ok)) {
         if (!batch_ok) return AWQ_ERR_UNSUPPORTED;
         g_last_kernel = "gemv_batch_fast";
-        const int64_t nchunk = (M + 31) / 32, rows = (M + nchunk - 1) / nchunk;
+        const int64_t nchunk = (M + fcap - 1) / fcap, rows = (M + nchunk - 1) / nchunk;
         for (int64_t m0 = 0; m0 < M; m0 += rows) {
             const int mm = (int)(M - m0 < rows ? M - m0 : rows);
             const int rc = awq_launch_gemv_batch_fast(x + m0 * K, qweight, scales, qzeros, y + m0 * N, mm, (int)K, (int)N, (int)group_size,

@@ -1,4 +1,4 @@
-// gemv_batch.hip -- batched decode (5 <= M <= 32 per launch) on the GEMV layout: weights stream through LDS by DMA into MFMA,
+// gemv_batch.hip -- batched decode (5 <= M <= 128 per launch) on the GEMV layout: weights stream through LDS by DMA into MFMA,
 // the activations live in REGISTERS as MFMA A fragments, the K range of a tile is split over the waves of ONE block, gfx950.
 //
 // Replaces awq_ext.gemmv2_forward_cuda (awq/modules/linear/gemv.py:168-176: the reference's kernel for more than 8 rows on
@@ -40,7 +40,8 @@
 //    inside the stream would break the counted waits: stores count in vmcnt but do not retire in order with loads).
 //  * K beyond one pass (8 waves x 512 k) is walked in PASSES: the A fragments of the next K range are re-requested (a drain: they
 //    queue behind the ring), the ring keeps running across the pass edge, partial sums add up in the parked tiles.
-//  * M > 32 is two launches from the C API (the A fragments of 64 rows do not fit the register file beside a useful K range).
+//  * M > 32 (round 6): still ONE launch up to 128 rows -- the wave groups of a block become ROW PARTS of <= 32 rows on the same tiles
+//    (see the kernel head); beyond 128 rows the C API walks chunks of <= 128.
 #include <type_traits>
 
 #include "awq_device.h"
@@ -67,6 +68,7 @@ struct BatchParams {
     int tiles_base, tiles_rem, tiles_max;  // tiles per owner: base (+1 for the first rem owners)
     int ring_off, pbuf_off, pbuf_pitch, ystage_off;  // LDS byte offsets; pbuf_pitch: bytes per wave (XS: the wave's staging area)
     int xs_rows;     // XS: batch rows the staging area holds at a time (min(M, 8): more rows arrive in chunks of eight)
+    int rs, rows_part;  // round 6: ROW PARTS -- the wt wave groups of a block are (wt / rs tile owners) x (rs row parts of rows_part <= 32 batch rows)
     int GP;          // FAST (GEMVFast layout): rows of scales / qzeros [GP, N]
     unsigned long long* trace;             // debug builds only (tools/trace_gemv_batch.py)
 };
@@ -144,10 +146,17 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-    const int M = p.M;
     const int wki = wave % p.wk, twi = wave / p.wk;
+    // Round 6 (one launch for 33 .. 128 rows, the matrix streamed ONCE): the wave groups of a block that used to own
+    // different tiles can instead own the SAME tiles for different 32-row PARTS of the batch (rs = 2 | 4): a part's A fragments still fit
+    // the registers (MI <= 2), the parts' weight requests for a tile go out within the same microsecond and meet in L2 (HBM traffic 1 x:
+    // profiles/r06_pmc_gemm_bs.txt had 2.0 / 2.9 / 3.8 x for the 2 / 3 / 4 launches of 64 / 96 / 128 rows), and K is walked in rs x as
+    // many passes (wk = 8 / wt waves side by side on a tile).
+    const int rsi = twi % p.rs, toi = twi / p.rs;  // row part, tile owner of the block
+    const int row_base = rsi * p.rows_part;        // first batch row of this wave group
+    const int M = max(0, min(p.rows_part, p.M - row_base));
     // owner = the wk waves that share tiles; owner ids interleave the blocks (consecutive owners sit on different CUs)
-    const int owner = twi * (int)gridDim.x + (int)blockIdx.x;
+    const int owner = toi * (int)gridDim.x + (int)blockIdx.x;
     const int t0 = owner * p.tiles_base + min(owner, p.tiles_rem);
     const int ntile = p.tiles_base + (owner < p.tiles_rem ? 1 : 0);
     const int nunit = ntile * p.passes;  // live units of this wave, flat: u = pass * ntile + tile
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                     for (int m = r0; m < r1 && present; ++m) {
                         const int j = (lane & 48) | ((lane & 15) ^ xs_f(m));
                         const int byte = min(256 * g0 + 16 * j, p.K * 2 - 16);
-                        AWQ_BT_DMA16((uint32_t)(m * p.K * 2 + byte), p.x, lds0 + (uint32_t)(xs_w + (m - r0) * 1024));
+                        AWQ_BT_DMA16((uint32_t)((row_base + m) * p.K * 2 + byte), p.x, lds0 + (uint32_t)(xs_w + (m - r0) * 1024));
                     }
                     if (FIRST && mi == 0 && half == 0) {
                         request(0);
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                     for (int c = 0; c < 4; ++c) {  // (lanes of batch rows >= M repeat row M - 1's addresses: no more lines per instruction)
                         const int m = min(16 * mi + n, M - 1);
                         const int kk = min(128 * (g0 + u) + 32 * kq + 8 * c, p.K - 8);
-                        AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (AWQ_BT_DBG & 1) ? 0u : (uint32_t)((m * p.K + kk) * 2), p.x);
+                        AWQ_BT_LOAD16(afr[(mi * GW + u) * 4 + c], (AWQ_BT_DBG & 1) ? 0u : (uint32_t)(((row_base + m) * p.K + kk) * 2), p.x);
                     }
             if constexpr (FIRST) {
                 request(0);
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             for (int q = 0; q < 4; ++q) {
                 const int item = lane + 64 * q, ml = item >> 4, nn = item & 15;
                 const int m = 16 * mi + ml;
-                if (m < M && row0 + nn < p.N) p.y[(int64_t)m * p.N + row0 + nn] = (half_t)src[((ml >> 2) * 16 + nn) * 4 + (ml & 3)];
+                if (m < M && row0 + nn < p.N) p.y[(int64_t)(row_base + m) * p.N + row0 + nn] = (half_t)src[((ml >> 2) * 16 + nn) * 4 + (ml & 3)];
             }
         }
     }
@@ -505,27 +514,31 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 }
 
 struct BatchPlan {
-    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max;
+    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max, rs, rows_part;
     size_t ring, pbuf_pitch, ystage;
 };
 
 // form: 0 = auto, 1 = activations through the LDS staging area (XS), 2 = direct fragment loads
 bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out, bool fast = false) {
-    if (M < 1 || M > 32 || N < 1 || K < 128 || K % 128 || g != 128) return false;
+    if (M < 1 || M > 128 || N < 1 || K < 128 || K % 128 || g != 128) return false;
     if (fast && (N % 16 || form == 2)) return false;  // GEMVFast: whole 4-row bundles, staged form only
     if ((int64_t)N * K / 2 >= ((int64_t)1 << 31) || (int64_t)M * K * 2 >= ((int64_t)1 << 31)) return false;  // 32-bit lane offsets
     BatchPlan b;
-    b.MI = M > 16 ? 2 : 1;
+    b.rs = M > 64 ? 4 : (M > 32 ? 2 : 1);          // row parts of at most 32 rows (balanced: 33 rows = 17 + 16)
+    b.rows_part = (M + b.rs - 1) / b.rs;
+    const int MP = b.rows_part;                     // rows a wave group holds
+    b.MI = MP > 16 ? 2 : 1;
     const int G = K / 128;
     int wk = 1;
-    while (wk < 8 && wk * GW < G) wk *= 2;
+    while (wk < 8 / b.rs && wk * GW < G) wk *= 2;  // (row parts take wave groups: at most 8 / rs waves side by side on a tile)
     b.wk = wk;
     b.wt = 8 / wk;
     b.passes = (G + wk * GW - 1) / (wk * GW);
     const int tiles = (N + 15) / 16;
-    const int want = (tiles + b.wt - 1) / b.wt;
+    const int towners = b.wt / b.rs;                // tile owners per block
+    const int want = (tiles + towners - 1) / towners;
     b.blocks = want < 256 ? want : 256;
-    const int owners = b.blocks * b.wt;
+    const int owners = b.blocks * towners;
     b.tiles_base = tiles / owners;
     b.tiles_rem = tiles % owners;
     b.tiles_max = b.tiles_base + (b.tiles_rem ? 1 : 0);
@@ -534,7 +547,7 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     const size_t budget = 160 * 1024;
     // XS: the staging area holds min(M, 8) batch rows per wave (more rows arrive in chunks of eight); the partial-tile buffers live
     // in it afterwards
-    const int rows = M < 8 ? M : 8;
+    const int rows = MP < 8 ? MP : 8;
     size_t staged = (size_t)rows * 1024 > plain ? (size_t)rows * 1024 : plain;
     if (fast && staged < (size_t)4096 + 256 * b.MI) staged = (size_t)4096 + 256 * b.MI;  // (the group sums sit behind the partial-tile buffers)
     const bool xs = form != 2 && b.ystage + 8 * staged + (size_t)8 * PIECE_B <= budget;
@@ -586,6 +599,7 @@ int launch_batch(const void* x, const void* qweight, const void* scales, const v
     p.pbuf_off = (int)b.ring;
     p.pbuf_pitch = (int)b.pbuf_pitch;
     p.xs_rows = b.xs_rows;
+    p.rs = b.rs; p.rows_part = b.rows_part;
     p.ystage_off = (int)(b.ring + 8 * b.pbuf_pitch);
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_batch_trace;

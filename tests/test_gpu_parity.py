@@ -747,10 +747,12 @@ def test_gemv_batch_kernel_vs_oracle(ops, oracle, K, N):
     reference's dequantised fp16 weights, fp32 product), bitwise reproducible, one-hot rows select rows of the bit-exact W, zero
     in -> zero out, f(2x) == 2 f(x)."""
     g = 128
-    all_m = list(range(1, 65)) if (K, N) == (4096, 11008) else [1, 3, 4, 5, 8, 12, 13, 16, 17, 24, 31, 32, 33, 48, 64]
+    # (round 6: one launch up to 128 rows -- 33 .. 64 rows as two row parts of a block, 65 .. 128 as four; every M 33 .. 128 at the benched shape)
+    all_m = list(range(1, 129)) if (K, N) == (4096, 11008) else [1, 3, 4, 5, 8, 12, 13, 16, 17, 24, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128]
     if K * N > 4096 * 12288:
-        all_m = [4, 5, 16, 17, 32, 64]
-    qw, qz, sc, xall = gemv_case(K, N, g, 64, seed=K + 7 * N)
+        all_m = [4, 5, 16, 17, 32, 64, 97, 128]
+    MX = 128
+    qw, qz, sc, xall = gemv_case(K, N, g, MX, seed=K + 7 * N)
     W = oracle.dequant_gemv(qw.numpy(), qz.numpy(), sc.numpy(), g)
     qwc, qzc, scc, xc = qw.cuda(), qz.cuda(), sc.cuda(), xall.cuda()
     Wt = ops.dequantize_weights_gemv(qwc, scc, qzc, g)
@@ -759,13 +761,13 @@ def test_gemv_batch_kernel_vs_oracle(ops, oracle, K, N):
     yex_all = oracle.matmul_exact_gemv(xall.numpy(), qw.numpy(), qz.numpy(), sc.numpy(), g)
     bt = ops.gemm_flags(kernel=GEMV_KERNEL_BATCH)
     for M in all_m:
-        x = xc[64 - M:]  # (a row offset: chunk boundaries of the 33 .. 64-row calls fall elsewhere for every M)
-        y32, wsig = y32_all[64 - M:], wsig_all[64 - M:]
+        x = xc[MX - M:]  # (a row offset: the row parts of the 33 .. 128-row calls fall elsewhere for every M)
+        y32, wsig = y32_all[MX - M:], wsig_all[MX - M:]
         # beside the 6-sigma-widened bound below: the default form within 1 ulp + 1e-4 rms of the EXACT product
-        assert_close_to_exact(ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt).cpu().numpy(), yex_all[64 - M:], f"batch K{K} N{N} M{M} vs exact")
+        assert_close_to_exact(ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt).cpu().numpy(), yex_all[MX - M:], f"batch K{K} N{N} M{M} vs exact")
         # forced forms: activations through the LDS staging area (unit=1; refused where it does not fit: M > ~12) or by direct
         # fragment loads (unit=2), ring depths 1 .. 3
-        variants = [0] if M not in (5, 8, 12, 16, 17, 32, 64) else [0, ops.gemm_flags(unit=1, splitk=1), ops.gemm_flags(unit=1, splitk=2),
+        variants = [0] if M not in (5, 8, 12, 16, 17, 32, 64, 128) else [0, ops.gemm_flags(unit=1, splitk=1), ops.gemm_flags(unit=1, splitk=2),
                                                                     ops.gemm_flags(unit=2, splitk=1), ops.gemm_flags(unit=2, splitk=2), ops.gemm_flags(unit=2, splitk=3)]
         for f in variants:
             try:
@@ -781,7 +783,7 @@ def test_gemv_batch_kernel_vs_oracle(ops, oracle, K, N):
             assert ops.last_kernel() == "gemv_batch" and torch.equal(ya, ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt))
         else:
             assert ops.last_kernel() in ("gemv_rows", "gemv_nk"), ops.last_kernel()
-    for M in (5, 16, 20, 64):
+    for M in (5, 16, 20, 64, 100):
         e = torch.zeros((M, K), dtype=torch.float16, device="cuda")
         ks = (torch.arange(M, device="cuda") * 977 + K - 5) % K
         e[torch.arange(M, device="cuda"), ks] = 1.0
@@ -1150,10 +1152,10 @@ def test_gemvfast_layout_vs_oracle(ops, oracle, K, N, g, M):
 def test_gemvfast_batch_kernel_vs_oracle(ops, oracle, K, N):
     """csrc/gemv_batch.hip in its GEMVFast form (round 5: the batched kernel on qweight int16 [N/4, K], scales / qzeros fp16 [GP, N]; the
     reference runs awq_v2_ext.gemm_forward_cuda_prefill there, gemv_fast.py:203-206): 7B and 70B-shard shapes, one and several passes
-    over K, few tiles, every ring form, batches 5 .. 96 (chunked above 32); against the oracle's W = fp16(w s + qzeros) and fp32 product;
+    over K, few tiles, every ring form, batches 1 .. 128 (round 6: one launch, 33 .. 128 rows as two / four row parts of a block); against the oracle's W = fp16(w s + qzeros) and fp32 product;
     one-hot rows select rows of the bit-exact W^T; bitwise reproducible."""
     g = 128
-    qw, sc, qz, xall = gemvfast_case(K, N, g, 96, seed=K + 3 * N)
+    qw, sc, qz, xall = gemvfast_case(K, N, g, 128, seed=K + 3 * N)
     W = oracle.dequant_gemvfast(qw.numpy(), sc.numpy(), qz.numpy(), g)
     qwc, scc, qzc, xc = qw.cuda(), sc.cuda(), qz.cuda(), xall.cuda()
     Wt = ops.dequantize_weights_gemv_fast(qwc, scc, qzc, g)
@@ -1161,11 +1163,11 @@ def test_gemvfast_batch_kernel_vs_oracle(ops, oracle, K, N):
     wsig_all = oracle.weight_rounding_sigma(xall.numpy(), W)
     yex_all = oracle.matmul_exact_gemvfast(xall.numpy(), qw.numpy(), sc.numpy(), qz.numpy(), g)  # (unpinned in the reference itself: autoawq-kernels)
     bt = ops.gemm_flags(kernel=GEMV_KERNEL_BATCH)
-    for M in ([1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 32, 33, 64, 96] if K * N <= 4096 * 11008 else [1, 4, 5, 16, 32, 64]):
-        x = xc[96 - M:]
-        y32, wsig = y32_all[96 - M:], wsig_all[96 - M:]
+    for M in ([1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 32, 33, 64, 65, 96, 127, 128] if K * N <= 4096 * 11008 else [1, 4, 5, 16, 32, 64, 128]):
+        x = xc[128 - M:]
+        y32, wsig = y32_all[128 - M:], wsig_all[128 - M:]
         # beside the 6-sigma-widened bound below: within 1 ulp + 1e-4 rms of the EXACT product w s + qzeros
-        assert_close_to_exact(ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt).cpu().numpy(), yex_all[96 - M:], f"batch-fast K{K} N{N} M{M} vs exact")
+        assert_close_to_exact(ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt).cpu().numpy(), yex_all[128 - M:], f"batch-fast K{K} N{N} M{M} vs exact")
         for f in ([0, ops.gemm_flags(splitk=1), ops.gemm_flags(splitk=2)] if M in (1, 5, 16, 17, 32) else [0]):
             y = ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)
             assert ops.last_kernel() == "gemv_batch_fast"
