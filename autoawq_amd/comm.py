@@ -82,7 +82,10 @@ class OneShotAllReduce:
         device = torch.device(device)
         with torch.cuda.device(device):
             st = _DeviceBytes(L.awq_allreduce_staging_bytes(max_halfs))
-            fl = _DeviceBytes(L.awq_allreduce_flag_bytes())
+            # the flag blocks of rounds 3-4 are unused since the protocol became a push of self-validating granules (round 5); the C ABI
+            # keeps the argument ("pass any mapped buffer"): the staging buffer itself is passed -- no second allocation, no second IPC
+            # mapping per peer
+            fl = st
             state = torch.zeros(L.awq_allreduce_state_bytes(), dtype=torch.uint8, device=device)
         return st, fl, state
 
@@ -119,13 +122,13 @@ class OneShotAllReduce:
         try:
             st, fl, state = cls._alloc(max_halfs, device)
             torch.cuda.synchronize(device)
-            mine = (st.ipc_handle(), st.nbytes, fl.ipc_handle(), fl.nbytes)
+            mine = (st.ipc_handle(), st.nbytes)
         except Exception as e:  # noqa: BLE001 -- reported to every rank below
             err = e
         agree(mine is not None, "allocation / IPC export", err)
         everyone = [None] * world
         dist.all_gather_object(everyone, mine, group=group)
-        staging, flags, keep, err = [], [], [st, fl], None
+        staging, flags, keep, err = [], [], [st], None
 
         def view(b):
             """the tensor view of a mapping must BE the mapping: torch infers the device of a raw pointer from the driver, and for a
@@ -139,13 +142,9 @@ class OneShotAllReduce:
 
         try:
             with torch.cuda.device(device):
-                for r, (hs, ns, hf, nf) in enumerate(everyone):
-                    if r == rank:
-                        staging.append(view(st))
-                        flags.append(view(fl))
-                    else:
-                        staging.append(view(_DeviceBytes(ns, handle=hs)))
-                        flags.append(view(_DeviceBytes(nf, handle=hf)))
+                for r, (hs, ns) in enumerate(everyone):
+                    staging.append(view(st) if r == rank else view(_DeviceBytes(ns, handle=hs)))
+                flags = staging  # (unused by the kernel: see _alloc)
         except Exception as e:  # noqa: BLE001
             err = e
         agree(err is None, "mapping the peers' buffers", err)

@@ -52,7 +52,12 @@ AWQ_DEV unsigned long long ld_sys_u64(const unsigned long long* p) {
 }
 
 __global__ __launch_bounds__(256) void awq_allreduce_oneshot_kernel(ArParams p) {
+    // ONE bounded wait per block, not per granule and source: the first thread whose spin gives up raises s_late, every
+    // later spin of the block sees it and gives up at once -- a dead peer costs a launch ~one spin bound, not granules-per-thread of them
+    __shared__ uint32_t s_late;
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_late = 0u;
+    __syncthreads();
     const int rank = p.rank0 + blockIdx.y;
     uint32_t* const state = p.state[blockIdx.y];
     const uint32_t e = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -79,7 +84,8 @@ __global__ __launch_bounds__(256) void awq_allreduce_oneshot_kernel(ArParams p) 
             const unsigned long long* src = mine + (long long)r * src_stride + g;
             unsigned long long v = ld_sys_u64(src);
             for (uint32_t spins = 0; (uint32_t)(v >> 32) != e; ++spins) {
-                if (spins > p.max_spin) {
+                if (spins > p.max_spin || *reinterpret_cast<volatile uint32_t*>(&s_late)) {
+                    *reinterpret_cast<volatile uint32_t*>(&s_late) = 1u;
                     __hip_atomic_store(state + 1, 1u + (uint32_t)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     late = true;
                     break;
