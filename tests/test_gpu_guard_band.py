@@ -15,7 +15,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.guard_skip]
 # the kernel-facing tests (every HIP kernel family, BASELINE shapes + ragged ones, M = 1 ... 16 and prefill sizes); the
 # whole suite runs under the same allocator by tools/guard_run.sh (profiles/r04_fault_hunt/)
 SUBSET = ("test_gemv_rows_kernel_vs_oracle or test_gemv_rows_block_fusions or config4 or dequant or unpack or gemv_lds or gemvfast or "
-          "test_gemm_vs_oracle_all_variants or attention or rmsnorm or rope or silu or moe or chain or gemv_batch or repack")
+          "test_gemm_vs_oracle_all_variants or attention or rmsnorm or rope or silu or moe or chain or gemv_batch or repack or "
+          "gemvfast_layout_prefill_route or route_a_replay")
 # default selection: one placement (flush against the END of the mapping: an over-read past an operand, the usual failure) of a compact
 # subset -- one family each; AWQ_FULL_MATRIX=1: both placements of the whole subset (135 s each on an MI355X; round 5: the driver's
 # suite is held near three minutes)
@@ -23,6 +24,7 @@ SUBSET = ("test_gemv_rows_kernel_vs_oracle or test_gemv_rows_block_fusions or co
 #  would be -- not the other large ones)
 COMPACT = ("(test_gemv_rows_kernel_vs_oracle and (4096-4096-128 or 11008-4096-128 or 4096-4099 or 384-7 or 1280-10 or 2048-200 or 256-16)) or "
            "(test_gemv_batch_kernel_vs_oracle and (4096-11008 or 11008-4096 or 2048-4099 or 16512-72 or 256-16 or 1024-200)) or "
+           "(test_gemvfast_layout_prefill_route_vs_oracle and (1-1024-200 or 1-512-64 or 1-4096-4096)) or "  # round 6: the FZ form + its repack, ragged N
            "test_gemv_batch_refuses or repack or prefill_attention or test_decode_attention_vs_oracle or unpack or "
            "test_dequant_golden or test_gemm_golden or test_moe_block_vs_oracle or rmsnorm or rope_kv or test_gemvfast_layout_golden")
 
