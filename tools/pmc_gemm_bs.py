@@ -72,7 +72,7 @@ def per_group(d, counter):
             continue
         if any(k in name for k in ("awq_gemv", "awq_gemm")):
             acc[cur][0] += float(r["Counter_Value"])
-            acc[cur][2].add(name.split("<")[0].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", ""))
+            acc[cur][2].add(name.replace("void ", "").replace("(anonymous namespace)::", "").split("<")[0].split("(")[0])
     return acc
 
 

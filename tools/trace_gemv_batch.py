@@ -56,7 +56,7 @@ def child(name):
     gen = torch.Generator(device=dev).manual_seed(3)
     st = torch.cuda.Stream(device=dev)
     BATCH = 5
-    cases = [(4096, 11008, 8, 1, 1), (4096, 11008, 8, 1, 2), (4096, 11008, 16, 1, 2), (4096, 11008, 32, 1, 2), (4096, 11008, 32, 2, 2), (11008, 4096, 8, 1, 2)]
+    cases = [(4096, 11008, 8, 1, 2), (4096, 11008, 32, 1, 2), (4096, 11008, 64, 1, 2), (4096, 11008, 128, 1, 2), (11008, 4096, 64, 1, 2)]  # (round 6: 64 / 128 rows = two / four row parts)
     for K, N, M, gw, rd in cases:  # gw: the activations' form (1 = LDS staging area, 2 = direct fragment loads)
         nsets = 28
         mats = [bench.rand_packed_nk(K, N, 128, dev, gen) for _ in range(nsets)]
