@@ -37,7 +37,7 @@ def gemm_forward_cuda_prefill(x, qweight, scales, qzeros):
     K, N = x.shape[-1], qweight.shape[0] * 4
     x2 = x.reshape(-1, K)
     g = infer_group_size(K, scales.shape[0])
-    if (x2.shape[0] <= 64 or (x2.shape[0] <= 96 and g == 128 and K % 128 == 0)) and N % 16 == 0:
+    if (x2.shape[0] <= 64 or (x2.shape[0] <= 128 and K <= 4096 and g == 128 and K % 128 == 0)) and N % 16 == 0:
         return ops.gemv_fast_forward(x2, qweight, scales, qzeros, g).reshape(x.shape[:-1] + (N,))
     from .modules.linear.gemv import prefill_route
 

@@ -36,13 +36,14 @@ def dequant_matmul_nk(x2d, wt):
 # M in launches of <= 32 rows, each streaming the matrix once -- three launches still beat the repack route at 4096 x 11008: 37 vs 50 us,
 # profiles/r05_prefill_routes.txt, r05_gemv_batch_sweep_final.txt; the reference switches to its batched kernel at 8 rows: gemv.py:168).
 # Above it: PREFILL_IMPL.
-PREFILL_MIN_ROWS = 97
+PREFILL_MIN_ROWS = 129
 
 
 def prefill_min_rows(in_features):
-    """Rows from which a call leaves the batched-decode kernel (launches of <= 32 rows): 97 while one pass of a block covers K
-    (K <= 4096: three launches still beat every prefill route at 4096 x 11008), 65 beyond (several passes per launch: at 11008 x 4096
-    96 rows cost ~65 us against ~55 for the prefill routes -- profiles/r06_prefill_routes.txt)."""
+    """Rows from which a call leaves the batched-decode kernel (round 6: ONE launch per <= 128 rows): 129 while one pass of a block's
+    waves covers K (K <= 4096: 128 rows cost 37 us at 4096 x 11008 against 51 / 58 for the prefill routes), 65 beyond (several passes
+    per row part: at 11008 x 4096 64 rows cost 37 us against 48 - 51, 96 rows more than the ~55 of the prefill routes --
+    profiles/r06_prefill_routes.txt, r06_gemv_batch_trace.txt)."""
     return PREFILL_MIN_ROWS if in_features <= 4096 else 65
 
 

@@ -7,8 +7,8 @@ Drop-in contract kept (reference gemv_fast.py:68-208):
     qzeros [8*ZW, N] fp16 = -(scale*zero), bias [N] fp16 | None;
   * from_linear(linear, w_bit, group_size, init_only=False, scales=None, zeros=None);
   * forward needs a 3-D input [batch, tokens, K] (gemv_fast.py:190), bias added afterwards.
-The reference picks its decode kernel for batch < 8 and one token, its prefill GEMM otherwise (gemv_fast.py:191-206); here up to 96
-rows run the batched decode kernel on the layout's own buffers (csrc/gemv_batch.hip, GEMVFast form; csrc/gemv_fast.hip for group
+The reference picks its decode kernel for batch < 8 and one token, its prefill GEMM otherwise (gemv_fast.py:191-206); here up to 128
+rows (64 for K > 4096) run the batched decode kernel on the layout's own buffers (csrc/gemv_batch.hip, GEMVFast form; csrc/gemv_fast.hip for group
 sizes other than 128), and prefill-sized inputs the hand-written pair `awq_gemv_fast_prefill` (round 6): the packed words transposed
 into a temporary of the call (csrc/repack.hip) + the register-decoded MFMA GEMM with this format's own scales / fp16 zero terms
 (csrc/gemm_regb.hip, FZ form) -- `PREFILL_IMPL = "fused"`.  The default, "auto", takes that pair where it measures ahead of or
@@ -23,7 +23,7 @@ from .gemv import dequant_matmul_nk, prefill_min_rows, prefill_route
 
 # up to this many rows: the decode / batched-decode kernels (round 5: csrc/gemv_batch.hip in its GEMVFast form, launches of <= 32 rows, group
 # size 128; other group sizes: 16 rows, csrc/gemv_fast.hip); above: dequantise + dense GEMM
-PREFILL_MIN_ROWS = 97
+PREFILL_MIN_ROWS = 129  # (gemv.prefill_min_rows: 129 while K <= 4096, 65 beyond)
 
 
 class WQLinear_GEMVFast(torch.nn.Module):
