@@ -420,8 +420,8 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
         for (int64_t m0 = 0; m0 < M; m0 += rows) {
             const int mm = (int)(M - m0 < rows ? M - m0 : rows);
             const int rc = awq_launch_gemv_batch(x + m0 * K, qweight, scales, qzeros, y + m0 * N, mm, (int)K, (int)N, (int)group_size,
-                                                 (int)zeros_width, (int)AWQ_GEMM_FLAG_UNIT(flags), (int)AWQ_GEMM_FLAG_SPLITK(flags),
-                                                 static_cast<hipStream_t>(stream));
+                                                 (int)zeros_width, (int)(AWQ_GEMM_FLAG_UNIT(flags) | (AWQ_GEMM_FLAG_WAVES(flags) << 4)),
+                                                 (int)AWQ_GEMM_FLAG_SPLITK(flags), static_cast<hipStream_t>(stream));
             if (rc != AWQ_OK) return rc;
         }
         return AWQ_OK;
@@ -510,7 +510,8 @@ int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint1
         for (int64_t m0 = 0; m0 < M; m0 += rows) {
             const int mm = (int)(M - m0 < rows ? M - m0 : rows);
             const int rc = awq_launch_gemv_batch_fast(x + m0 * K, qweight, scales, qzeros, y + m0 * N, mm, (int)K, (int)N, (int)group_size,
-                                                      (int)group_rows, (int)AWQ_GEMM_FLAG_SPLITK(flags), static_cast<hipStream_t>(stream));
+                                                      (int)group_rows, (int)((AWQ_GEMM_FLAG_SPLITK(flags) & 15u) | (AWQ_GEMM_FLAG_WAVES(flags) << 4)),
+                                                      static_cast<hipStream_t>(stream));
             if (rc != AWQ_OK) return rc;
         }
         return AWQ_OK;

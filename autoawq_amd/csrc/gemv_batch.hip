@@ -69,6 +69,8 @@ struct BatchParams {
     int ring_off, pbuf_off, pbuf_pitch, ystage_off;  // LDS byte offsets; pbuf_pitch: bytes per wave (XS: the wave's staging area)
     int xs_rows;     // XS: batch rows the staging area holds at a time (min(M, 8): more rows arrive in chunks of eight)
     int rs, rows_part;  // round 6: ROW PARTS -- the wt wave groups of a block are (wt / rs tile owners) x (rs row parts of rows_part <= 32 batch rows)
+    int brs;            // ... or brs row parts ACROSS blocks (blocks of one XCD that walk the same tiles for different batch rows; rs == 1 then)
+    int ys_in_area;     // 1: the parked tiles live in the dead tail of the waves' staging areas (three 1-KiB slots per area) instead of a region of their own
     int GP;          // FAST (GEMVFast layout): rows of scales / qzeros [GP, N]
     unsigned long long* trace;             // debug builds only (tools/trace_gemv_batch.py)
 };
@@ -153,10 +155,20 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     // profiles/r06_pmc_gemm_bs.txt had 2.0 / 2.9 / 3.8 x for the 2 / 3 / 4 launches of 64 / 96 / 128 rows), and K is walked in rs x as
     // many passes (wk = 8 / wt waves side by side on a tile).
     const int rsi = twi % p.rs, toi = twi / p.rs;  // row part, tile owner of the block
-    const int row_base = rsi * p.rows_part;        // first batch row of this wave group
+    // Row parts ACROSS blocks (brs > 1, the default above 32 rows): the activations a CU pulls through its L2 port are M K 2 / brs bytes
+    // instead of all M K 2 (at 64 rows x 4096 k: 512 KB per CU against 88 KB of weights -- the activations, not the matrix, were the
+    // launch's L2 -> CU traffic, staged twice because a part's K range then needed two passes); the brs blocks that walk the same tiles
+    // are brs consecutive residents of ONE XCD (block ids b, b + 8, ..: the dispatcher deals blocks to the eight XCDs round robin), so
+    // their weight requests meet in that XCD's L2 (FETCH_SIZE 1.10 x algorithmic at 64 rows; with neighbouring block ids, i.e.
+    // different XCDs, it was 1.94 x: profiles/r06_batch_parts.txt).
+    const int bq = (int)blockIdx.x >> 3;
+    const int bpart = p.brs > 1 ? bq % p.brs : 0;
+    const int oblock = p.brs > 1 ? (bq / p.brs) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+    const int nob = (int)gridDim.x / p.brs;                     // blocks with different tiles
+    const int row_base = (bpart * p.rs + rsi) * p.rows_part;    // first batch row of this wave group
     const int M = max(0, min(p.rows_part, p.M - row_base));
     // owner = the wk waves that share tiles; owner ids interleave the blocks (consecutive owners sit on different CUs)
-    const int owner = toi * (int)gridDim.x + (int)blockIdx.x;
+    const int owner = toi * nob + oblock;
     const int t0 = owner * p.tiles_base + min(owner, p.tiles_rem);
     const int ntile = p.tiles_base + (owner < p.tiles_rem ? 1 : 0);
     const int nunit = ntile * p.passes;  // live units of this wave, flat: u = pass * ntile + tile
@@ -164,7 +176,11 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     const int rowbytes = p.KW * 4;
     const int xs_w = p.pbuf_off + wave * p.pbuf_pitch;  // XS: this wave's staging area [M][1 KiB]; later its partial-tile buffers
 #ifdef AWQ_GEMV_TRACE
-    unsigned long long ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 12 .. 15: time spent waiting / requesting / consuming / exchanging
+    unsigned long long tph = 0;
+#define BT_PHASE(slot) do { const unsigned long long now_ = wall_clock64(); ts[slot] += now_ - tph; tph = now_; } while (0)
+#else
+#define BT_PHASE(slot) do { } while (0)
 #endif
     BT_STAMP(0);
 
@@ -357,7 +373,14 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     BT_STAMP(1);
 
     // ---- stream
-    float4_t* ystage = reinterpret_cast<float4_t*>(smem + p.ystage_off);  // [wt][tiles_max][MI][64 lanes]
+    // parked tiles [wt][tiles_max][MI] x 64 lanes x float4: a region of their own, or (one pass, many tiles per owner: the region would
+    // cost the ring its second slot) 1-KiB slots in the tail of the waves' staging areas, dead once every wave has its fragments -- the
+    // first slot is written behind the first tile's exchange barrier, which every wave reaches after its own staging
+    auto yslot = [&](int s) {
+        const int a = s / 3;
+        const int off = p.ys_in_area ? p.pbuf_off + a * p.pbuf_pitch + 4608 + (s - 3 * a) * 1024 : p.ystage_off + s * 1024;
+        return reinterpret_cast<float4_t*>(smem + off);
+    };
     auto pbuf = [&](int w, int parity, int mi) { return reinterpret_cast<float4_t*>(smem + p.pbuf_off + w * p.pbuf_pitch + (parity * MI + mi) * 1024); };
     int u = 0, it = 0;  // live units requested so far; iterations (the parity of the partial-tile buffer)
     for (int ps = 0; ps < p.passes; ++ps) {
@@ -373,12 +396,18 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             float4_t acc[MI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi] = float4_t{0.f, 0.f, 0.f, 0.f};
+#ifdef AWQ_GEMV_TRACE
+            tph = wall_clock64();
+#endif
             if (live) {
                 if constexpr (LAZY) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only this piece was in flight
+                    BT_PHASE(12);
                     request(u + 1);  // (its slot was read out before the previous iteration ended)
+                    BT_PHASE(13);
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM * (RD - 1)) : "memory");
+                    BT_PHASE(12);
                 }
 #ifdef AWQ_GEMV_TRACE
                 if (u < 3) ts[4 + 2 * u] = wall_clock64();
@@ -424,6 +453,16 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 } else if constexpr (AWQ_BT_DBG & 2) {
 #pragma unroll
                     for (int uu = 0; uu < GW; ++uu) acc[0] += __builtin_bit_cast(float4_t, wq[uu]) + __builtin_bit_cast(float4_t, sq) + (float)zw;
+                    if constexpr (AWQ_BT_DBG & 8) __builtin_amdgcn_s_sleep(21);  // (the consumption's duration without its instructions)
+                } else if constexpr (AWQ_BT_DBG & 16) {  // the MFMAs on undecoded words: no decode VALU
+#pragma unroll
+                    for (int uu = 0; uu < GW; ++uu)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const u32x4 b = {wq[uu][c], wq[uu][(c + 1) & 3], sq[c], zw};
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma16(afr[(mi * GW + uu) * 4 + c], b, acc[mi]);
+                        }
                 } else
 #pragma unroll
                 for (int uu = 0; uu < GW; ++uu) {
@@ -445,6 +484,9 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                         b[1] = h22u(u2h2(and_or(ww, 0x00F000F0u, 0x54005400u)) - zhi);
                         b[2] = h22u(u2h2(and_or(w8, 0x000F000Fu, 0x64006400u)) - zlo);
                         b[3] = h22u(u2h2(and_or(w8, 0x00F000F0u, 0x54005400u)) - zhi);
+                        if constexpr (AWQ_BT_DBG & 32) {  // the decode without the MFMAs
+                            gacc[0] += __builtin_bit_cast(float4_t, b);
+                        } else
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) gacc[mi] = mfma16(afr[(mi * GW + uu) * 4 + c], b, gacc[mi]);
                     }
@@ -454,7 +496,11 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                         for (int r = 0; r < 4; ++r) acc[mi][r] = __builtin_fmaf(sc, gacc[mi][r], acc[mi][r]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the slot has returned before it is overwritten
-                if constexpr (!LAZY) request(u + RD);
+                BT_PHASE(14);
+                if constexpr (!LAZY) {
+                    request(u + RD);
+                    BT_PHASE(13);
+                }
 #ifdef AWQ_GEMV_TRACE
                 if (u < 3) ts[5 + 2 * u] = wall_clock64();
 #endif
@@ -473,17 +519,21 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                         const int mi = f >> 6, sl = f & 63;
                         float4_t s = pbuf(twi * p.wk, it & 1, mi)[sl];
                         for (int j = 1; j < p.wk; ++j) s += pbuf(twi * p.wk + j, it & 1, mi)[sl];
-                        float4_t* dst = ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64 + sl;
+                        float4_t* dst = yslot((twi * p.tiles_max + tl) * MI + mi) + sl;
                         *dst = ps > 0 ? *dst + s : s;
                     }
                 }
             } else if (live) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    float4_t* dst = ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64 + lane;
+                    float4_t* dst = yslot((twi * p.tiles_max + tl) * MI + mi) + lane;
                     *dst = ps > 0 ? *dst + acc[mi] : acc[mi];
                 }
             }
+#ifdef AWQ_GEMV_TRACE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            BT_PHASE(15);
+#endif
         }
     }
     BT_STAMP(10);
@@ -495,7 +545,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
         const int row0 = (t0 + tl) * 16;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const float* src = reinterpret_cast<const float*>(ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64);
+            const float* src = reinterpret_cast<const float*>(yslot((twi * p.tiles_max + tl) * MI + mi));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int item = lane + 64 * q, ml = item >> 4, nn = item & 15;
@@ -508,24 +558,29 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     BT_STAMP(11);
     if (p.trace && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) p.trace[((size_t)blockIdx.x * 8 + wave) * 12 + i] = ts[i];
+        for (int i = 0; i < 16; ++i) p.trace[((size_t)blockIdx.x * 8 + wave) * 16 + i] = ts[i];
     }
 #endif
 }
 
 struct BatchPlan {
-    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max, rs, rows_part;
+    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max, rs, rows_part, brs, ys_in_area;
     size_t ring, pbuf_pitch, ystage;
 };
 
 // form: 0 = auto, 1 = activations through the LDS staging area (XS), 2 = direct fragment loads
 bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out, bool fast = false) {
     if (M < 1 || M > 128 || N < 1 || K < 128 || K % 128 || g != 128) return false;
+    const int parts_req = (form >> 4) & 15;         // 0 = auto, 1 = every part inside the block, 2 .. 4 = that many parts across blocks
+    form &= 15;
     if (fast && (N % 16 || form == 2)) return false;  // GEMVFast: whole 4-row bundles, staged form only
     if ((int64_t)N * K / 2 >= ((int64_t)1 << 31) || (int64_t)M * K * 2 >= ((int64_t)1 << 31)) return false;  // 32-bit lane offsets
     BatchPlan b;
-    b.rs = M > 64 ? 4 : (M > 32 ? 2 : 1);          // row parts of at most 32 rows (balanced: 33 rows = 17 + 16)
-    b.rows_part = (M + b.rs - 1) / b.rs;
+    const int nparts = M > 64 ? 4 : (M > 32 ? 2 : 1);  // row parts of at most 32 rows (balanced: 33 rows = 17 + 16)
+    b.brs = parts_req >= 2 ? parts_req : (parts_req == 1 ? 1 : nparts);
+    b.rs = b.brs > 1 ? 1 : nparts;
+    b.rows_part = (M + b.rs * b.brs - 1) / (b.rs * b.brs);
+    if (b.rows_part > 32) return false;
     const int MP = b.rows_part;                     // rows a wave group holds
     b.MI = MP > 16 ? 2 : 1;
     const int G = K / 128;
@@ -537,8 +592,13 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     const int tiles = (N + 15) / 16;
     const int towners = b.wt / b.rs;                // tile owners per block
     const int want = (tiles + towners - 1) / towners;
-    b.blocks = want < 256 ? want : 256;
-    const int owners = b.blocks * towners;
+    int nob = want < 256 ? want : 256;              // blocks with different tiles
+    if (b.brs > 1) {                                // whole rounds of the eight XCDs, brs residents of an XCD per tile list
+        const int q = (want + 7) / 8 < 32 / b.brs ? (want + 7) / 8 : 32 / b.brs;
+        nob = 8 * q;
+    }
+    b.blocks = nob * b.brs;
+    const int owners = nob * towners;
     b.tiles_base = tiles / owners;
     b.tiles_rem = tiles % owners;
     b.tiles_max = b.tiles_base + (b.tiles_rem ? 1 : 0);
@@ -550,6 +610,13 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     const int rows = MP < 8 ? MP : 8;
     size_t staged = (size_t)rows * 1024 > plain ? (size_t)rows * 1024 : plain;
     if (fast && staged < (size_t)4096 + 256 * b.MI) staged = (size_t)4096 + 256 * b.MI;  // (the group sums sit behind the partial-tile buffers)
+    // the parked tiles move into the staging areas' tails where their own region would cost the ring its second slot (see the kernel)
+    b.ys_in_area = 0;
+    if (form != 2 && b.passes == 1 && wk > 1 && staged >= 8192 && b.wt * b.tiles_max * b.MI <= 24 &&
+        b.ystage + 8 * staged + (size_t)16 * PIECE_B > budget) {
+        b.ys_in_area = 1;
+        b.ystage = 0;
+    }
     const bool xs = form != 2 && b.ystage + 8 * staged + (size_t)8 * PIECE_B <= budget;
     if ((form == 1 || fast) && !xs) return false;
     b.XS = xs ? 1 : 0;
@@ -599,7 +666,7 @@ int launch_batch(const void* x, const void* qweight, const void* scales, const v
     p.pbuf_off = (int)b.ring;
     p.pbuf_pitch = (int)b.pbuf_pitch;
     p.xs_rows = b.xs_rows;
-    p.rs = b.rs; p.rows_part = b.rows_part;
+    p.rs = b.rs; p.rows_part = b.rows_part; p.brs = b.brs; p.ys_in_area = b.ys_in_area;
     p.ystage_off = (int)(b.ring + 8 * b.pbuf_pitch);
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_batch_trace;
@@ -640,6 +707,8 @@ bool awq_gemv_batch_fast_supports(int M, int K, int N, int g) {
 int awq_launch_gemv_batch_fast(const uint16_t* x, const int16_t* qweight, const uint16_t* scales, const uint16_t* qzeros, uint16_t* y,
                                int M, int K, int N, int g, int group_rows, int depth, hipStream_t st) {
     if (group_rows < K / 128) return AWQ_ERR_BAD_SHAPE;
+    const int parts = (depth >> 4) & 15;  // (row parts across blocks: see plan_batch)
+    depth &= 15;
     if (depth > 2) depth = 2;
-    return launch_batch(x, qweight, scales, qzeros, y, M, K, N, g, 0, group_rows, 0, depth, true, st);
+    return launch_batch(x, qweight, scales, qzeros, y, M, K, N, g, 0, group_rows, parts << 4, depth, true, st);
 }

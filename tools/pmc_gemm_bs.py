@@ -41,7 +41,7 @@ def run():
                     if layout == "gemm":
                         ops.gemm_forward(x, qw, sc, qz)
                     else:
-                        ops.gemv_forward(x, qw, sc, qz, 128)
+                        ops.gemv_forward(x, qw, sc, qz, 128, flags=int(os.environ.get("AWQ_PMC_GEMV_FLAGS", "0"), 0))
             torch.cuda.synchronize()
             print(f"{layout} M={M}: kernel {ops.last_kernel()}", flush=True)
         del sets

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "autoawq_amd", "csrc")
 BIN = os.path.join(ROOT, "tools", "bin")
-VARIANTS = {"trace": ["-DAWQ_GEMV_TRACE"], "dbg1": ["-DAWQ_BT_DBG=1"], "dbg2": ["-DAWQ_BT_DBG=2"], "dbg4": ["-DAWQ_BT_DBG=4"], "dbg7": ["-DAWQ_BT_DBG=7"],
-            "dbg3": ["-DAWQ_BT_DBG=3"]}
+VARIANTS = {"trace": ["-DAWQ_GEMV_TRACE"], "trace6": ["-DAWQ_GEMV_TRACE", "-DAWQ_BT_DBG=6"], "trace14": ["-DAWQ_GEMV_TRACE", "-DAWQ_BT_DBG=14"], "trace4": ["-DAWQ_GEMV_TRACE", "-DAWQ_BT_DBG=4"], "dbg1": ["-DAWQ_BT_DBG=1"], "dbg2": ["-DAWQ_BT_DBG=2"], "dbg4": ["-DAWQ_BT_DBG=4"], "dbg7": ["-DAWQ_BT_DBG=7"],
+            "dbg3": ["-DAWQ_BT_DBG=3"], "dbg14": ["-DAWQ_BT_DBG=14"], "dbg20": ["-DAWQ_BT_DBG=20"], "dbg36": ["-DAWQ_BT_DBG=36"], "dbg6": ["-DAWQ_BT_DBG=6"]}
 
 
 def lib_path(name):
@@ -69,9 +69,9 @@ def child(name):
 
         us = bench.graph_time(f, st, reps=10, min_seconds=0.1) / len(mats)
         print(f"[{name}] K={K} N={N} M={M} form={'xs' if gw == 1 else 'direct'} rd={rd}: {us:.2f} us", flush=True)
-        if name == "trace":
+        if name.startswith("trace"):
             L.awq_debug_set_trace_batch.argtypes = [ctypes.c_void_p]
-            trace = torch.zeros(256 * 8 * 12, dtype=torch.int64, device=dev)
+            trace = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
             for qw, qz, sc in mats[:-1]:
                 ops.gemv_forward(x, qw, sc, qz, 128, flags=fl)
             torch.cuda.synchronize()
@@ -80,8 +80,10 @@ def child(name):
             ops.gemv_forward(x, qw, sc, qz, 128, flags=fl)
             torch.cuda.synchronize()
             L.awq_debug_set_trace_batch(None)
-            t = trace.cpu().numpy().reshape(-1, 12).astype(np.float64)
+            t = trace.cpu().numpy().reshape(-1, 16).astype(np.float64)
             t = t[t[:, 0] != 0]
+            phases = t[:, 12:] / 100.0  # accumulated us per wave over its units
+            t = t[:, :12]
             t0 = t[:, 0].min()
             t = np.where(t > 0, (t - t0) / 100.0, np.nan)  # wall_clock64: 100 MHz
 
@@ -93,6 +95,9 @@ def child(name):
             print(f"   {t.shape[0]} waves, absolute us since the first wave started (p0 p10 p50 p90 p100):")
             for i, nm in enumerate(names):
                 print(f"   {nm:36s}: {q(t[:, i])}")
+            print("   per wave, summed over its units (us):")
+            for i, nm in enumerate(["waiting for the piece", "requesting", "consuming (LDS reads, decode, MFMA)", "partial-tile exchange (barrier)"]):
+                print(f"   {nm:36s}: {q(phases[:, i])}")
         del mats
         torch.cuda.empty_cache()
 
@@ -105,5 +110,6 @@ if __name__ == "__main__":
     if "--build-only" in sys.argv:
         print("built", ", ".join(VARIANTS))
         sys.exit(0)
-    for name in VARIANTS:
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    for name in (only[0] if only else VARIANTS):
         subprocess.call([sys.executable, os.path.abspath(__file__), "--child", name])
