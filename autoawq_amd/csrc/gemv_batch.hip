@@ -70,7 +70,6 @@ struct BatchParams {
     int xs_rows;     // XS: batch rows the staging area holds at a time (min(M, 8): more rows arrive in chunks of eight)
     int rs, rows_part;  // round 6: ROW PARTS -- the wt wave groups of a block are (wt / rs tile owners) x (rs row parts of rows_part <= 32 batch rows)
     int brs;            // ... or brs row parts ACROSS blocks (blocks of one XCD that walk the same tiles for different batch rows; rs == 1 then)
-    int ys_in_area;     // 1: the parked tiles live in the dead tail of the waves' staging areas (three 1-KiB slots per area) instead of a region of their own
     int GP;          // FAST (GEMVFast layout): rows of scales / qzeros [GP, N]
     unsigned long long* trace;             // debug builds only (tools/trace_gemv_batch.py)
 };
@@ -373,14 +372,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     BT_STAMP(1);
 
     // ---- stream
-    // parked tiles [wt][tiles_max][MI] x 64 lanes x float4: a region of their own, or (one pass, many tiles per owner: the region would
-    // cost the ring its second slot) 1-KiB slots in the tail of the waves' staging areas, dead once every wave has its fragments -- the
-    // first slot is written behind the first tile's exchange barrier, which every wave reaches after its own staging
-    auto yslot = [&](int s) {
-        const int a = s / 3;
-        const int off = p.ys_in_area ? p.pbuf_off + a * p.pbuf_pitch + 4608 + (s - 3 * a) * 1024 : p.ystage_off + s * 1024;
-        return reinterpret_cast<float4_t*>(smem + off);
-    };
+    float4_t* ystage = reinterpret_cast<float4_t*>(smem + p.ystage_off);  // [wt][tiles_max][MI][64 lanes]
     auto pbuf = [&](int w, int parity, int mi) { return reinterpret_cast<float4_t*>(smem + p.pbuf_off + w * p.pbuf_pitch + (parity * MI + mi) * 1024); };
     int u = 0, it = 0;  // live units requested so far; iterations (the parity of the partial-tile buffer)
     for (int ps = 0; ps < p.passes; ++ps) {
@@ -519,14 +511,14 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                         const int mi = f >> 6, sl = f & 63;
                         float4_t s = pbuf(twi * p.wk, it & 1, mi)[sl];
                         for (int j = 1; j < p.wk; ++j) s += pbuf(twi * p.wk + j, it & 1, mi)[sl];
-                        float4_t* dst = yslot((twi * p.tiles_max + tl) * MI + mi) + sl;
+                        float4_t* dst = ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64 + sl;
                         *dst = ps > 0 ? *dst + s : s;
                     }
                 }
             } else if (live) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    float4_t* dst = yslot((twi * p.tiles_max + tl) * MI + mi) + lane;
+                    float4_t* dst = ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64 + lane;
                     *dst = ps > 0 ? *dst + acc[mi] : acc[mi];
                 }
             }
@@ -545,7 +537,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
         const int row0 = (t0 + tl) * 16;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const float* src = reinterpret_cast<const float*>(yslot((twi * p.tiles_max + tl) * MI + mi));
+            const float* src = reinterpret_cast<const float*>(ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int item = lane + 64 * q, ml = item >> 4, nn = item & 15;
@@ -564,7 +556,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 }
 
 struct BatchPlan {
-    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max, rs, rows_part, brs, ys_in_area;
+    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max, rs, rows_part, brs;
     size_t ring, pbuf_pitch, ystage;
 };
 
@@ -577,7 +569,14 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     if ((int64_t)N * K / 2 >= ((int64_t)1 << 31) || (int64_t)M * K * 2 >= ((int64_t)1 << 31)) return false;  // 32-bit lane offsets
     BatchPlan b;
     const int nparts = M > 64 ? 4 : (M > 32 ? 2 : 1);  // row parts of at most 32 rows (balanced: 33 rows = 17 + 16)
-    b.brs = parts_req >= 2 ? parts_req : (parts_req == 1 ? 1 : nparts);
+    // AUTO (profiles/r06_batch_parts.txt): the parts go ACROSS blocks -- two up to 64 rows, three up to 96 where the tile lists are long
+    // (N > 4096: 240 blocks with 27 - 32 rows each beat 256 blocks with 20 - 24), else four; 17 .. 32 rows also split in two where a
+    // block would own a single tile (N <= 4096: 8.3 vs 9.6 us at 4096 x 4096, 19.8 vs 21.6 at 11008 x 4096, M = 32)
+    const int tiles_all = (N + 15) / 16;
+    int auto_brs = nparts;
+    if (M > 64 && M <= 96 && tiles_all > 256) auto_brs = 3;
+    if (M > 16 && M <= 32 && tiles_all <= 256) auto_brs = 2;
+    b.brs = parts_req >= 2 ? parts_req : (parts_req == 1 ? 1 : auto_brs);
     b.rs = b.brs > 1 ? 1 : nparts;
     b.rows_part = (M + b.rs * b.brs - 1) / (b.rs * b.brs);
     if (b.rows_part > 32) return false;
@@ -610,20 +609,16 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     const int rows = MP < 8 ? MP : 8;
     size_t staged = (size_t)rows * 1024 > plain ? (size_t)rows * 1024 : plain;
     if (fast && staged < (size_t)4096 + 256 * b.MI) staged = (size_t)4096 + 256 * b.MI;  // (the group sums sit behind the partial-tile buffers)
-    // the parked tiles move into the staging areas' tails where their own region would cost the ring its second slot (see the kernel)
-    b.ys_in_area = 0;
-    if (form != 2 && b.passes == 1 && wk > 1 && staged >= 8192 && b.wt * b.tiles_max * b.MI <= 24 &&
-        b.ystage + 8 * staged + (size_t)16 * PIECE_B > budget) {
-        b.ys_in_area = 1;
-        b.ystage = 0;
-    }
     const bool xs = form != 2 && b.ystage + 8 * staged + (size_t)8 * PIECE_B <= budget;
     if ((form == 1 || fast) && !xs) return false;
     b.XS = xs ? 1 : 0;
     b.xs_rows = rows;
     b.pbuf_pitch = xs ? staged : plain;
     const size_t fixed = b.ystage + 8 * b.pbuf_pitch;
-    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : 2;
+    // ring slots, AUTO: two (lazy) up to 32 rows on the GEMV layout; ONE with row parts across blocks and on the GEMVFast layout -- the
+    // per-wave phase times (profiles/r06_gemv_batch_trace.txt) show no wave ever waiting for a piece there: a unit is bound by what
+    // the two waves of a SIMD issue (requests, decode, MFMA, exchange), and the one-slot form issues less (1 - 2 % / 1.5 - 5 % faster)
+    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : ((b.brs > 1 || fast) ? 1 : 2);
     while (rd > 1 && fixed + (size_t)8 * rd * PIECE_B > budget) --rd;
     if (fixed + (size_t)8 * rd * PIECE_B > budget) return false;
     b.RD = rd;
@@ -666,7 +661,7 @@ int launch_batch(const void* x, const void* qweight, const void* scales, const v
     p.pbuf_off = (int)b.ring;
     p.pbuf_pitch = (int)b.pbuf_pitch;
     p.xs_rows = b.xs_rows;
-    p.rs = b.rs; p.rows_part = b.rows_part; p.brs = b.brs; p.ys_in_area = b.ys_in_area;
+    p.rs = b.rs; p.rows_part = b.rows_part; p.brs = b.brs;
     p.ystage_off = (int)(b.ring + 8 * b.pbuf_pitch);
 #ifdef AWQ_GEMV_TRACE
     p.trace = g_batch_trace;

@@ -769,11 +769,17 @@ def test_gemv_batch_kernel_vs_oracle(ops, oracle, K, N):
         # fragment loads (unit=2), ring depths 1 .. 3
         variants = [0] if M not in (5, 8, 12, 16, 17, 32, 64, 128) else [0, ops.gemm_flags(unit=1, splitk=1), ops.gemm_flags(unit=1, splitk=2),
                                                                     ops.gemm_flags(unit=2, splitk=1), ops.gemm_flags(unit=2, splitk=2), ops.gemm_flags(unit=2, splitk=3)]
+        # the row parts (round 6): inside the block (waves=1) or across 2 / 3 / 4 blocks of one XCD (refused where a part would exceed 32 rows)
+        if M in (17, 24, 32, 33, 48, 64, 65, 80, 96, 100, 127, 128):
+            variants = variants + [ops.gemm_flags(waves=w) for w in (1, 2, 3, 4)]
         for f in variants:
             try:
                 y = ops.gemv_forward(x, qwc, scc, qzc, g, flags=bt | f)
             except Exception as e:
-                assert "code -3" in str(e) and ((f >> 20) & 0xF) == 1 and M > 8, (e, M, f)  # the staged form: only where M KiB per wave fit
+                w = (f >> 24) & 0xF
+                staged_refused = ((f >> 20) & 0xF) == 1 and M > 8  # the staged form: only where M KiB per wave fit
+                parts_refused = (w >= 2 and (M + w - 1) // w > 32) or (w == 1 and M > 32)  # (in-block parts: where their tile lists overflow LDS)
+                assert "code -3" in str(e) and (staged_refused or parts_refused), (e, M, f)
                 continue
             assert ops.last_kernel() == "gemv_batch"
             assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"batch K{K} N{N} M{M} f{f:x}", wsigma=wsig)
@@ -1168,14 +1174,24 @@ def test_gemvfast_batch_kernel_vs_oracle(ops, oracle, K, N):
         y32, wsig = y32_all[128 - M:], wsig_all[128 - M:]
         # beside the 6-sigma-widened bound below: within 1 ulp + 1e-4 rms of the EXACT product w s + qzeros
         assert_close_to_exact(ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt).cpu().numpy(), yex_all[128 - M:], f"batch-fast K{K} N{N} M{M} vs exact")
-        for f in ([0, ops.gemm_flags(splitk=1), ops.gemm_flags(splitk=2)] if M in (1, 5, 16, 17, 32) else [0]):
-            y = ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)
+        # forced forms: ring slots 1 | 2; row parts inside the block (waves=1) or across 2 / 3 / 4 blocks of an XCD (refused where a part
+        # would exceed 32 rows)
+        forms = [0, ops.gemm_flags(splitk=1), ops.gemm_flags(splitk=2)] if M in (1, 5, 16, 17, 32) else [0]
+        if M in (17, 32, 33, 64, 96, 127, 128):
+            forms += [ops.gemm_flags(waves=w) for w in (1, 2, 3, 4)]
+        for f in forms:
+            try:
+                y = ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)
+            except Exception as e:
+                w = (f >> 24) & 0xF
+                assert "code -3" in str(e) and (w == 1 and M > 32 or w >= 2 and (M + w - 1) // w > 32), (e, M, f)  # (in-block parts: where their tile lists overflow LDS)
+                continue
             assert ops.last_kernel() == "gemv_batch_fast"
             assert_product_close(y.cpu().numpy().astype(np.float64), y32, f"batch-fast K{K} N{N} M{M} f{f:x}", wsigma=wsig)
             assert torch.equal(y, ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt | f)), "not bitwise reproducible"
         ya = ops.gemv_fast_forward(x, qwc, scc, qzc, g)
         if M >= 5 or 2048 < K <= 4096:  # AUTO takes it
-            assert ops.last_kernel() == "gemv_batch_fast" and torch.equal(ya, y)
+            assert ops.last_kernel() == "gemv_batch_fast" and torch.equal(ya, ops.gemv_fast_forward(x, qwc, scc, qzc, g, flags=bt))
         else:
             assert ops.last_kernel() == "gemv_fast"
     for M in (5, 16, 20):

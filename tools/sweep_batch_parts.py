@@ -14,10 +14,9 @@ import bench  # noqa: E402
 from autoawq_amd import ops  # noqa: E402
 
 BATCH = 5
-UNIT = int(os.environ.get("AWQ_SWEEP_UNIT", "0"))  # 8: the blocks of a tile list are neighbours in block id (experiment)
 ROWS = (8, 16, 24, 32, 33, 48, 64, 80, 96, 128)
-# (row parts: 0 = auto, 1 = inside the block, 2 .. 4 = across blocks; ring: 0 = auto (two slots, lazy), 1 = one slot, 4 = two slots, eager)
-CONFIGS = ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (0, 4), (1, 4), (2, 4), (4, 4), (0, 1))
+# (row parts: 0 = auto, 1 = inside the block, 2 .. 4 = across blocks of one XCD; ring slots per wave: 0 = auto, 1 = one, 2 = two (lazy))
+CONFIGS = ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (0, 2))
 
 
 def main():
@@ -33,7 +32,7 @@ def main():
             ref = x.float() @ wt.t()
             for parts, depth in CONFIGS:
                 try:
-                    y = ops.gemv_forward(x, qw, sc, qz, 128, flags=ops.gemm_flags(kernel=BATCH, waves=parts, splitk=depth, unit=UNIT))
+                    y = ops.gemv_forward(x, qw, sc, qz, 128, flags=ops.gemm_flags(kernel=BATCH, waves=parts, splitk=depth))
                 except Exception as e:
                     assert "code -3" in str(e), e
                     continue
@@ -52,7 +51,7 @@ def main():
             x = torch.randn((M, K), device=dev, generator=gen).half()
             line = []
             for parts, depth in CONFIGS:
-                fl = ops.gemm_flags(kernel=BATCH, waves=parts, splitk=depth, unit=UNIT)
+                fl = ops.gemm_flags(kernel=BATCH, waves=parts, splitk=depth)
 
                 def f():
                     for qw, qz, sc in mats:
@@ -64,6 +63,38 @@ def main():
                     line.append(f"p{parts}d{depth}    - ")
             print(f"K={K} N={N} M={M:3d}: " + "  ".join(line), flush=True)
         del mats
+    # the same kernel on the GEMVFast layout's buffers
+    for K, N in ([(4096, 11008)] if quick else [(4096, 11008), (4096, 4096), (11008, 4096)]):
+        qw, qz, sc = bench.rand_packed_nk(K, N, 128, dev, gen, fast=True)
+        wt = ops.dequantize_weights_gemv_fast(qw, sc, qz, 128).float()
+        nsets = max(4, min(28, int(640e6 / (K * N / 2))))
+        mats = [bench.rand_packed_nk(K, N, 128, dev, gen, fast=True) for _ in range(nsets)]
+        for M in (1, 2, 4) + ROWS:
+            x = (torch.randn((M, K), device=dev, generator=gen) * 0.5).half()
+            ref = x.float() @ wt.t()
+            line = []
+            for parts, depth in CONFIGS:
+                fl = ops.gemm_flags(kernel=BATCH, waves=parts, splitk=depth)
+                try:
+                    y = ops.gemv_fast_forward(x, qw, sc, qz, 128, flags=fl)
+                except Exception as e:
+                    assert "code -3" in str(e), e
+                    line.append(f"p{parts}d{depth}    - ")
+                    continue
+                err = (y.float() - ref).abs()
+                ok = bool((err <= ref.abs() * 2.0 ** -9 + 2e-2).all()) and bool(torch.isfinite(y).all())
+                bad += not ok
+                if not ok:
+                    print(f"MISMATCH fast K={K} N={N} M={M} parts={parts} depth={depth}: max err {float(err.max()):.4g}")
+
+                def f():
+                    for a, b, c in mats:
+                        ops.gemv_fast_forward(x, a, c, b, 128, flags=fl)
+                us = bench.graph_time(f, st, reps=10, min_seconds=0.1) / len(mats)
+                line.append(f"p{parts}d{depth} {us:6.2f}")
+            print(f"fast K={K} N={N} M={M:3d}: " + "  ".join(line), flush=True)
+        del mats
+    print("check (incl. GEMVFast):", "FAILED" if bad else "all within tolerance")
     return 1 if bad else 0
 
 
