@@ -37,9 +37,11 @@ def gemm_forward_cuda_prefill(x, qweight, scales, qzeros):
     K, N = x.shape[-1], qweight.shape[0] * 4
     x2 = x.reshape(-1, K)
     g = infer_group_size(K, scales.shape[0])
-    if (x2.shape[0] <= 64 or (x2.shape[0] <= 128 and K <= 4096 and g == 128 and K % 128 == 0)) and N % 16 == 0:
+    from .modules.linear.gemv import prefill_min_rows, prefill_route
+
+    # (the batched-decode kernel in launches of <= 128 rows while it measures ahead of the prefill routes: gemv.prefill_min_rows)
+    if (x2.shape[0] <= 64 or (x2.shape[0] < prefill_min_rows(K) and g == 128 and K % 128 == 0)) and N % 16 == 0:
         return ops.gemv_fast_forward(x2, qweight, scales, qzeros, g).reshape(x.shape[:-1] + (N,))
-    from .modules.linear.gemv import prefill_route
 
     out = None
     if prefill_route(x2.shape[0], K, N) == "hand":

@@ -410,8 +410,9 @@ int awq_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* 
     }
     const int auto_k = kern == AWQ_GEMV_KERNEL_AUTO ? awq_gemv_auto_kernel(M, K, N, group_size) : -1;
     if (kern == AWQ_GEMV_KERNEL_BATCH || auto_k == (int)AWQ_GEMV_KERNEL_BATCH) {
-        // one launch per <= 128 rows (round 6: up to four 32-row parts share a tile's weights inside a block); where the parts do not fit
-        // the LDS budget (very long tile lists per block) 32-row launches as before
+        // one launch per <= 128 rows (round 6: up to four row parts of <= 32 rows, each in its own block, the blocks of a tile list
+        // residents of one XCD so that the matrix is fetched from HBM once); where the parts do not fit the LDS budget (very long
+        // tile lists per block) launches of fewer rows
         int64_t cap = 128;
         while (cap > 32 && !awq_gemv_batch_supports((int)(M > cap ? cap : M), (int)K, (int)N, (int)group_size)) cap /= 2;
         if (!awq_gemv_batch_supports((int)(M > cap ? cap : M), (int)K, (int)N, (int)group_size)) return AWQ_ERR_UNSUPPORTED;
@@ -496,7 +497,7 @@ int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint1
     // round 5: from five rows the batched kernel (gemv_batch.hip, GEMVFast form: any M in launches of <= 32 rows); AWQ_GEMM_FLAG_KERNEL:
     // 0 = auto, 1 = the 16-row kernel (gemv_fast.hip, M <= 16), AWQ_GEMV_KERNEL_BATCH = the batched kernel
     const uint32_t kern = AWQ_GEMM_FLAG_KERNEL(flags);
-    int64_t fcap = 128;  // rows per launch (round 6: row parts, see gemv_batch.hip)
+    int64_t fcap = 128;  // rows per launch (round 6: row parts across blocks, see gemv_batch.hip)
     while (fcap > 32 && !awq_gemv_batch_fast_supports((int)(M > fcap ? fcap : M), (int)K, (int)N, (int)group_size)) fcap /= 2;
     const bool batch_ok = awq_gemv_batch_fast_supports((int)(M > fcap ? fcap : M), (int)K, (int)N, (int)group_size);
     // below five rows AUTO takes it where ONE pass of eight waves covers K (2048 < K <= 4096): there it is ahead of the 16-row kernel at

@@ -1,4 +1,4 @@
-// gemv_batch.hip -- batched decode (5 <= M <= 128 per launch) on the GEMV layout: weights stream through LDS by DMA into MFMA,
+// gemv_batch.hip -- batched decode (1 <= M <= 128 per launch) on the GEMV / GEMVFast layouts: weights stream through LDS by DMA into MFMA,
 // the activations live in REGISTERS as MFMA A fragments, the K range of a tile is split over the waves of ONE block, gfx950.
 //
 // Replaces awq_ext.gemmv2_forward_cuda (awq/modules/linear/gemv.py:168-176: the reference's kernel for more than 8 rows on
@@ -40,8 +40,13 @@
 //    inside the stream would break the counted waits: stores count in vmcnt but do not retire in order with loads).
 //  * K beyond one pass (8 waves x 512 k) is walked in PASSES: the A fragments of the next K range are re-requested (a drain: they
 //    queue behind the ring), the ring keeps running across the pass edge, partial sums add up in the parked tiles.
-//  * M > 32 (round 6): still ONE launch up to 128 rows -- the wave groups of a block become ROW PARTS of <= 32 rows on the same tiles
-//    (see the kernel head); beyond 128 rows the C API walks chunks of <= 128.
+//  * M > 32 (round 6): still ONE launch up to 128 rows -- ROW PARTS of <= 32 rows, each part in its own block, the blocks that walk the
+//    same tiles residents of one XCD (see the kernel head; the first form -- the parts as wave groups of one block -- stays
+//    selectable: AWQ_GEMM_FLAG_WAVES = 1); beyond 128 rows the C API walks balanced chunks of <= 128.
+//  * What bounds a unit (tile x pass) is not memory: the per-wave phase times of the -DAWQ_GEMV_TRACE build show ~0 us spent waiting
+//    for a piece; the two waves of a SIMD issue ~0.75 us each per unit (requests, decode VALU, 32 MFMAs at MI 2, exchange) and do not
+//    overlap much (MFMA-only + decode-only switch-off runs add up to the full cost): profiles/r06_gemv_batch_trace.txt.  Hence ONE
+//    ring slot wherever the parts are used (a second one bought nothing and cost issue slots).
 #include <type_traits>
 
 #include "awq_device.h"
@@ -148,11 +153,10 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     const int n = lane & 15, kq = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     const int wki = wave % p.wk, twi = wave / p.wk;
-    // Round 6 (one launch for 33 .. 128 rows, the matrix streamed ONCE): the wave groups of a block that used to own
-    // different tiles can instead own the SAME tiles for different 32-row PARTS of the batch (rs = 2 | 4): a part's A fragments still fit
-    // the registers (MI <= 2), the parts' weight requests for a tile go out within the same microsecond and meet in L2 (HBM traffic 1 x:
-    // profiles/r06_pmc_gemm_bs.txt had 2.0 / 2.9 / 3.8 x for the 2 / 3 / 4 launches of 64 / 96 / 128 rows), and K is walked in rs x as
-    // many passes (wk = 8 / wt waves side by side on a tile).
+    // Round 6 (one launch for 33 .. 128 rows, the matrix streamed ONCE), first form (rs = 2 | 4, kept selectable):
+    // the wave groups of a block that used to own different tiles own the SAME tiles for different 32-row PARTS of the batch; K is
+    // then walked in rs x as many passes (wk = 8 / wt waves side by side on a tile) and every block stages ALL of x: 21 / 35 / 37 us at
+    // 64 / 96 / 128 rows of 4096 x 11008, against 19 / 25 / 29 for the parts across blocks below.
     const int rsi = twi % p.rs, toi = twi / p.rs;  // row part, tile owner of the block
     // Row parts ACROSS blocks (brs > 1, the default above 32 rows): the activations a CU pulls through its L2 port are M K 2 / brs bytes
     // instead of all M K 2 (at 64 rows x 4096 k: 512 KB per CU against 88 KB of weights -- the activations, not the matrix, were the

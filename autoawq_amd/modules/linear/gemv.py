@@ -36,15 +36,16 @@ def dequant_matmul_nk(x2d, wt):
 # M in launches of <= 32 rows, each streaming the matrix once -- three launches still beat the repack route at 4096 x 11008: 37 vs 50 us,
 # profiles/r05_prefill_routes.txt, r05_gemv_batch_sweep_final.txt; the reference switches to its batched kernel at 8 rows: gemv.py:168).
 # Above it: PREFILL_IMPL.
-PREFILL_MIN_ROWS = 129
+PREFILL_MIN_ROWS = 257
 
 
 def prefill_min_rows(in_features):
-    """Rows from which a call leaves the batched-decode kernel (round 6: ONE launch per <= 128 rows): 129 while one pass of a block's
-    waves covers K (K <= 4096: 128 rows cost 37 us at 4096 x 11008 against 51 / 58 for the prefill routes), 65 beyond (several passes
-    per row part: at 11008 x 4096 64 rows cost 37 us against 48 - 51, 96 rows more than the ~55 of the prefill routes --
-    profiles/r06_prefill_routes.txt, r06_gemv_batch_trace.txt)."""
-    return PREFILL_MIN_ROWS if in_features <= 4096 else 65
+    """Rows from which a call leaves the batched-decode kernel (csrc/gemv_batch.hip: one launch per <= 128 rows, the row parts across
+    blocks of one XCD; more rows in balanced launches): 257 while one pass of a block's waves covers K (K <= 4096: at 4096 x 11008
+    128 / 192 / 256 rows cost 31 / 52 / 63 us against 52 / 58 / 66 for dequantise + dense GEMM, 384 rows 89 against 67), 193 beyond
+    (11008 x 4096: 128 / 192 rows 42 / 78 us against 62 / 83 for the best prefill route, 256 rows 82 against 70) --
+    profiles/r06_prefill_routes.txt; ADVICE r05."""
+    return PREFILL_MIN_ROWS if in_features <= 4096 else 193
 
 
 def prefill_route(rows, in_features, out_features):

@@ -23,7 +23,7 @@ from .gemv import dequant_matmul_nk, prefill_min_rows, prefill_route
 
 # up to this many rows: the decode / batched-decode kernels (round 5: csrc/gemv_batch.hip in its GEMVFast form, launches of <= 32 rows, group
 # size 128; other group sizes: 16 rows, csrc/gemv_fast.hip); above: dequantise + dense GEMM
-PREFILL_MIN_ROWS = 129  # (gemv.prefill_min_rows: 129 while K <= 4096, 65 beyond)
+PREFILL_MIN_ROWS = 257  # (gemv.prefill_min_rows: 257 while K <= 4096, 193 beyond)
 
 
 class WQLinear_GEMVFast(torch.nn.Module):

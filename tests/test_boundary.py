@@ -347,7 +347,7 @@ def test_auto_dispatch_table_host_only():
 def test_prefill_route_policy_is_a_pure_function_of_shape_and_rows():
     """modules/linear/gemv.py::prefill_route / prefill_min_rows (round 6, ADVICE r05): the hand-written pair only where it measured
     ahead of or level with dequantise + dense GEMM (profiles/r06_prefill_routes.txt) -- from 3072 rows on matrices at least as wide
-    as tall; the batched-decode kernel (one launch per <= 128 rows) up to 128 rows while one pass covers K, 64 beyond.  Both modules and the awq_v2_ext shim use it."""
+    as tall; the batched-decode kernel (one launch per <= 128 rows) up to 256 rows while one pass covers K, 192 beyond.  Both modules and the awq_v2_ext shim use it."""
     from autoawq_amd.modules.linear.gemv import PREFILL_MIN_ROWS, WQLinear_GEMV, prefill_min_rows, prefill_route
     from autoawq_amd.modules.linear.gemv_fast import WQLinear_GEMVFast
 
@@ -355,4 +355,4 @@ def test_prefill_route_policy_is_a_pure_function_of_shape_and_rows():
     assert prefill_route(16384, 4096, 11008) == "hand" and prefill_route(4096, 4096, 11008) == "hand" and prefill_route(3072, 4096, 4096) == "hand"
     assert prefill_route(2048, 4096, 11008) == "two_pass" and prefill_route(128, 4096, 11008) == "two_pass"
     assert prefill_route(16384, 11008, 4096) == "two_pass"  # the tall (down-projection) shape: the vendor GEMM runs at 0.60 of peak there
-    assert prefill_min_rows(4096) == PREFILL_MIN_ROWS == 129 and prefill_min_rows(11008) == 65 and prefill_min_rows(8192) == 65
+    assert prefill_min_rows(4096) == PREFILL_MIN_ROWS == 257 and prefill_min_rows(11008) == 193 and prefill_min_rows(8192) == 193

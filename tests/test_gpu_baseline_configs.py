@@ -213,7 +213,9 @@ def test_gemv_layout_prefill_kernel_vs_oracle(ops, oracle, K, N, M, bm):
 
         mod = WQLinear_GEMV(4, 128, K, N, False, "cuda")
         mod.qweight, mod.qzeros, mod.scales = dq, dz, ds
-        from autoawq_amd.modules.linear.gemv import PREFILL_MIN_ROWS
+        from autoawq_amd.modules.linear.gemv import prefill_min_rows
+
+        PREFILL_MIN_ROWS = prefill_min_rows(K)
 
         # the module's routes: below PREFILL_MIN_ROWS the batched-decode kernel; from there "repack" (default: csrc/repack.hip + the
         # fused MFMA GEMM on the temporary), "two_pass" (dequantise + dense GEMM) or "fused" (this kernel)
