@@ -45,8 +45,8 @@
 //    selectable: AWQ_GEMM_FLAG_WAVES = 1); beyond 128 rows the C API walks balanced chunks of <= 128.
 //  * What bounds a unit (tile x pass) is not memory: the per-wave phase times of the -DAWQ_GEMV_TRACE build show ~0 us spent waiting
 //    for a piece; the two waves of a SIMD issue ~0.75 us each per unit (requests, decode VALU, 32 MFMAs at MI 2, exchange) and do not
-//    overlap much (MFMA-only + decode-only switch-off runs add up to the full cost): profiles/r06_gemv_batch_trace.txt.  Hence ONE
-//    ring slot wherever the parts are used (a second one bought nothing and cost issue slots).
+//    overlap much (MFMA-only + decode-only switch-off runs add up to the full cost): profiles/r06_gemv_batch_trace.txt.  Ring depth
+//    therefore hardly matters (one slot and two lazy ones within 1 - 3 %), and the successor unit's request is division- and branch-free.
 #include <type_traits>
 
 #include "awq_device.h"
@@ -188,13 +188,12 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     BT_STAMP(0);
 
     // ---- request flat unit u into ring slot u % RD (past the end: clamped addresses -- the counted waits need the requests)
-    auto request = [&](int u) {
-        const bool live = u < nunit;
-        const int uu = live ? u : 0;
-        const int nt1 = max(ntile, 1);
-        const int ps = uu / nt1, tl = uu - ps * nt1;
+    //      request_at: unit u = (pass ps, tile tl) given by the caller (the stream knows its successor without a division); a dead unit
+    //      re-reads the owner's first piece (valid memory, nobody consumes it)
+    auto request_at = [&](int u, int ps_u, int tl_u, bool live) {
+        const int ps = live ? ps_u : 0, tl = live ? tl_u : 0;
         const int g0 = (ps * p.wk + wki) * GW;
-        const int row0 = live ? (t0 + tl) * 16 : 0;
+        const int row0 = (ntile > 0 ? t0 + tl : 0) * 16;
         const uint32_t slot = lds0 + (uint32_t)(ring + (u % RD) * PIECE_B);
         if constexpr (FAST) {
             const int rb2 = p.K * 2;  // bytes of an int16 row
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 const int kqq = ((lane >> 2) & 3) ^ T[i];
                 const int off = 256 * (lane >> 4) + 128 * (kqq >> 1) + 32 * (lane & 3) + 16 * (kqq & 1);
                 const int byte = min(256 * g0 + off, rb2 - 16);
-                const uint32_t voff = live ? (uint32_t)(min((row0 >> 2) + i, (p.N >> 2) - 1) * rb2 + byte) : 0u;
+                const uint32_t voff = (uint32_t)(min((row0 >> 2) + i, (p.N >> 2) - 1) * rb2 + byte);
                 AWQ_BT_DMA16(voff, p.qweight, slot + 1024u * i);
             }
             // scales / qzeros of groups g0 .. g0 + 3 for the tile's 16 rows: 32 bytes per group, lane l: group (l >> 3) & 3, dword l & 7
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             const int r = i * 4 + (lane >> 4);  // row of the tile (four rows of 256 bytes per instruction)
             const int c = ((lane & 15) ^ r) & 15;
             const int byte = min(g0 * 64 + 16 * c, rowbytes - 16);  // past the row end (a ragged or dead piece): its last chunk (A is 0 there)
-            const uint32_t voff = live ? (uint32_t)(min(row0 + r, p.N - 1) * rowbytes + byte) : 0u;
+            const uint32_t voff = (uint32_t)(min(row0 + r, p.N - 1) * rowbytes + byte);
             AWQ_BT_DMA16(voff, p.qweight, slot + 1024u * i);
         }
         {
@@ -229,6 +228,14 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             const int zword = min(g0 >> 3, p.ZW - 1);
             AWQ_BT_DMA4((uint32_t)((r * p.ZW + zword) * 4), p.qzeros, slot + (uint32_t)(PIECE_W + 1024));
         }
+    };
+
+    auto request = [&](int u) {
+        const bool live = u < nunit;
+        const int uu = live ? u : 0;
+        const int nt1 = max(ntile, 1);
+        const int ps = uu / nt1;
+        request_at(u, ps, uu - ps * nt1, live);
     };
 
     // ---- activations of pass ps -> A fragments in registers (pair-permuted), zero for batch rows >= M and groups >= G.
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 if constexpr (LAZY) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only this piece was in flight
                     BT_PHASE(12);
-                    request(u + 1);  // (its slot was read out before the previous iteration ended)
+                    request_at(u + 1, tl + 1 < ntile ? ps : ps + 1, tl + 1 < ntile ? tl + 1 : 0, u + 1 < nunit);  // (its slot was read out before the previous iteration ended)
                     BT_PHASE(13);
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM * (RD - 1)) : "memory");
@@ -494,7 +501,8 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the slot has returned before it is overwritten
                 BT_PHASE(14);
                 if constexpr (!LAZY) {
-                    request(u + RD);
+                    if constexpr (RD == 1) request_at(u + 1, tl + 1 < ntile ? ps : ps + 1, tl + 1 < ntile ? tl + 1 : 0, u + 1 < nunit);
+                    else request(u + RD);
                     BT_PHASE(13);
                 }
 #ifdef AWQ_GEMV_TRACE
@@ -619,10 +627,10 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     b.xs_rows = rows;
     b.pbuf_pitch = xs ? staged : plain;
     const size_t fixed = b.ystage + 8 * b.pbuf_pitch;
-    // ring slots, AUTO: two (lazy) up to 32 rows on the GEMV layout; ONE with row parts across blocks and on the GEMVFast layout -- the
-    // per-wave phase times (profiles/r06_gemv_batch_trace.txt) show no wave ever waiting for a piece there: a unit is bound by what
-    // the two waves of a SIMD issue (requests, decode, MFMA, exchange), and the one-slot form issues less (1 - 2 % / 1.5 - 5 % faster)
-    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : ((b.brs > 1 || fast) ? 1 : 2);
+    // ring slots, AUTO: two (lazy) wherever they fit, else one -- the per-wave phase times (profiles/r06_gemv_batch_trace.txt) show no
+    // wave waiting for a piece in either form: a unit is bound by what the two waves of a SIMD issue (requests, decode, MFMA, exchange);
+    // one slot and two measure within 1 - 3 % of each other (profiles/r06_batch_parts.txt)
+    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : 2;
     while (rd > 1 && fixed + (size_t)8 * rd * PIECE_B > budget) --rd;
     if (fixed + (size_t)8 * rd * PIECE_B > budget) return false;
     b.RD = rd;
