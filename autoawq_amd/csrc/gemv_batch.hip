@@ -72,7 +72,7 @@ struct BatchParams {
     int passes;      // ceil(G / (wk * GW))
     int tiles_base, tiles_rem, tiles_max;  // tiles per owner: base (+1 for the first rem owners)
     int ring_off, pbuf_off, pbuf_pitch, ystage_off;  // LDS byte offsets; pbuf_pitch: bytes per wave (XS: the wave's staging area)
-    int xs_rows;     // XS: batch rows the staging area holds at a time (min(M, 8 | 12): more rows arrive in chunks of that many)
+    int xs_rows;     // XS: batch rows the staging area holds at a time (min(M, 8): more rows arrive in chunks of eight)
     int rs, rows_part;  // round 6: ROW PARTS -- the wt wave groups of a block are (wt / rs tile owners) x (rs row parts of rows_part <= 32 batch rows)
     int brs;            // ... or brs row parts ACROSS blocks (blocks of one XCD that walk the same tiles for different batch rows; rs == 1 then)
     int GP;          // FAST (GEMVFast layout): rows of scales / qzeros [GP, N]
@@ -142,9 +142,8 @@ AWQ_DEV int xs_f(int m) { return ((m & 3) << 2) | ((m >> 2) & 3); }
 // half kq % 2) of its row, step c its dword c -- so the A fragment of step c is dword c of each of the lane's four activation chunks:
 // one 4 x 4 dword transpose per pass, no pair permute.  Nibbles decode to 16 + w (exponent 2^4), the group folds y += s (acc - 16 sx) + qzeros sx with sx = sum of x over the
 // group (one ones-MFMA chain per pass, parked in LDS), the arithmetic of csrc/gemv_fast.hip.
-template <int MI, int RD, bool XS, bool FAST = false, int CH = 8>
+template <int MI, int RD, bool XS, bool FAST = false>
 __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
-    static_assert(CH == 8 || (CH == 12 && MI == 2 && XS && RD == 1), "twelve-row chunks: 32-row parts, one ring slot");
     static_assert(!FAST || XS, "the GEMVFast form keeps its group sums in the staging area");
     constexpr int NA = MI * GW * 4;  // A fragments (16 bytes each) per lane
     constexpr bool LAZY = RD == 2;
@@ -281,63 +280,57 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
         constexpr bool FIRST = decltype(first_piece_c)::value;  // pass 0: nothing older is in flight, the ring starts here
         const int g0 = (ps * p.wk + wki) * GW;
         if constexpr (XS) {
-            // chunks of CH (8 | 12) batch rows through the staging area: one coalesced 1-KiB instruction per row (the wave's 512 k of it),
-            // swizzled on the global side; a chunk is requested once the previous one has been read.  A chunk that holds a 16-row tile's
-            // first rows defines the tile's fragment registers (every lane takes what it reads); later chunks of the tile merge into the
-            // lanes of their rows.  CH = 12 (round 6, one ring slot instead of two): 32 rows in three round trips instead of four.
-            constexpr int ROWS = 16 * MI, NCH = (ROWS + CH - 1) / CH;
+            // chunks of eight batch rows through the staging area (rows 16 mi + 8 half ..): one coalesced 1-KiB instruction per row (the
+            // wave's 512 k of it), swizzled on the global side; a chunk is requested once the previous one has been read
 #pragma unroll
-            for (int ci = 0; ci < NCH; ++ci) {
-                // (straight-line on purpose: a wave-uniform skip of an absent chunk made hipcc keep two copies of the fragment registers;
-                //  an absent chunk requests nothing, reads stale bytes and merges nothing)
-                const int r0 = ci * CH;
-                const int r1e = r0 + CH < ROWS ? r0 + CH : ROWS;
-                const int r1 = max(min(r1e, M), r0 + 1);
-                const bool present = r0 < M;
-                for (int m = r0; m < r1 && present; ++m) {
-                    const int j = (lane & 48) | ((lane & 15) ^ xs_f(m));
-                    const int byte = min(256 * g0 + 16 * j, p.K * 2 - 16);
-                    AWQ_BT_DMA16((uint32_t)((row_base + m) * p.K * 2 + byte), p.x, lds0 + (uint32_t)(xs_w + (m - r0) * 1024));
-                }
-                if (FIRST && ci == 0) {
-                    request(0);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM) : "memory");  // the chunk is older than the piece
-                } else if (present) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int tr = 16 * mi;  // the tile's first row
-                    if (r0 >= tr + 16 || r1e <= tr) continue;  // (chunk and tile apart: folds away)
-                    const int m = min(max(tr + n, r0), r1 - 1);  // (lanes of other chunks / of rows >= M read some row of the chunk)
-                    const int f = xs_f(m);
-                    if (r0 <= tr) {  // every lane takes what it reads (lanes of later chunks: overwritten by them, or zeroed below)
-                        const unsigned char* row = smem + xs_w + (m - r0) * 1024;
-#pragma unroll
-                        for (int u = 0; u < GW; ++u)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                afr[(mi * GW + u) * 4 + c] = *reinterpret_cast<const u32x4*>(row + 16 * (16 * u + ((4 * kq + c) ^ f)));
-                    } else {  // the lanes of the chunk's rows only (none if the chunk is absent)
-                        const int lo = r0 - tr, hi = (r1e < tr + 16 ? r1e : tr + 16) - tr;
-                        const unsigned long long mask = present ? (unsigned long long)((1u << hi) - (1u << lo)) * 0x0001000100010001ull : 0ull;
-                        unsigned long long save;  // (an SGPR pair each statement uses as scratch)
-                        const uint32_t rb = lds0 + (uint32_t)(xs_w + (m - r0) * 1024);
-                        uint32_t ad[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) ad[c] = rb + 16u * (uint32_t)((4 * kq + c) ^ f);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 0) * 4 + c], ad[c], 0, mask, save);
-                            AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 1) * 4 + c], ad[c], 256, mask, save);
-                            AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 2) * 4 + c], ad[c], 512, mask, save);
-                            AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 3) * 4 + c], ad[c], 768, mask, save);
-                        }
-                        AWQ_BT_LGKM16(afr, mi * 16);
+                for (int half = 0; half < 2; ++half) {
+                    // (straight-line on purpose: a wave-uniform skip of an absent chunk made hipcc keep two copies of the fragment registers;
+                    //  an absent chunk requests nothing, reads stale bytes and merges nothing)
+                    const int r0 = 16 * mi + 8 * half;
+                    const int r1 = max(min(r0 + 8, M), r0 + 1);
+                    const bool present = r0 < M;
+                    for (int m = r0; m < r1 && present; ++m) {
+                        const int j = (lane & 48) | ((lane & 15) ^ xs_f(m));
+                        const int byte = min(256 * g0 + 16 * j, p.K * 2 - 16);
+                        AWQ_BT_DMA16((uint32_t)((row_base + m) * p.K * 2 + byte), p.x, lds0 + (uint32_t)(xs_w + (m - r0) * 1024));
                     }
+                    if (FIRST && mi == 0 && half == 0) {
+                        request(0);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LDM) : "memory");  // the chunk is older than the piece
+                    } else if (present) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    const int m = min(max(16 * mi + n, r0), r1 - 1);  // (lanes of the other half / of rows >= M read some row of the chunk)
+                    const int f = xs_f(m);
+                    {
+                        if (half == 0) {  // every lane takes what it reads (lanes 8-15: overwritten by the second half, or zeroed below)
+                            const unsigned char* row = smem + xs_w + (m - r0) * 1024;
+#pragma unroll
+                            for (int u = 0; u < GW; ++u)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    afr[(mi * GW + u) * 4 + c] = *reinterpret_cast<const u32x4*>(row + 16 * (16 * u + ((4 * kq + c) ^ f)));
+                        } else {  // lanes 8-15 of every 16 only (none if the chunk is absent)
+                            const unsigned long long mask = present ? 0xFF00FF00FF00FF00ull : 0ull;
+                            unsigned long long save;  // (an SGPR pair each statement uses as scratch)
+                            const uint32_t rb = lds0 + (uint32_t)(xs_w + (m - r0) * 1024);
+                            uint32_t ad[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) ad[c] = rb + 16u * (uint32_t)((4 * kq + c) ^ f);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 0) * 4 + c], ad[c], 0, mask, save);
+                                AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 1) * 4 + c], ad[c], 256, mask, save);
+                                AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 2) * 4 + c], ad[c], 512, mask, save);
+                                AWQ_BT_LDS_READ16_MASKED(afr[(mi * GW + 3) * 4 + c], ad[c], 768, mask, save);
+                            }
+                            AWQ_BT_LGKM16(afr, mi * 16);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk has been read: the next one may land on it
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk has been read: the next one may land on it
-            }
         } else {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -575,7 +568,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 }
 
 struct BatchPlan {
-    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max, rs, rows_part, brs, CH;
+    int MI, RD, XS, xs_rows, wk, wt, passes, blocks, tiles_base, tiles_rem, tiles_max, rs, rows_part, brs;
     size_t ring, pbuf_pitch, ystage;
 };
 
@@ -625,17 +618,11 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     const size_t budget = 160 * 1024;
     // XS: the staging area holds min(M, 8) batch rows per wave (more rows arrive in chunks of eight); the partial-tile buffers live
     // in it afterwards
-    // ... or (form 3; AUTO where it fits: 17 .. 32 rows per part, depth 0 | 1) TWELVE rows beside ONE ring slot: 32 rows reach the
-    // registers in three round trips instead of four (each ~1 us), and the second slot was not buying anything (see below)
-    const bool ch12 = (form == 0 || form == 3) && b.MI == 2 && (rd_req == 0 || rd_req == 1) &&
-                      b.ystage + (size_t)8 * 12288 + (size_t)8 * PIECE_B <= budget;
-    if (form == 3 && !ch12) return false;
-    b.CH = ch12 ? 12 : 8;
-    const int rows = MP < b.CH ? MP : b.CH;
+    const int rows = MP < 8 ? MP : 8;
     size_t staged = (size_t)rows * 1024 > plain ? (size_t)rows * 1024 : plain;
     if (fast && staged < (size_t)4096 + 256 * b.MI) staged = (size_t)4096 + 256 * b.MI;  // (the group sums sit behind the partial-tile buffers)
     const bool xs = form != 2 && b.ystage + 8 * staged + (size_t)8 * PIECE_B <= budget;
-    if ((form == 1 || form == 3 || fast) && !xs) return false;
+    if ((form == 1 || fast) && !xs) return false;
     b.XS = xs ? 1 : 0;
     b.xs_rows = rows;
     b.pbuf_pitch = xs ? staged : plain;
@@ -643,7 +630,7 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     // ring slots, AUTO: two (lazy) wherever they fit, else one -- the per-wave phase times (profiles/r06_gemv_batch_trace.txt) show no
     // wave waiting for a piece in either form: a unit is bound by what the two waves of a SIMD issue (requests, decode, MFMA, exchange);
     // one slot and two measure within 1 - 3 % of each other (profiles/r06_batch_parts.txt)
-    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : (ch12 ? 1 : 2);
+    int rd = (rd_req >= 1 && rd_req <= 3) ? rd_req : 2;
     while (rd > 1 && fixed + (size_t)8 * rd * PIECE_B > budget) --rd;
     if (fixed + (size_t)8 * rd * PIECE_B > budget) return false;
     b.RD = rd;
@@ -694,21 +681,18 @@ int launch_batch(const void* x, const void* qweight, const void* scales, const v
     p.trace = nullptr;
 #endif
     const size_t lds = b.ring + 8 * b.pbuf_pitch + b.ystage;
-#define AWQ_BT_CASE_CH(MIV, RDV, XSV, FASTV, CHV)                                                                                       \
-    if (b.MI == MIV && b.RD == RDV && b.XS == XSV && fast == FASTV && b.CH == CHV) {                                                    \
+#define AWQ_BT_CASE(MIV, RDV, XSV, FASTV)                                                                                               \
+    if (b.MI == MIV && b.RD == RDV && b.XS == XSV && fast == FASTV) {                                                                   \
         static std::atomic<unsigned long long> opted{0};                                                                                \
-        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_batch_kernel<MIV, RDV, (XSV != 0), FASTV, CHV>), opted)) return AWQ_ERR_LAUNCH; \
-        hipLaunchKernelGGL((awq_gemv_batch_kernel<MIV, RDV, (XSV != 0), FASTV, CHV>), dim3((unsigned)b.blocks), dim3(512), lds, st, p); \
+        if (!awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_batch_kernel<MIV, RDV, (XSV != 0), FASTV>), opted)) return AWQ_ERR_LAUNCH; \
+        hipLaunchKernelGGL((awq_gemv_batch_kernel<MIV, RDV, (XSV != 0), FASTV>), dim3((unsigned)b.blocks), dim3(512), lds, st, p);      \
         return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;                                                               \
     }
-#define AWQ_BT_CASE(MIV, RDV, XSV, FASTV) AWQ_BT_CASE_CH(MIV, RDV, XSV, FASTV, 8)
-    AWQ_BT_CASE_CH(2, 1, 1, false, 12) AWQ_BT_CASE_CH(2, 1, 1, true, 12)
     AWQ_BT_CASE(1, 1, 0, false) AWQ_BT_CASE(1, 2, 0, false) AWQ_BT_CASE(1, 3, 0, false) AWQ_BT_CASE(2, 1, 0, false) AWQ_BT_CASE(2, 2, 0, false)
     AWQ_BT_CASE(2, 3, 0, false) AWQ_BT_CASE(1, 1, 1, false) AWQ_BT_CASE(1, 2, 1, false) AWQ_BT_CASE(1, 3, 1, false) AWQ_BT_CASE(2, 1, 1, false)
     AWQ_BT_CASE(2, 2, 1, false) AWQ_BT_CASE(2, 3, 1, false)
     AWQ_BT_CASE(1, 1, 1, true) AWQ_BT_CASE(1, 2, 1, true) AWQ_BT_CASE(2, 1, 1, true) AWQ_BT_CASE(2, 2, 1, true)
 #undef AWQ_BT_CASE
-#undef AWQ_BT_CASE_CH
     return AWQ_ERR_UNSUPPORTED;
 }
 }  // namespace

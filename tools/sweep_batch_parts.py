@@ -16,7 +16,7 @@ from autoawq_amd import ops  # noqa: E402
 BATCH = 5
 ROWS = (8, 16, 24, 32, 33, 48, 64, 80, 96, 128)
 # (row parts: 0 = auto, 1 = inside the block, 2 .. 4 = across blocks of one XCD; ring slots per wave: 0 = auto, 1 = one, 2 = two (lazy))
-CONFIGS = ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (0, 2))  # (0, 2): two ring slots, i.e. also eight-row staging chunks instead of twelve
+CONFIGS = ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (0, 2))
 
 
 def main():
