@@ -190,11 +190,15 @@ AWQ_EXPORT int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweigh
 #define AWQ_GEMV_KERNEL_TILE16 1u /* 16 rows per block through v_mfma_f32_16x16x32_f16, M <= 16 */
 #define AWQ_GEMV_KERNEL_ROWS 2u   /* row-streaming kernel (1 KiB of one row per wave instruction, activations in registers), M <= 4 */
 #define AWQ_GEMV_KERNEL_LDS 3u    /* weights through LDS by DMA into MFMA 16x16x32, 2 <= M <= 16 with M K <= 32768; _SPLITK: waves per tile */
-#define AWQ_GEMV_KERNEL_BATCH 5u  /* round 5: ANY M in one call (launches of <= 32 rows), group_size 128, K % 128 == 0: activations as MFMA A
-                                     fragments in registers, a tile's K range split over the eight waves of ONE block (no exchange, no
-                                     workspace), weights by LDS-DMA in row-contiguous pieces (gemv_batch.hip).  AUTO takes it from M = 5.
+#define AWQ_GEMV_KERNEL_BATCH 5u  /* round 5: ANY M in one call (round 6: launches of <= 128 rows), group_size 128, K % 128 == 0: activations
+                                     as MFMA A fragments in registers, a tile's K range split over the eight waves of ONE block (no exchange,
+                                     no workspace), weights by LDS-DMA in row-contiguous pieces (gemv_batch.hip).  AUTO takes it from M = 5.
+                                     Above 32 rows a launch works in ROW PARTS of <= 32 rows, each part in its own block, the blocks of a
+                                     tile list residents of one XCD (the matrix leaves HBM once).
                                      _UNIT: how the activations reach the registers (1 = coalesced LDS-DMA into a wave-private staging
-                                     area, 2 = direct 16-byte fragment loads; 0 = auto: staged when it fits), _SPLITK: pieces in flight (1 .. 3) */
+                                     area, 2 = direct 16-byte fragment loads; 0 = auto: staged when it fits), _SPLITK: ring slots per wave
+                                     (1 .. 3), _WAVES: the row parts (0 = auto, 1 = as wave groups inside one block -- round 6's first
+                                     form --, 2 .. 4 = that many parts across blocks; refused where a part would exceed 32 rows) */
 #define AWQ_GEMV_KERNEL_PREFILL 4u /* any M in ONE call: the register-decoded MFMA GEMM on this layout's own buffers (gemm_regb.hip, NK
                                      form; K % 64 == 0, group_size % 64 == 0, N % 4 == 0); _NLOG = 2: 256-row tiles.  EXPLICIT only:
                                      measured 0.29 of the MFMA peak at M = 16384 (dequantise + dense GEMM: 0.42) and latency-bound
@@ -226,8 +230,8 @@ AWQ_EXPORT int awq_repack_gemv_to_gemm(const int32_t* qweight, const uint16_t* s
 /* Replaces awq_v2_ext.gemv_forward_cuda_decode(x, qweight, scales, qzeros, m, n, k, group_size) and, for
  * small M, awq_v2_ext.gemm_forward_cuda_prefill (gemv_fast.py:185-208).  y [M, N] = x [M, K] @ W^T with
  * W = w*s + qzeros; N % 16 == 0, K % 128 == 0.  group_rows = rows of scales / qzeros (8*ZW).  AUTO (AWQ_GEMM_FLAG_KERNEL 0): from
- * M = 5 the batched kernel (gemv_batch.hip in its GEMVFast form, group_size 128: ANY M in one call, launches of <= 32 rows;
- * also AWQ_GEMV_KERNEL_BATCH explicitly, _SPLITK = ring slots 1 | 2); below that, or with AWQ_GEMM_FLAG_KERNEL = 1, the 16-row kernel
+ * M = 5 the batched kernel (gemv_batch.hip in its GEMVFast form, group_size 128: ANY M in one call, launches of <= 128 rows;
+ * also AWQ_GEMV_KERNEL_BATCH explicitly, _SPLITK = ring slots 1 | 2, _WAVES = the row parts as above); below that, or with AWQ_GEMM_FLAG_KERNEL = 1, the 16-row kernel
  * (gemv_fast.hip: 1 <= M <= 16 per call, the host wrapper chunks). */
 AWQ_EXPORT int awq_gemv_fast_forward(const uint16_t* x, const int16_t* qweight, const uint16_t* scales,
                                      const uint16_t* qzeros, uint16_t* y, int64_t M, int64_t K, int64_t N,
