@@ -384,13 +384,8 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 
     // ---- stream
     float4_t* ystage = reinterpret_cast<float4_t*>(smem + p.ystage_off);  // [wt][tiles_max][MI][64 lanes]
-    // partial-tile buffers: [generation parity][slot of the exchange group][mi] x 1 KiB per wave.  XG tiles share ONE barrier (their
-    // partial tiles are parked side by side and summed together): half the synchronisation points of the block's eight waves
-    constexpr int XG = FAST ? 1 : 2;  // (GEMVFast: the group sums sit behind the two buffers of one tile)
-    auto pbuf = [&](int w, int parity, int slot, int mi) {
-        return reinterpret_cast<float4_t*>(smem + p.pbuf_off + w * p.pbuf_pitch + ((parity * XG + slot) * MI + mi) * 1024);
-    };
-    int u = 0, gi = 0;  // live units requested so far; exchange groups closed so far (the parity of the partial-tile buffers)
+    auto pbuf = [&](int w, int parity, int mi) { return reinterpret_cast<float4_t*>(smem + p.pbuf_off + w * p.pbuf_pitch + (parity * MI + mi) * 1024); };
+    int u = 0, it = 0;  // live units requested so far; iterations (the parity of the partial-tile buffer)
     for (int ps = 0; ps < p.passes; ++ps) {
         if (ps > 0) {  // the next K range of the activations (they queue behind the ring: a drain)
             if constexpr (XS) {
@@ -399,7 +394,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             load_a(ps, std::false_type{});
         }
         const int g0 = (ps * p.wk + wki) * GW;
-        for (int tl = 0; tl < p.tiles_max; ++tl) {
+        for (int tl = 0; tl < p.tiles_max; ++tl, ++it) {
             const bool live = tl < ntile;  // wave-uniform (and the same for the wk waves of an owner)
             float4_t acc[MI];
 #pragma unroll
@@ -517,25 +512,20 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
             }
             // ---- the wk partial tiles meet in LDS; lane (n, kq) holds D[m = 4 kq + r][n] in acc[mi][r]
             if (p.wk > 1 && !(AWQ_BT_DBG & 4)) {
-                const int slot = tl & (XG - 1);
                 if (live) {
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) pbuf(wave, gi & 1, slot, mi)[lane] = acc[mi];
+                    for (int mi = 0; mi < MI; ++mi) pbuf(wave, it & 1, mi)[lane] = acc[mi];
                 }
-                if (slot == XG - 1 || tl == p.tiles_max - 1) {  // (wave-uniform: the group is full, or the pass ends)
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    const int f = wki + p.wk * lane;  // this wave's share of a tile's MI x 64 float4 slots
-                    for (int sg = 0; sg <= slot; ++sg) {
-                        const int tls = tl - slot + sg;
-                        if (tls < ntile && f < 64 * MI) {
-                            const int mi = f >> 6, sl = f & 63;
-                            float4_t s = pbuf(twi * p.wk, gi & 1, sg, mi)[sl];
-                            for (int j = 1; j < p.wk; ++j) s += pbuf(twi * p.wk + j, gi & 1, sg, mi)[sl];
-                            float4_t* dst = ystage + ((twi * p.tiles_max + tls) * MI + mi) * 64 + sl;
-                            *dst = ps > 0 ? *dst + s : s;
-                        }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (live) {
+                    const int f = wki + p.wk * lane;  // this wave's share of the tile's MI x 64 float4 slots
+                    if (f < 64 * MI) {
+                        const int mi = f >> 6, sl = f & 63;
+                        float4_t s = pbuf(twi * p.wk, it & 1, mi)[sl];
+                        for (int j = 1; j < p.wk; ++j) s += pbuf(twi * p.wk + j, it & 1, mi)[sl];
+                        float4_t* dst = ystage + ((twi * p.tiles_max + tl) * MI + mi) * 64 + sl;
+                        *dst = ps > 0 ? *dst + s : s;
                     }
-                    ++gi;
                 }
             } else if (live) {
 #pragma unroll
@@ -624,7 +614,7 @@ bool plan_batch(int M, int K, int N, int g, int form, int rd_req, BatchPlan* out
     b.tiles_rem = tiles % owners;
     b.tiles_max = b.tiles_base + (b.tiles_rem ? 1 : 0);
     b.ystage = (size_t)b.wt * b.tiles_max * b.MI * 1024;
-    const size_t plain = wk > 1 ? (size_t)2 * (fast ? 1 : 2) * b.MI * 1024 : 0;  // (two generations x the tiles of an exchange group)
+    const size_t plain = wk > 1 ? (size_t)2 * b.MI * 1024 : 0;
     const size_t budget = 160 * 1024;
     // XS: the staging area holds min(M, 8) batch rows per wave (more rows arrive in chunks of eight); the partial-tile buffers live
     // in it afterwards
