@@ -256,7 +256,7 @@ def leg_gemm_bs(dev, ops):
     # the same matrix shape in the WQLinear_GEMV format (awq_gemv_forward: row-streaming kernel to 4 rows, the batched kernel from 5)
     sets = [rand_packed_nk(K, N, GROUP, dev, gen) for _ in range(nsets)]
     out["gemv_layout_by_batch"] = {}
-    for M in (1, 2, 4, 5, 8, 12, 16, 24, 32, 48, 64, 96):  # (round 5: from four rows at this shape csrc/gemv_batch.hip, launches of <= 32 rows on the layout's own buffers)
+    for M in (1, 2, 4, 5, 8, 12, 16, 24, 32, 48, 64, 96, 128):  # (from four rows at this shape csrc/gemv_batch.hip: one launch per <= 128 rows on the layout's own buffers)
         x = torch.randn((M, K), device=dev, generator=gen).half()
 
         def fn2():
@@ -268,7 +268,7 @@ def leg_gemm_bs(dev, ops):
         out["gemv_layout_by_batch"][str(M)] = {"us": us, "kernel": ops.last_kernel(),
                                                "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                             "frac": by / us / 1e3 / HBM_PEAK_GBS, "bytes_per_launch": by}}
-    for M in (1, 8, 64, 96):
+    for M in (1, 8, 64, 96, 128):
         r = out["gemv_layout_by_batch"][str(M)]["roofline"]
         r["traffic"] = traffic.get(("gemv", str(M)))
         r["traffic_measured_in"] = "profiles/" + PMC_BS_FILE
@@ -278,7 +278,7 @@ def leg_gemm_bs(dev, ops):
     # ... and in the WQLinear_GEMVFast format (round 5: the batched kernel reads this layout too)
     sets = [rand_packed_nk(K, N, GROUP, dev, gen, fast=True) for _ in range(nsets)]
     out["gemvfast_layout_by_batch"] = {}
-    for M in (1, 8, 32, 64):
+    for M in (1, 8, 32, 64, 128):
         x = torch.randn((M, K), device=dev, generator=gen).half()
 
         def fn3():
