@@ -190,54 +190,11 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
     // ---- request flat unit u into ring slot u % RD (past the end: clamped addresses -- the counted waits need the requests)
     //      request_at: unit u = (pass ps, tile tl) given by the caller (the stream knows its successor without a division); a dead unit
     //      re-reads the owner's first piece (valid memory, nobody consumes it)
-    //      An INTERIOR piece (whole tile inside N, whole K range inside the row -- all but the last tile / pass) goes out with
-    //      loop-invariant lane offsets on a wave-uniform base advanced by scalar arithmetic: no address VALU in the stream.
-    uint32_t inv_w[GW], inv_s, inv_z = 0;  // (GEMVFast: scales and zero terms share one offset)
-    if constexpr (FAST) {
-#pragma unroll
-        for (int i = 0; i < GW; ++i) {
-            constexpr int T[4] = {0, 2, 3, 1};
-            const int kqq = ((lane >> 2) & 3) ^ T[i];
-            inv_w[i] = (uint32_t)(i * p.K * 2 + 256 * (lane >> 4) + 128 * (kqq >> 1) + 32 * (lane & 3) + 16 * (kqq & 1));
-        }
-        inv_s = (uint32_t)(((lane >> 3) & 3) * p.N * 2 + 4 * (lane & 7));
-    } else {
-#pragma unroll
-        for (int i = 0; i < GW; ++i) {
-            const int r = i * 4 + (lane >> 4);
-            inv_w[i] = (uint32_t)(r * rowbytes + 16 * (((lane & 15) ^ r) & 15));
-        }
-        inv_s = (uint32_t)(n * p.SW * 2);
-        inv_z = (uint32_t)(n * p.ZW * 4);
-    }
     auto request_at = [&](int u, int ps_u, int tl_u, bool live) {
         const int ps = live ? ps_u : 0, tl = live ? tl_u : 0;
         const int g0 = (ps * p.wk + wki) * GW;
         const int row0 = (ntile > 0 ? t0 + tl : 0) * 16;
         const uint32_t slot = lds0 + (uint32_t)(ring + (u % RD) * PIECE_B);
-        constexpr bool INTERIOR = !(FAST && MI == 2 && RD == 1);  // (that one form has no registers to spare for the lane offsets: it spilled)
-        if constexpr (FAST && INTERIOR) {
-            if (row0 + 16 <= p.N && g0 + GW <= p.G && g0 + GW <= p.GP) {  // (wave-uniform)
-                const char* bw = reinterpret_cast<const char*>(p.qweight) + (uint32_t)__builtin_amdgcn_readfirstlane((row0 >> 2) * p.K * 2 + 256 * g0);
-                const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((g0 * p.N + row0) * 2);
-#pragma unroll
-                for (int i = 0; i < GW; ++i) AWQ_BT_DMA16(inv_w[i], bw, slot + 1024u * i);
-                AWQ_BT_DMA4(inv_s, reinterpret_cast<const char*>(p.scales) + so, slot + (uint32_t)PIECE_W);
-                AWQ_BT_DMA4(inv_s, reinterpret_cast<const char*>(p.qzeros) + so, slot + (uint32_t)(PIECE_W + 1024));
-                return;
-            }
-        } else if constexpr (!FAST) {
-            if (row0 + 16 <= p.N && g0 + GW <= p.G && ((2 * g0) & ~15) + 16 <= p.SW * 2 && (g0 >> 3) < p.ZW) {  // (wave-uniform)
-                const char* bw = reinterpret_cast<const char*>(p.qweight) + (uint32_t)__builtin_amdgcn_readfirstlane(row0 * rowbytes + g0 * 64);
-                const char* bs = reinterpret_cast<const char*>(p.scales) + (uint32_t)__builtin_amdgcn_readfirstlane(row0 * p.SW * 2 + ((2 * g0) & ~15));
-                const char* bz = reinterpret_cast<const char*>(p.qzeros) + (uint32_t)__builtin_amdgcn_readfirstlane((row0 * p.ZW + (g0 >> 3)) * 4);
-#pragma unroll
-                for (int i = 0; i < GW; ++i) AWQ_BT_DMA16(inv_w[i], bw, slot + 1024u * i);
-                AWQ_BT_DMA16(inv_s, bs, slot + (uint32_t)PIECE_W);
-                AWQ_BT_DMA4(inv_z, bz, slot + (uint32_t)(PIECE_W + 1024));
-                return;
-            }
-        }
         if constexpr (FAST) {
             const int rb2 = p.K * 2;  // bytes of an int16 row
 #pragma unroll
@@ -460,8 +417,7 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
 #endif
                 const unsigned char* slot = smem + ring + (u % RD) * PIECE_B;
                 const uint32_t zw = *reinterpret_cast<const uint32_t*>(slot + PIECE_W + 1024 + 4 * lane);
-                // (g0 & 7 is 0 or 4: the piece's four scales are the low or the high 8 bytes of the row's 16-byte chunk of eight)
-                const u32x2 sq = *reinterpret_cast<const u32x2*>(slot + PIECE_W + 16 * lane + 2 * (g0 & 4));
+                const u32x4 sq = *reinterpret_cast<const u32x4*>(slot + PIECE_W + 16 * lane);  // 8 scales: groups (g0 & ~7) ..
                 u32x4 wq[GW];
 #pragma unroll
                 for (int uu = 0; uu < GW; ++uu) wq[uu] = *reinterpret_cast<const u32x4*>(slot + n * 256 + (((4 * uu + kq) ^ n) & 15) * 16);
@@ -499,14 +455,14 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                     }
                 } else if constexpr (AWQ_BT_DBG & 2) {
 #pragma unroll
-                    for (int uu = 0; uu < GW; ++uu) acc[0] += __builtin_bit_cast(float4_t, wq[uu]) + __builtin_bit_cast(float4_t, u32x4{sq[0], sq[1], sq[0], sq[1]}) + (float)zw;
+                    for (int uu = 0; uu < GW; ++uu) acc[0] += __builtin_bit_cast(float4_t, wq[uu]) + __builtin_bit_cast(float4_t, sq) + (float)zw;
                     if constexpr (AWQ_BT_DBG & 8) __builtin_amdgcn_s_sleep(21);  // (the consumption's duration without its instructions)
                 } else if constexpr (AWQ_BT_DBG & 16) {  // the MFMAs on undecoded words: no decode VALU
 #pragma unroll
                     for (int uu = 0; uu < GW; ++uu)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const u32x4 b = {wq[uu][c], wq[uu][(c + 1) & 3], sq[c & 1], zw};
+                            const u32x4 b = {wq[uu][c], wq[uu][(c + 1) & 3], sq[c], zw};
 #pragma unroll
                             for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma16(afr[(mi * GW + uu) * 4 + c], b, acc[mi]);
                         }
@@ -517,7 +473,8 @@ __global__ __launch_bounds__(512) void awq_gemv_batch_kernel(BatchParams p) {
                     const uint32_t z = (zw >> (4 * gi)) & 15u;
                     const half2_t zlo = u2h2(0x64006400u | z | (z << 16));         // (1024 + z, 1024 + z)
                     const half2_t zhi = u2h2(0x54005400u | (z << 4) | (z << 20));  // (64 + z, 64 + z)
-                    const uint32_t sw = sq[uu >> 1];
+                    // (g0 & 7 is 0 or 4: the piece's four scales are the low or the high 8 bytes of the chunk)
+                    const uint32_t sw = (g0 & 4) ? sq[2 + (uu >> 1)] : sq[uu >> 1];
                     const float sc = (float)u2h2(sw)[uu & 1];
                     float4_t gacc[MI];
 #pragma unroll
