@@ -9,7 +9,7 @@ Drop-in contract kept (reference awq/modules/linear/gemv.py:27-197):
   * forward (:156-186): any leading dims, any float dtype (computed in fp16, cast back), bias added
     AFTER the cast back, in the input dtype (:183-185).
 What differs by design: the arithmetic runs in libawq_hip.so on the module's own buffers at every batch
-size (csrc/gemv_rows.hip up to 2 - 4 rows, csrc/gemv_batch.hip from there (5 rows; 4 while K > 2048; 3 while K > 6144) in launches of <= 32 -- gemv_lds.hip / gemv_nk.hip for the
+size (csrc/gemv_rows.hip up to 2 - 4 rows, csrc/gemv_batch.hip from there (5 rows; 4 while K > 2048; 3 while K > 6144) in launches of <= 128 rows -- gemv_lds.hip / gemv_nk.hip for the
 group sizes it does not take; from PREFILL_MIN_ROWS rows PREFILL_IMPL); there is no CPU path -- a non-HIP tensor raises.
 """
 import torch
@@ -32,10 +32,9 @@ def dequant_matmul_nk(x2d, wt):
     return torch.matmul(x2d, wt.t())
 
 
-# Up to this many rows the call runs the decode / batched-decode kernels on the layout's own buffers (round 5: csrc/gemv_batch.hip takes any
-# M in launches of <= 32 rows, each streaming the matrix once -- three launches still beat the repack route at 4096 x 11008: 37 vs 50 us,
-# profiles/r05_prefill_routes.txt, r05_gemv_batch_sweep_final.txt; the reference switches to its batched kernel at 8 rows: gemv.py:168).
-# Above it: PREFILL_IMPL.
+# Below this many rows the call runs the decode / batched-decode kernels on the layout's own buffers (csrc/gemv_batch.hip takes any M in
+# launches of <= 128 rows, each streaming the matrix once: see prefill_min_rows; the reference switches to its batched kernel at 8
+# rows: gemv.py:168).  From it: PREFILL_IMPL.
 PREFILL_MIN_ROWS = 257
 
 

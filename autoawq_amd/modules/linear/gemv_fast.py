@@ -21,8 +21,8 @@ from ... import _lib, ops
 from ...utils.packing import calculate_zeros_width, pack_intweight_fast, quantize_int_weights_nk
 from .gemv import dequant_matmul_nk, prefill_min_rows, prefill_route
 
-# up to this many rows: the decode / batched-decode kernels (round 5: csrc/gemv_batch.hip in its GEMVFast form, launches of <= 32 rows, group
-# size 128; other group sizes: 16 rows, csrc/gemv_fast.hip); above: dequantise + dense GEMM
+# below this many rows: the decode / batched-decode kernels (csrc/gemv_batch.hip in its GEMVFast form, launches of <= 128 rows, group
+# size 128; other group sizes: 16 rows, csrc/gemv_fast.hip); from it: PREFILL_IMPL
 PREFILL_MIN_ROWS = 257  # (gemv.prefill_min_rows: 257 while K <= 4096, 193 beyond)
 
 

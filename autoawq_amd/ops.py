@@ -261,7 +261,7 @@ def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
         return y
     kern = flags & 0xF
     if kern == GEMV_KERNEL_BATCH or (kern == 0 and L.awq_gemv_auto_kernel(M, K, N, group_size) == GEMV_KERNEL_BATCH):
-        # round 5: the batched kernel (csrc/gemv_batch.hip) takes ANY M in one call (launches of <= 32 rows inside the library)
+        # round 5: the batched kernel (csrc/gemv_batch.hip) takes ANY M in one call (launches of <= 128 rows inside the library)
         with torch.cuda.device(x2d.device):
             rc = L.awq_gemv_forward(_ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), M, K, N, group_size, ZW, flags,
                                     _stream())
@@ -497,7 +497,7 @@ def gemv_fast_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     L = _lib.lib()
     kern = flags & 0xF
     if (kern == GEMV_KERNEL_BATCH or (kern == 0 and M >= 5)):
-        # round 5: the batched kernel in its GEMVFast form takes ANY M in one call (launches of <= 32 rows inside the library); shapes it
+        # round 5: the batched kernel in its GEMVFast form takes ANY M in one call (launches of <= 128 rows inside the library); shapes it
         # refuses (group sizes other than 128) fall through to the 16-row kernel in chunks
         with torch.cuda.device(x2d.device):
             rc = L.awq_gemv_fast_forward(_ptr(x2d), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), M, K, N, group_size, GP, flags, _stream())
