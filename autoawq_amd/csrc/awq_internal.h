@@ -96,6 +96,12 @@ struct AwqRowsFx {  // decoder-block prologue / epilogue of the row-streaming ke
     float norm_eps = 0.f;
     const uint16_t* res = nullptr;
     bool pairs = false;
+    // grouped form (MoE decode): one virtual batch-1 call per (token, expert) pair over expert stacks [E, N, ...]; M must be 1,
+    // x holds the activation rows (pair i reads row i / x_div), y [num_pairs, N (N / 2 with pairs)]
+    const int32_t* pair_expert = nullptr;  // [num_pairs] on the device; a value outside [0, num_experts) skips the pair
+    const float* pair_scale = nullptr;     // [num_pairs] routing weights folded into the epilogue, or null
+    int num_pairs = 0, num_experts = 0, x_div = 1;
+    int parts = 0;                         // blocks one expert matrix is dealt over (0 = auto)
 };
 int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                          uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st,

@@ -284,10 +284,11 @@ int awq_moe_route_local(const float* gating_logits, float* topk_weights, int32_t
                         int32_t* expert_ids, int32_t* num_tokens_post_padded, int64_t num_tokens, int64_t num_experts,
                         int64_t topk, int renormalize, int64_t block_rows, int64_t first_expert, int64_t num_local,
                         void* stream) {
-    if (num_tokens < 0 || num_experts < 1 || topk < 1 || block_rows < 1) return AWQ_ERR_BAD_SHAPE;
+    if (num_tokens < 0 || num_experts < 1 || topk < 1 || block_rows < 0) return AWQ_ERR_BAD_SHAPE;
     if (first_expert < 0 || num_local < 1 || first_expert + num_local > num_experts) return AWQ_ERR_BAD_SHAPE;
     if (num_tokens == 0) return AWQ_OK;
-    if (!gating_logits || !topk_weights || !topk_ids || !sorted_token_ids || !expert_ids || !num_tokens_post_padded)
+    // block_rows == 0: routing only (softmax, top-k, renormalisation) -- the three alignment outputs are not touched and may be NULL
+    if (!gating_logits || !topk_weights || !topk_ids || (block_rows > 0 && (!sorted_token_ids || !expert_ids || !num_tokens_post_padded)))
         return AWQ_ERR_NULL;
     if (num_tokens * topk > (1 << 24)) return AWQ_ERR_UNSUPPORTED;
     return awq_launch_moe_route(gating_logits, topk_weights, topk_ids, sorted_token_ids, expert_ids,
@@ -467,6 +468,36 @@ int awq_gemv_forward_ex(const AwqGemvEx* e) {
     g_last_kernel = "gemv_rows";
     return awq_launch_gemv_rows(e->x, e->qweight, e->scales, e->qzeros, e->y, (int)M, (int)K, (int)N, (int)g, (int)ZW, 0, 0, 0, 0,
                                 static_cast<hipStream_t>(e->stream), &fx);
+}
+
+int awq_grouped_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                             uint16_t* y, const int32_t* pair_experts, const float* pair_weights, int64_t num_pairs,
+                             int64_t x_div, int64_t num_experts, int64_t K, int64_t N, int64_t group_size,
+                             int64_t zeros_width, uint32_t flags, int64_t parts, void* stream) {
+    const int64_t g = group_size, ZW = zeros_width;
+    if (K <= 0 || N < 0 || g <= 0 || K % g || K % 8 || ZW <= 0 || ZW * 8 < K / g) return AWQ_ERR_BAD_SHAPE;
+    if (num_pairs < 0 || num_experts < 1 || x_div < 1 || parts < 0 || K > INT32_MAX || N > INT32_MAX || num_experts > INT32_MAX ||
+        (flags & ~AWQ_GEMV_EX_SILU_PAIRS))
+        return AWQ_ERR_BAD_SHAPE;
+    const bool pairs = flags & AWQ_GEMV_EX_SILU_PAIRS;
+    if (pairs && (pair_weights || N % 2)) return AWQ_ERR_BAD_SHAPE;
+    if (num_pairs == 0 || N == 0) return AWQ_OK;
+    if (!x || !qweight || !scales || !qzeros || !y || !pair_experts) return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales)) return AWQ_ERR_BAD_ALIGNMENT;
+    if (num_pairs > 8191 || parts > 65535 || x_div > num_pairs) return AWQ_ERR_UNSUPPORTED;
+    // the per-expert strides must keep every expert's tensors 16-byte aligned (whole rows of 16-byte multiples)
+    if ((N * (K / 8) * 4) % 16 || (N * ZW * 16) % 16) return AWQ_ERR_UNSUPPORTED;
+    AwqRowsFx fx;
+    fx.pairs = pairs;
+    fx.pair_expert = pair_experts;
+    fx.pair_scale = pair_weights;
+    fx.num_pairs = (int)num_pairs;
+    fx.num_experts = (int)num_experts;
+    fx.x_div = (int)x_div;
+    fx.parts = (int)parts;
+    g_last_kernel = "gemv_rows_grouped";
+    return awq_launch_gemv_rows(x, qweight, scales, qzeros, y, 1, (int)K, (int)N, (int)g, (int)ZW, 0, 0, 0, 0,
+                                static_cast<hipStream_t>(stream), &fx);
 }
 
 size_t awq_gemv_lds_bytes(int64_t M, int64_t K, int64_t zeros_width) {

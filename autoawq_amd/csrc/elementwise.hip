@@ -58,41 +58,48 @@ __global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restr
     const int P = T * k;
     if (tid < E) counts[tid] = 0;
     __syncthreads();
-    for (int t = tid; t < T; t += 256) {
-        float v[ROUTE_MAX_E];
-        float mx = -INFINITY;
-        for (int e = 0; e < E; ++e) {
-            v[e] = logits[(int64_t)t * E + e];
-            mx = fmaxf(mx, v[e]);
-        }
+    // phase 1, one WAVE per token, lane e holds expert e's logit (round 6: the first version kept a token's E values in a
+    // run-time indexed private array -- scratch memory: 10 us for four tokens).  The arithmetic keeps its order: the softmax
+    // denominator is summed over e = 0 .. E - 1 in sequence, the k selections take the first maximum.
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int t = wv; t < T; t += 4) {
+        const float lg = lane < E ? logits[(int64_t)t * E + lane] : -INFINITY;
+        float mx = lg;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float v = lane < E ? expf(lg - mx) : -3.f;  // (lanes past E never win a selection: every real value is >= 0)
         float sum = 0.f;
-        for (int e = 0; e < E; ++e) {
-            v[e] = expf(v[e] - mx);
-            sum += v[e];
-        }
+        for (int e = 0; e < E; ++e) sum += __shfl(v, e, 64);
         const float inv = 1.0f / sum;
-        float wsel[ROUTE_MAX_K];
-        int isel[ROUTE_MAX_K];
-        float wsum = 0.f;
+        float wsum = 0.f, mine = 0.f;
+        int mine_id = 0;
         for (int j = 0; j < k; ++j) {
-            int best = 0;
-            float bv = -1.f;
-            for (int e = 0; e < E; ++e)
-                if (v[e] > bv) {
-                    bv = v[e];
-                    best = e;
+            float bv = v;
+            int best = lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(best, o, 64);
+                if (ov > bv || (ov == bv && oi < best)) {
+                    bv = ov;
+                    best = oi;
                 }
-            v[best] = -2.f;  // taken
-            wsel[j] = bv * inv;
-            isel[j] = best;
-            wsum += wsel[j];
-            if (best >= e0 && best < e0 + nl) atomicAdd(&counts[best - e0], 1);  // pairs of experts outside [e0, e0 + nl) are not placed
+            }
+            if (lane == best) v = -2.f;  // taken
+            const float wj = bv * inv;
+            wsum += wj;
+            if (lane == j) {
+                mine = wj;
+                mine_id = best;
+            }
         }
-        for (int j = 0; j < k; ++j) {
-            topk_w[(int64_t)t * k + j] = renorm ? wsel[j] / wsum : wsel[j];
-            topk_ids[(int64_t)t * k + j] = isel[j];
+        if (lane < k) {
+            topk_w[(int64_t)t * k + lane] = renorm ? mine / wsum : mine;
+            topk_ids[(int64_t)t * k + lane] = mine_id;
+            if (mine_id >= e0 && mine_id < e0 + nl) atomicAdd(&counts[mine_id - e0], 1);  // pairs of experts outside [e0, e0 + nl) are not placed
         }
     }
+    if (block <= 0) return;  // routing only (the row-streaming MoE decode path runs pairs, not aligned blocks)
     __syncthreads();
     if (tid == 0) {
         int pos = 0;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restr
 int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int* sorted_ids, int* expert_ids,
                          int* num_post_pad, int T, int E, int k, int renorm, int block, int first_expert, int num_local,
                          hipStream_t st) {
-    if (T < 1 || E < 1 || E > ROUTE_MAX_E || k < 1 || k > ROUTE_MAX_K || k > E || block < 1) return AWQ_ERR_UNSUPPORTED;
+    if (T < 1 || E < 1 || E > ROUTE_MAX_E || k < 1 || k > ROUTE_MAX_K || k > E || block < 0) return AWQ_ERR_UNSUPPORTED;
     if (first_expert < 0 || num_local < 1 || first_expert + num_local > E) return AWQ_ERR_BAD_SHAPE;
     const int P = T * k;
     hipLaunchKernelGGL(awq_moe_route_kernel, dim3(1), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,

@@ -518,19 +518,22 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
         const char* e = getenv("AWQ_REGB_DBG");
         const int dbg = e ? atoi(e) : 0;
         if (dbg) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (dbg == 1) hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 1>), dim3(grid), dim3(512), lds, a.stream, p);
-            else if (dbg == 2) hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 2>), dim3(grid), dim3(512), lds, a.stream, p);
-            else if (dbg == 4) hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 4>), dim3(grid), dim3(512), lds, a.stream, p);
-            else if (dbg == 8) hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 8>), dim3(grid), dim3(512), lds, a.stream, p);
-            else if (dbg == 16) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 16>), dim3(grid), dim3(512), lds, a.stream, p);
-            } else hipLaunchKernelGGL((awq_gemm_regb_kernel<2, 15>), dim3(grid), dim3(512), lds, a.stream, p);
+            auto go = [&](auto wgm_c, auto dbg_c) {
+                constexpr int W = decltype(wgm_c)::value, D = decltype(dbg_c)::value;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_regb_kernel<W, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((awq_gemm_regb_kernel<W, D>), dim3(grid), dim3(W * 256), lds, a.stream, p);
+            };
+            auto by_dbg = [&](auto wgm_c) {
+                using std::integral_constant;
+                if (dbg == 1) go(wgm_c, integral_constant<int, 1>{});
+                else if (dbg == 2) go(wgm_c, integral_constant<int, 2>{});
+                else if (dbg == 4) go(wgm_c, integral_constant<int, 4>{});
+                else if (dbg == 8) go(wgm_c, integral_constant<int, 8>{});
+                else if (dbg == 16) go(wgm_c, integral_constant<int, 16>{});
+                else go(wgm_c, integral_constant<int, 15>{});
+            };
+            if (bm == 256) by_dbg(std::integral_constant<int, 2>{});
+            else by_dbg(std::integral_constant<int, 1>{});
             return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
         }
     }

@@ -85,10 +85,20 @@ struct RowsParams {
     const half_t* norm_w;       // FX_NORM: x := fp16(x * rsqrt(mean(x^2) + eps) * norm_w), == awq_rmsnorm_kernel's arithmetic
     float norm_eps;
     const half_t* res;          // FX_RES: y := fp16(fp16(W x) + res), the two roundings of the unfused add
+    // FX_GROUPED (MoE decode, round 6): one virtual batch-1 GEMV per (token, expert) pair over stacked GEMV-layout experts.
+    // grid = (8 * pairs, ceil(parts / 8)): blockIdx.x = 8 * pair + xcd, part = 8 * blockIdx.y + xcd -- the blocks that stream
+    // part q of ALL pairs are consecutive residents of ONE XCD (ids differing by 8), so pairs that share an expert meet in its L2.
+    const int* pair_expert;     // [pairs] expert of pair i (topk_ids flattened); outside [0, E): the pair's rows are not written
+    const float* pair_scale;    // FX_SCALE: y := fp16(W x * pair_scale[i]) (fp32 product, one rounding)
+    int E, parts;               // parts = blocks one matrix is dealt over
+    uint32_t x_div_magic;       // x row of pair i = i / x_div = (i * magic) >> 32; 0: x_div == 1
+    int y_pitch, y_rows;        // halfs between the y rows of two pairs; number of pairs (grid.x = 8 * y_rows)
+    long long w_stride, z_stride, s_stride;  // bytes between two experts' qweight / qzeros / scales
 };
 
 // FX bits of the kernel template
 constexpr int FX_NORM = 1, FX_RES = 2, FX_PAIRS = 4;  // FX_PAIRS: rows (2 i, 2 i + 1) = (gate_i, up_i), y[i] = silu(gate) * up
+constexpr int FX_GROUPED = 8, FX_SCALE = 16;          // MoE decode: per-pair expert indirection; routing weight in the epilogue
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -114,6 +124,14 @@ AWQ_DEV float4_t mfma4(u32x2 a, u32x2 b, float4_t c) {
 // The wait names every register of the round (they stay allocated until the data has landed) and prints them as a comment:
 // tools/isa_audit.py checks that they ARE the registers the request wrote (no compiler copy of a register whose load is
 // still in flight) and that nothing between request and wait touches them.
+// the grouped form's request: the same four loads WITHOUT the non-temporal hint -- pairs that share an expert stream the same
+// lines from neighbouring CUs of one XCD, and the line a first reader brought in has to stay in that XCD's L2 for the others
+#define AWQ_ROWS_REQUEST_KEEP(R, vw0, vw1, vw2, vw3, base)                                                                   \
+    asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\t"                                        \
+                 "global_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %8"                                            \
+                 : "=&v"(R.q[0]), "=&v"(R.q[1]), "=&v"(R.q[2]), "=&v"(R.q[3])                                                  \
+                 : "v"(vw0), "v"(vw1), "v"(vw2), "v"(vw3), "s"(base)                                                           \
+                 : "memory")
 #define AWQ_ROWS_WAIT(R, newer) \
     asm volatile("s_waitcnt vmcnt(%4) ; releases %0 %1 %2 %3" : "+v"(R.q[0]), "+v"(R.q[1]), "+v"(R.q[2]), "+v"(R.q[3]) : "n"(newer))
 // 1 KiB (64 x 16 bytes) / 256 bytes (64 x 4) from global memory straight into LDS at M0 + 16 (4) * lane: no VGPRs
@@ -163,6 +181,8 @@ struct QuadSel {
 template <int SL, int D, int MM, int FX = 0>
 __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     static_assert(FX == 0 || MM == 1, "the block prologue / epilogue is built for batch 1");
+    static_assert(!(FX & FX_SCALE) || (FX & FX_GROUPED), "the routing weight belongs to the grouped form");
+    static_assert(!(FX & FX_GROUPED) || !(FX & (FX_NORM | FX_RES)), "grouped form: silu pairs or the routing weight only");
     constexpr int RPU = rows_per_su(SL);  // rows per super-unit
     constexpr int R = SL * RPU / 4;       // rounds per super-unit; unit u of an SU = (row u / SL, slot u % SL)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -174,7 +194,31 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     ROWS_STAMP(0);
-    const int gi = blockIdx.x * p.rg + rgi;
+    // the five tensor bases: the kernel arguments themselves, or (FX_GROUPED) this pair's expert / activation row / output row
+    const uint32_t* qw_base = p.qweight;
+    const uint32_t* qz_base = p.qzeros;
+    const half_t* sc_base = p.scales;
+    const half_t* x_base = p.x;
+    half_t* y_base = p.y;
+    float pscale = 1.f;
+    int part = blockIdx.x;
+    if constexpr (FX & FX_GROUPED) {
+        const int pr = blockIdx.x >> 3;
+        part = 8 * blockIdx.y + (blockIdx.x & 7);
+        if (part >= p.parts) return;
+        const int e = p.pair_expert[pr];  // (scalar load: uniform index)
+        if ((unsigned)e >= (unsigned)p.E) return;
+        qw_base = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.qweight) + (long long)e * p.w_stride);
+        qz_base = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.qzeros) + (long long)e * p.z_stride);
+        sc_base = reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(p.scales) + (long long)e * p.s_stride);
+        x_base = p.x + (long long)(p.x_div_magic ? (int)__umulhi((uint32_t)pr, p.x_div_magic) : pr) * p.K;
+        y_base = p.y + (long long)pr * p.y_pitch;
+        if constexpr (FX & FX_SCALE) pscale = p.pair_scale[pr];
+        // opaque from here (never rematerialised next to a load that reads them), and five wait states between whatever wrote
+        // these SGPRs and the first vector-memory instruction that takes one as its base (cdna_hip_programming.md 5.7 item 2)
+        asm volatile("s_nop 4" : "+s"(qw_base), "+s"(qz_base), "+s"(sc_base), "+s"(x_base));
+    }
+    const int gi = part * p.rg + rgi;
     const int t0 = (gi * p.su_base + min(gi, p.su_rem)) * p.su_gran;  // first SU of this wave's row group
     const int nt = (p.su_base + (gi < p.su_rem ? 1 : 0)) * p.su_gran;
     const int last_row = p.N - 1;
@@ -195,7 +239,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                 const int cb = s * p.wk + wki;
                 const int c = min(cb * 64 + lane, p.C - 1);
                 const int j = rgi & 3, m = rgi >> 2;
-                AWQ_ROWS_DMA16((uint32_t)((m * p.K + 32 * c + 8 * j) * 2), p.x, lds0 + (uint32_t)(((m * 4 + j) * Cq + cb * 64) * 16));
+                AWQ_ROWS_DMA16((uint32_t)((m * p.K + 32 * c + 8 * j) * 2), x_base, lds0 + (uint32_t)(((m * 4 + j) * Cq + cb * 64) * 16));
             }
         } else
 #pragma unroll
@@ -206,7 +250,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                 const int j = jm & 3, m = jm >> 2;
                 const uint32_t src = (uint32_t)((m * p.K + 32 * c + 8 * j) * 2);
                 const uint32_t dst = lds0 + (uint32_t)(((m * 4 + j) * Cq + cb * 64) * 16);
-                AWQ_ROWS_DMA16(src, p.x, dst);
+                AWQ_ROWS_DMA16(src, x_base, dst);
             }
         }
     }
@@ -233,11 +277,11 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                 const uint32_t so = sc_bytes > 0 ? sc_src + (uint32_t)min(16 * lane, sc_bytes - 16) : 0u;
                 const uint32_t zo = zd > 0 ? z_src + 4u * (uint32_t)min(lane, zd - 1) : 0u;
                 asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dword %1, %3, %5"
-                             : "=&v"(scv), "=&v"(zv) : "v"(so), "v"(zo), "s"(p.scales), "s"(p.qzeros) : "memory");
+                             : "=&v"(scv), "=&v"(zv) : "v"(so), "v"(zo), "s"(sc_base), "s"(qz_base) : "memory");
             } else {
                 for (int o = 0; o < sc_bytes; o += 1024)
-                    AWQ_ROWS_DMA16(sc_src + (uint32_t)min(o + 16 * lane, sc_bytes - 16), p.scales, lds0 + (uint32_t)(sc_off + o));
-                for (int o = 0; o < zd; o += 64) AWQ_ROWS_DMA4(z_src + 4u * (uint32_t)min(o + lane, zd - 1), p.qzeros, lds0 + (uint32_t)(z_off + 4 * o));
+                    AWQ_ROWS_DMA16(sc_src + (uint32_t)min(o + 16 * lane, sc_bytes - 16), sc_base, lds0 + (uint32_t)(sc_off + o));
+                for (int o = 0; o < zd; o += 64) AWQ_ROWS_DMA4(z_src + 4u * (uint32_t)min(o + lane, zd - 1), qz_base, lds0 + (uint32_t)(z_off + 4 * o));
             }
         }
     };
@@ -274,7 +318,11 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
         const int rowb = p.KW * 4;  // bytes per row
         const uint32_t wa = (uint32_t)(ra * rowb) + (live ? woff[(4 * r + 0) % SL] : 0u), wb = (uint32_t)(rb * rowb) + (live ? woff[(4 * r + 1) % SL] : 0u);
         const uint32_t wc = (uint32_t)(rc * rowb) + (live ? woff[(4 * r + 2) % SL] : 0u), wd = (uint32_t)(rd * rowb) + (live ? woff[(4 * r + 3) % SL] : 0u);
-        AWQ_ROWS_REQUEST(Rd, wa, wb, wc, wd, p.qweight);
+        if constexpr (FX & FX_GROUPED) {
+            AWQ_ROWS_REQUEST_KEEP(Rd, wa, wb, wc, wd, qw_base);
+        } else {
+            AWQ_ROWS_REQUEST(Rd, wa, wb, wc, wd, qw_base);
+        }
     };
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -559,17 +607,17 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
             if constexpr (FX & FX_PAIRS) {  // rows (2 e, 2 e + 1) = (gate, up) of output e: the unfused path's two roundings
                 for (int e = lane; e < (nrows >> 1); e += 64) {
                     const float gt = (float)(half_t)row_sum(0, 2 * e), up = (float)(half_t)row_sum(0, 2 * e + 1);
-                    p.y[((t0 * RPU) >> 1) + e] = (half_t)awq_silu_mul_f32(gt, up);  // == awq_silu_and_mul_kernel
+                    y_base[((t0 * RPU) >> 1) + e] = (half_t)awq_silu_mul_f32(gt, up);  // == awq_silu_and_mul_kernel
                 }
             } else if constexpr (FX & FX_RES) {
                 if (lane < nrows) {
                     const half_t r = __builtin_bit_cast(half_t, (unsigned short)resv);
-                    p.y[t0 * RPU + lane] = (half_t)((float)(half_t)row_sum(0, lane) + (float)r);
+                    y_base[t0 * RPU + lane] = (half_t)((float)(half_t)row_sum(0, lane) + (float)r);
                 }
             } else {
                 for (int e = lane; e < nrows * MM; e += 64) {
                     const int m = MM == 1 ? 0 : e / nrows, j = MM == 1 ? e : e - m * nrows;
-                    p.y[(int64_t)m * p.N + t0 * RPU + j] = (half_t)row_sum(m, j);
+                    y_base[(int64_t)m * p.N + t0 * RPU + j] = (FX & FX_SCALE) ? (half_t)(row_sum(m, j) * pscale) : (half_t)row_sum(m, j);
                 }
             }
         } else {
@@ -577,7 +625,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
             ROWS_STAMP(6);
             const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
             for (int rgj = 0; rgj < p.rg; ++rgj) {
-                const int gj = blockIdx.x * p.rg + rgj;
+                const int gj = part * p.rg + rgj;
                 const int tj0 = (gj * p.su_base + min(gj, p.su_rem)) * p.su_gran, ntj = (p.su_base + (gj < p.su_rem ? 1 : 0)) * p.su_gran;
                 const int nr = min((tj0 + ntj) * RPU, p.N) - tj0 * RPU;
                 for (int e = tid; e < nr * MM; e += nthr) {
@@ -588,7 +636,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                         const float4_t v = rp[w];
                         sum += (v[0] + v[1]) + (v[2] + v[3]);
                     }
-                    p.y[(int64_t)m * p.N + tj0 * RPU + j] = (half_t)sum;
+                    y_base[(int64_t)m * p.N + tj0 * RPU + j] = (half_t)sum;
                 }
             }
         }
@@ -609,7 +657,8 @@ int launch_rows(const RowsParams& p, int blocks, size_t lds, hipStream_t st) {
         static std::atomic<unsigned long long> opted{0};
         (void)awq_lds_opt_in(reinterpret_cast<const void*>(&awq_gemv_rows_kernel<SL, D, MM, FX>), opted);
     }
-    hipLaunchKernelGGL((awq_gemv_rows_kernel<SL, D, MM, FX>), dim3((unsigned)blocks), dim3(64 * p.wk, p.rg), lds, st, p);
+    const dim3 grid = (FX & FX_GROUPED) ? dim3(8u * (unsigned)p.y_rows, (unsigned)(blocks + 7) / 8u) : dim3((unsigned)blocks);
+    hipLaunchKernelGGL((awq_gemv_rows_kernel<SL, D, MM, FX>), grid, dim3(64 * p.wk, p.rg), lds, st, p);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
@@ -631,6 +680,9 @@ int launch_rows_fx(int fx, const RowsParams& p, int blocks, size_t lds, hipStrea
         case FX_NORM | FX_PAIRS:
             if constexpr (SL != 8) return launch_rows<SL, D, 1, FX_NORM | FX_PAIRS>(p, blocks, lds, st);
             return AWQ_ERR_UNSUPPORTED;
+        case FX_GROUPED: return launch_rows<SL, D, 1, FX_GROUPED>(p, blocks, lds, st);
+        case FX_GROUPED | FX_PAIRS: return launch_rows<SL, D, 1, FX_GROUPED | FX_PAIRS>(p, blocks, lds, st);
+        case FX_GROUPED | FX_SCALE: return launch_rows<SL, D, 1, FX_GROUPED | FX_SCALE>(p, blocks, lds, st);
         default: return AWQ_ERR_UNSUPPORTED;
     }
 }
@@ -681,8 +733,13 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
                          uint16_t* y, int M, int K, int N, int g, int ZW, int waves, int depth, int bpc, int sl, hipStream_t st,
                          const AwqRowsFx* fxa) {
     if (!awq_gemv_rows_supports(M, K, N, g)) return AWQ_ERR_UNSUPPORTED;
-    const int fx = fxa ? (fxa->norm_w ? FX_NORM : 0) | (fxa->res ? FX_RES : 0) | (fxa->pairs ? FX_PAIRS : 0) : 0;
+    const int fx = fxa ? (fxa->norm_w ? FX_NORM : 0) | (fxa->res ? FX_RES : 0) | (fxa->pairs ? FX_PAIRS : 0) |
+                             (fxa->pair_expert ? FX_GROUPED : 0) | (fxa->pair_scale ? FX_SCALE : 0) : 0;
     if (fx && (M != 1 || ((fx & FX_PAIRS) && ((fx & FX_RES) || N % 2)))) return AWQ_ERR_UNSUPPORTED;
+    if ((fx & FX_SCALE) && !(fx & FX_GROUPED)) return AWQ_ERR_UNSUPPORTED;
+    if ((fx & FX_GROUPED) && ((fx & (FX_NORM | FX_RES)) || ((fx & FX_PAIRS) && (fx & FX_SCALE)) || fxa->num_pairs < 1 || fxa->num_pairs > 8191 ||
+                              fxa->num_experts < 1 || fxa->x_div < 1))
+        return AWQ_ERR_UNSUPPORTED;
     if ((int64_t)N * K / 2 >= ((int64_t)1 << 32) || (int64_t)N * ZW * 16 >= ((int64_t)1 << 32) || (int64_t)M * K * 2 >= ((int64_t)1 << 31))
         return AWQ_ERR_UNSUPPORTED;  // 32-bit byte offsets
     RowsParams p;
@@ -715,6 +772,7 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     const int su_units = p.su_total / p.su_gran;      // N is even with pairs
     const bool bpc_auto = bpc <= 0;
     if (bpc_auto) bpc = p.su_total > 8 * 256 * p.rg ? 2 : 1;
+    if ((fx & FX_GROUPED) && bpc_auto) bpc = 1;  // the pairs multiply the blocks in flight: parts = 256 per matrix, or `parts` asked for
     const bool one_round = SL * RPU == 4;
     int blocks = 0;
     auto partition = [&](int per_cu) {
@@ -727,10 +785,25 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
         p.su_max = (p.su_base + (p.su_rem ? 1 : 0)) * p.su_gran;
     };
     partition(bpc);
+    if (fx & FX_GROUPED) {
+        // parts per matrix: the pairs multiply the blocks in flight, and a wave should stream ~100 KB behind its prologue (x into
+        // registers: 28 KB per block at K = 14336) -- 512 blocks in all, between 64 and 256 parts, a multiple of 8 (dense XCD map).
+        // Mixtral w2 (14336 -> 4096), 8 pairs: 38.5 us at 64 parts, 45 at 256, 75 at 1024; w1|w3 level from 64 to 512
+        // (profiles/r06_moe_rows.txt).  fxa->parts > 0 forces a count.
+        int want = fxa->parts > 0 ? fxa->parts : (512 / fxa->num_pairs + 7) / 8 * 8;
+        if (fxa->parts <= 0) want = want < 64 ? 64 : (want > 256 ? 256 : want);
+        blocks = want;
+        const int max_blocks = (su_units + p.rg - 1) / p.rg;
+        if (blocks > max_blocks) blocks = max_blocks;
+        const int groups = blocks * p.rg;
+        p.su_base = su_units / groups;
+        p.su_rem = su_units % groups;
+        p.su_max = (p.su_base + (p.su_rem ? 1 : 0)) * p.su_gran;
+    }
     // Two super-units in flight per wave need an even count in EVERY row group (one straight-line drain).  Where the rows do
     // not divide that way (4096 x 11008: 5504 super-units over 1024 row groups) the same bytes stay in flight through two
     // blocks per CU with one super-unit each instead (7.0 us; one block per CU and one in flight: 8.0).
-    if (bpc_auto && bpc == 1 && (depth < 1 || depth > 2) && one_round && p.su_max >= 2 && p.su_max <= 8 &&
+    if (!(fx & FX_GROUPED) && bpc_auto && bpc == 1 && (depth < 1 || depth > 2) && one_round && p.su_max >= 2 && p.su_max <= 8 &&
         (p.su_rem != 0 || (p.su_base * p.su_gran) % 2)) {
         bpc = 2;
         partition(bpc);
@@ -739,6 +812,21 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     p.norm_w = fxa ? reinterpret_cast<const half_t*>(fxa->norm_w) : nullptr;
     p.norm_eps = fxa ? fxa->norm_eps : 0.f;
     p.res = fxa ? reinterpret_cast<const half_t*>(fxa->res) : nullptr;
+    p.pair_expert = nullptr; p.pair_scale = nullptr;
+    p.E = 0; p.parts = blocks; p.x_div_magic = 0; p.y_pitch = 0; p.y_rows = 0;
+    p.w_stride = p.z_stride = p.s_stride = 0;
+    if (fx & FX_GROUPED) {
+        p.pair_expert = fxa->pair_expert;
+        p.pair_scale = fxa->pair_scale;
+        p.E = fxa->num_experts;
+        p.y_rows = fxa->num_pairs;
+        p.y_pitch = (fx & FX_PAIRS) ? N / 2 : N;
+        if (fxa->x_div > 1 && !awq_magic_u32((uint32_t)fxa->x_div, (uint32_t)fxa->num_pairs + 1u, &p.x_div_magic)) return AWQ_ERR_UNSUPPORTED;
+        p.w_stride = (long long)N * p.KW * 4;
+        p.z_stride = (long long)N * p.ZW * 4;
+        p.s_stride = (long long)N * p.SW * 2;
+        if ((int64_t)(fxa->num_pairs / fxa->x_div + 1) * K * 2 >= ((int64_t)1 << 31)) return AWQ_ERR_UNSUPPORTED;
+    }
     if (depth < 1 || depth > 2) depth = p.su_max >= 2 && p.su_max <= 8 && bpc == 1 && one_round ? 2 : 1;
     if (!one_round || (SL == 4 && M > 1) || (SL == 2 && M > 3)) depth = 1;  // instantiated combinations (register budget)
     if (p.su_rem != 0 || (p.su_base * p.su_gran) % 2) depth = 1;  // two in flight only when every row group gets an even count

@@ -25,6 +25,33 @@ DECODE_MAX_PAIRS = 64
 FUSE_ACTIVATION_INTO_W2 = False
 
 
+# Decode on GEMV-layout twins of the expert stacks (round 6): up to this many (token, expert) pairs every pair runs as one
+# batch-1 call of the row-streaming kernel, all pairs in one launch per projection (ops.grouped_gemv_forward); beyond, or
+# without twins, the GEMM-layout grouped kernel.  Mixtral shape, top-2, us per block rows / GEMM-layout grouped kernel
+# (tools/bench_moe.py --sweep, profiles/r06_moe_rows.txt): 1 token 47.6 / 69.9, 2: 79.2 / 110.5, 4: 113.7 / 131.8,
+# 8 tokens (16 pairs, all 8 experts) 205 / 193 -- every pair decodes its expert's weights again (HBM traffic follows the
+# DISTINCT experts, the VALU work the pairs), so the hand-over sits between 8 and 16 pairs.
+ROWS_MAX_PAIRS = 12
+ROWS_PARTS = (0, 0)  # blocks one expert matrix is dealt over in the w1|w3 / w2 launch (0 = the kernel's default)
+
+
+def build_decode_twins(ws, w2s):
+    """GEMV-layout copies of the stacked experts for the decode path: `ws` (w1|w3 concatenated on N) with its gate / up columns
+    interleaved as row pairs, `w2s` as it is.  A SECOND resident copy of the experts (the GEMM-layout stacks stay: prefill-
+    sized token counts read those), built once at load -- `fuse_mixtral(decode_layout="auto")` -- and attached as
+    `ws.decode_twin` / `w2s.decode_twin`; rebuild after re-assigning or writing the stacks' buffers."""
+    from ...utils.convert import gemm_stack_to_gemv
+
+    K1, K2 = ws.qweight.shape[1], w2s.qweight.shape[1]
+    for K, G in ((K1, ws.qzeros.shape[1]), (K2, w2s.qzeros.shape[1])):
+        if (K // G) % 128 or K > 16384:  # shapes the row-streaming kernel does not take: no twins, the GEMM-layout kernel serves
+            ws.decode_twin = w2s.decode_twin = None
+            return None, None
+    ws.decode_twin = gemm_stack_to_gemv(ws.qweight, ws.qzeros, ws.scales, interleave_halves=True)
+    w2s.decode_twin = gemm_stack_to_gemv(w2s.qweight, w2s.qzeros, w2s.scales)
+    return ws.decode_twin, w2s.decode_twin
+
+
 class FusedSparseMoeBlock(torch.nn.Module):
     def __init__(self, top_k, gate, ws, w2s):
         super().__init__()
@@ -75,6 +102,29 @@ def _apply_moe_prefill(w1, w2, x, gating_output, topk, renormalize):
     return out.view(T, topk, H).sum(dim=1)
 
 
+def _apply_moe_rows(t1, t2, x, gating_output, topk, renormalize):
+    """Decode on the GEMV-layout twins: softmax / top-k, ONE launch of the row-streaming kernel for w1|w3 over all pairs with
+    silu(gate) * up written by the launch itself, ONE for w2 with the routing weight in its epilogue, the top-k sum.  No
+    alignment pass (no blocks: every pair is a batch-1 call), nothing read back.  None: a shape the kernel does not take."""
+    in_dtype = x.dtype
+    xh = x.half() if in_dtype != torch.float16 else x
+    num_experts = t1.qweight.shape[0]
+    if num_experts <= 64 and topk <= 8 and x.shape[0] <= 1024:
+        topk_weights, topk_ids = ops.moe_route(gating_output, topk, renormalize, 0)[:2]  # routing only: no alignment pass
+    else:
+        topk_weights, topk_ids = fused_topk(gating_output, topk, renormalize)
+    try:
+        act = ops.grouped_gemv_forward(xh, t1.qweight, t1.scales, t1.qzeros, topk_ids, t1.group_size, silu_pairs=True, parts=ROWS_PARTS[0])
+        out = ops.grouped_gemv_forward(act.view(-1, act.shape[-1]), t2.qweight, t2.scales, t2.qzeros, topk_ids, t2.group_size,
+                                       topk_weights=topk_weights, parts=ROWS_PARTS[1])
+    except ops._lib.AwqHipError as e:
+        if getattr(e, "code", 0) != -3:
+            raise
+        return None
+    out = torch.sum(out, dim=1)
+    return out.to(in_dtype) if in_dtype != torch.float16 else out
+
+
 def _per_expert_gemms(w1, w2, xs, counts):
     """Fallback of the prefill path for odd shapes: one awq_gemm_forward per expert and projection (reads the counts back)."""
     ys = torch.empty((xs.shape[0], w2.qweight.shape[2] * 8), dtype=torch.float16, device=xs.device)
@@ -95,6 +145,11 @@ def apply_moe_weights(w1: Dict[str, torch.Tensor], w2: Dict[str, torch.Tensor], 
         in_dtype = x.dtype
         out = _apply_moe_prefill(w1, w2, x.half() if in_dtype != torch.float16 else x, gating_output, topk, renormalize)
         return out.to(in_dtype) if in_dtype != torch.float16 else out
+    t1, t2 = getattr(w1, "decode_twin", None), getattr(w2, "decode_twin", None)
+    if t1 is not None and t2 is not None and x.shape[0] * topk <= ROWS_MAX_PAIRS and x.is_cuda:
+        out = _apply_moe_rows(t1, t2, x, gating_output, topk, renormalize)
+        if out is not None:
+            return out
     rows = DECODE_BLOCK_ROWS if x.shape[0] * topk <= DECODE_MAX_PAIRS else BLOCK_ROWS
     if num_experts <= 64 and topk <= 8 and x.shape[0] <= 1024:  # one-launch routing
         topk_weights, topk_ids, sorted_token_ids, expert_ids, num_tokens_post_padded = ops.moe_route(

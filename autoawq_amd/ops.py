@@ -422,9 +422,45 @@ def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_
     return y
 
 
+def grouped_gemv_forward(x, qweight, scales, qzeros, topk_ids, group_size, topk_weights=None, silu_pairs=False, parts=0,
+                         zero_init=False):
+    """MoE decode on GEMV-layout expert stacks (awq_grouped_gemv_forward; the decode-sized calls of
+    awq/modules/fused/moe.py:60-89): x [T, K] (every token feeds its topk pairs) or [T * topk, K] (one row per pair) fp16,
+    qweight [E, N, K/8] i32, qzeros [E, N, ZW] i32, scales [E, N, 8 ZW] fp16, topk_ids [T, topk] i32 on the device.
+    Returns [T, topk, N] (N / 2 with silu_pairs: rows (2 j, 2 j + 1) of every expert = (gate_j, up_j), silu(gate) * up
+    written by the launch); topk_weights [T, topk] fp32 multiplies each pair's row before its one rounding.  One launch of
+    the row-streaming kernel for all pairs; pairs whose id is outside [0, E) are skipped (zero_init: their rows read as 0)."""
+    _require_gpu(x, qweight, scales, qzeros, topk_ids, topk_weights)
+    if x.dtype != torch.float16 or topk_ids.dtype != torch.int32:
+        raise _lib.AwqHipError("grouped_gemv_forward expects fp16 activations and int32 topk_ids")
+    T, topk = topk_ids.shape
+    E, N, KW = qweight.shape
+    K, ZW = KW * 8, qzeros.shape[2]
+    P = T * topk
+    x = x.contiguous()
+    if x.dim() != 2 or x.shape[1] != K or x.shape[0] not in (T, P):
+        raise _lib.AwqHipError(f"grouped_gemv_forward: x{tuple(x.shape)} does not match {T} tokens x top-{topk}, K = {K}")
+    x_div = topk if x.shape[0] == T and topk > 1 else 1
+    if qzeros.shape[:2] != (E, N) or scales.shape != (E, N, ZW * 8):
+        raise _lib.AwqHipError(f"grouped_gemv_forward: shape mismatch qweight{tuple(qweight.shape)} qzeros{tuple(qzeros.shape)} "
+                               f"scales{tuple(scales.shape)}")
+    qweight, scales, qzeros, topk_ids = qweight.contiguous(), scales.contiguous(), qzeros.contiguous(), topk_ids.contiguous()
+    w = topk_weights.contiguous().float() if topk_weights is not None else None
+    if w is not None and w.numel() != P:
+        raise _lib.AwqHipError("grouped_gemv_forward: topk_weights must hold one weight per pair")
+    y = (torch.zeros if zero_init else torch.empty)((T, topk, N // 2 if silu_pairs else N), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().awq_grouped_gemv_forward(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), _ptr(topk_ids),
+                                                 _ptr(w), P, x_div, E, K, N, group_size, ZW,
+                                                 GEMV_EX_SILU_PAIRS if silu_pairs else 0, parts, _stream())
+    _lib.check(rc, "awq_grouped_gemv_forward")
+    return y
+
+
 def moe_route(gating_output, topk, renormalize, block_size, first_expert=0, num_local=None):
     """softmax + top-k (+ renormalise) + block alignment in ONE launch (awq_moe_route): returns
     (topk_weights [T, k] fp32, topk_ids [T, k] i32, sorted_token_ids, expert_ids, num_tokens_post_padded).
+    block_size = 0: routing only (the last three are None).
     first_expert / num_local (expert parallel, awq_moe_route_local): only the pairs of experts
     [first_expert, first_expert + num_local) are placed, expert_ids are relative to first_expert; topk_ids stay global."""
     _require_gpu(gating_output)
@@ -434,6 +470,11 @@ def moe_route(gating_output, topk, renormalize, block_size, first_expert=0, num_
     dev = g.device
     w = torch.empty((T, topk), dtype=torch.float32, device=dev)
     ids = torch.empty((T, topk), dtype=torch.int32, device=dev)
+    if block_size == 0:  # routing only: no alignment pass (the row-streaming MoE decode path runs pairs, not blocks)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().awq_moe_route_local(_ptr(g), _ptr(w), _ptr(ids), None, None, None, T, E, topk,
+                                                      1 if renormalize else 0, 0, first_expert, nl, _stream()), "awq_moe_route_local")
+        return w, ids, None, None, None
     sorted_ids = torch.empty((T * topk + nl * (block_size - 1),), dtype=torch.int32, device=dev)
     expert_ids = torch.empty((T * topk + nl,), dtype=torch.int32, device=dev)
     npad = torch.empty((1,), dtype=torch.int32, device=dev)

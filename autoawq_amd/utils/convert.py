@@ -90,6 +90,44 @@ def pack_linear(version, w, z, s, bias, in_features, out_features, group_size):
     return m
 
 
+class ExpertStackGemv:
+    """GEMV-layout twin of a stacked GEMM-layout expert tensor set (what `fuse_linears(..., operation=torch.stack)` returns,
+    awq/utils/fused_utils.py:145-162): qweight [E, N, K/8] i32, qzeros [E, N, ZW] i32, scales [E, N, 8 ZW] fp16."""
+
+    def __init__(self, qweight, qzeros, scales, group_size, pairs):
+        self.qweight, self.qzeros, self.scales, self.group_size, self.pairs = qweight, qzeros, scales, group_size, pairs
+
+
+def gemm_stack_to_gemv(qweight, qzeros, scales, interleave_halves=False):
+    """Stacked GEMM-layout experts (qweight [E, K, N/8], qzeros [E, K/g, N/8], scales [E, K/g, N]) -> the same integers, zero
+    points and scales in the GEMV layout, stacked (qweight [E, N, K/8], qzeros [E, N, ZW], scales [E, N, 8 ZW]); no
+    floating-point arithmetic.  interleave_halves: output row 2 j = column j, row 2 j + 1 = column N/2 + j of every expert
+    (Mixtral's w1|w3 concatenation, awq/models/mixtral.py:131-142, as (gate_j, up_j) row pairs: the form the row-streaming
+    kernel's silu-pairs epilogue reads).  One expert at a time (the unpacked integers of one 4096 x 28672 matrix are 470 MB)."""
+    E, K, NW = qweight.shape
+    N, G = NW * 8, qzeros.shape[1]
+    g = K // G
+    zw = calculate_zeros_width(K, g)
+    dev = qweight.device
+    oq = torch.empty((E, N, K // 8), dtype=torch.int32, device=dev)
+    oz = torch.empty((E, N, zw), dtype=torch.int32, device=dev)
+    os_ = torch.zeros((E, N, zw * 8), dtype=torch.float16, device=dev)
+    perm = None
+    if interleave_halves:
+        perm = torch.stack([torch.arange(N // 2, device=dev), torch.arange(N // 2, N, device=dev)], dim=1).reshape(-1)
+    for e in range(E):
+        w = _unpack_rows(qweight[e], AWQ_ORDER).t()          # [N, K]
+        z = _unpack_rows(qzeros[e], AWQ_ORDER).t()           # [N, G]
+        sc = scales[e].t()                                   # [N, G]
+        if perm is not None:
+            w, z, sc = w.index_select(0, perm), z.index_select(0, perm), sc.index_select(0, perm)
+        oq[e] = pack_rows_int4(w.contiguous(), GEMV_ORDER)
+        oz[e] = pack_zeros_nk(z.contiguous(), zw)
+        os_[e, :, :G] = sc
+        del w, z, sc
+    return ExpertStackGemv(oq, oz, os_, g, interleave_halves)
+
+
 def convert_linear(m, version):
     """Repack one WQLinear_* into another layout (returns `m` itself if it already has it)."""
     version = version.lower()

@@ -483,10 +483,16 @@ def leg_moe(dev):
 
     r = bench_moe.run(dev=dev, verbose=False)
     by, us = r["bytes"], r["us_per_block"]
-    return {"what": "Mixtral-8x7B-shape fused MoE MLP, bs=4, top-2 (BASELINE configs[4]); router excluded", "us_per_block": us,
+    ug = r["gemm_layout_grouped_us"]
+    return {"what": "Mixtral-8x7B-shape fused MoE MLP, bs=4, top-2 (BASELINE configs[4]); router excluded; the decode path of "
+                    "fuse_mixtral(decode_layout='auto'): GEMV-layout twins of the expert stacks, every (token, expert) pair one batch-1 "
+                    "call of the row-streaming kernel, all pairs in ONE launch per projection (awq_grouped_gemv_forward), silu * mul "
+                    "and the routing weight in the launches' epilogues", "us_per_block": us, "kernel": r["kernel"],
             "experts_hit": r["experts_hit"], "checked_against": r["checked_against"],
             "roofline": {"bound": "hbm", "achieved": by / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS,
-                         "bytes_per_block": by}}
+                         "bytes_per_block": by},
+            "gemm_layout_grouped_kernel": {"us_per_block": ug, "frac": by / ug / 1e3 / HBM_PEAK_GBS,
+                                           "what": "the checkpoint's own GEMM-layout stacks through awq_grouped_gemm_forward (rounds 1-5's path)"}}
 
 
 def forward_lin(ops, lin, x):

@@ -118,7 +118,8 @@ AWQ_EXPORT int awq_silu_and_mul(const uint16_t* gate_up, uint16_t* out, int64_t 
 /* Replaces awq_ext.topk_softmax + awq_ext.moe_alig_block_size (moe.py:94-171) in one launch:
  * gating_logits [T, E] fp32 -> topk_weights [T, k] fp32 (softmax, optionally renormalised),
  * topk_ids [T, k], sorted_token_ids [T*k + E*(block_rows-1)] (sentinel T*k), expert_ids [T*k + E],
- * num_tokens_post_padded [1].  E <= 64, k <= 8. */
+ * num_tokens_post_padded [1].  E <= 64, k <= 8.  block_rows = 0: routing only -- the three alignment outputs are not written and
+ * may be NULL (the row-streaming MoE decode path, awq_grouped_gemv_forward, runs pairs, not aligned blocks). */
 AWQ_EXPORT int awq_moe_route(const float* gating_logits, float* topk_weights, int32_t* topk_ids,
                              int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_padded,
                              int64_t num_tokens, int64_t num_experts, int64_t topk, int renormalize,
@@ -383,6 +384,26 @@ typedef struct AwqGemvEx {
     const uint16_t* add_residual;
 } AwqGemvEx;
 AWQ_EXPORT int awq_gemv_forward_ex(const AwqGemvEx* args);
+
+/* MoE DECODE on GEMV-layout expert stacks (round 6; the decode-sized calls of apply_moe_weights, awq/modules/fused/moe.py:60-89:
+ * awq_ext.grouped_gemm_forward on the stacked experts of awq/models/mixtral.py:130-158).  The reference keeps the experts in the
+ * GEMM layout only; this entry point reads the SAME weights repacked to the GEMV layout and stacked on a leading dim --
+ * qweight [E, N, K/8] int32, qzeros [E, N, ZW] int32, scales [E, N, 8 ZW] fp16 -- and runs every (token, expert) pair as one
+ * batch-1 call of the row-streaming kernel (csrc/gemv_rows.hip), all pairs in ONE launch:
+ *   y[i] = x[i / x_div] @ W[pair_experts[i]]^T            i = 0 .. num_pairs - 1, pair i = token * topk + slot
+ * pair_experts [num_pairs] int32 ON THE DEVICE (= topk_ids flattened; nothing is read back: capturable); an id outside
+ * [0, num_experts) leaves row i of y untouched (expert-parallel shards).  x_div = topk for the w1|w3 call (x = the tokens),
+ * 1 for the w2 call (x = one row per pair).
+ *   pair_weights != NULL              y[i] = fp16(fp32 product * pair_weights[i]) (mul_routed_weight, moe.py:84-88)
+ *   AWQ_GEMV_EX_SILU_PAIRS (flags)    rows (2 j, 2 j + 1) of every expert are (gate_j, up_j); y [num_pairs, N / 2] =
+ *                                     fp16(silu(fp16 gate) * fp16 up) == awq_silu_and_mul (moe.py:73-76).  Not with pair_weights.
+ * The blocks that stream one part of the matrices of ALL pairs are residents of one XCD: pairs that share an expert meet in its
+ * L2, so HBM traffic follows the DISTINCT experts.  parts: blocks one expert matrix is dealt over (0 = auto).
+ * AWQ_ERR_UNSUPPORTED: K > 16384, group_size % 128, num_pairs > 8191 -- the caller keeps the GEMM-layout grouped kernel. */
+AWQ_EXPORT int awq_grouped_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                                        uint16_t* y, const int32_t* pair_experts, const float* pair_weights, int64_t num_pairs,
+                                        int64_t x_div, int64_t num_experts, int64_t K, int64_t N, int64_t group_size,
+                                        int64_t zeros_width, uint32_t flags, int64_t parts, void* stream);
 
 /* awq_rope_kv_append + awq_decode_attention in ONE launch for a decode step (S = 1, full rotary,
  * head_dim = 128): qkv [B, (n_heads + 2*n_kv_heads) * 128] is the fused projection's output; query

@@ -18,8 +18,12 @@ class Stack:
     pass
 
 
-def run(dev=None, verbose=True, layers=2, reps=20):
+def run(dev=None, verbose=True, layers=2, reps=20, T=T, twins=True):
+    """twins: the decode path of fuse_mixtral(decode_layout="auto") -- GEMV-layout copies of the expert stacks, every pair one
+    batch-1 call of the row-streaming kernel (modules/fused/moe.py::_apply_moe_rows); the GEMM-layout grouped kernel
+    (rounds 1-5) is timed beside it and the two outputs are compared."""
     from autoawq_amd import ops
+    from autoawq_amd.modules.fused import moe as moe_mod
     from autoawq_amd.modules.fused.moe import apply_moe_weights
     from bench import algorithmic_bytes
 
@@ -58,31 +62,46 @@ def run(dev=None, verbose=True, layers=2, reps=20):
         for a, b in stacks:
             apply_moe_weights(a, b, x, logits, topk, True)
 
-    s = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(s):
-        step()
-        step()
-        s.synchronize()
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr, stream=s):
+    def timed():
+        s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s):
             step()
-        gr.replay()
-        s.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(s)
-        for _ in range(reps):
+            step()
+            s.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                step()
             gr.replay()
-        e1.record(s)
-        e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (reps * len(stacks))
-    del gr, stacks
+            s.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            for _ in range(reps):
+                gr.replay()
+            e1.record(s)
+            e1.synchronize()
+        del gr
+        return e0.elapsed_time(e1) * 1e3 / (reps * len(stacks))
+
+    us_gemm = timed()
+    us, rel_t, kern = us_gemm, None, ops.last_kernel()
+    if twins:
+        for a, b in stacks:
+            moe_mod.build_decode_twins(a, b)
+        got_t = apply_moe_weights(w1, w2, x, logits, topk, True).float()
+        kern = ops.last_kernel()
+        rel_t = float((got_t - want).abs().max() / want.abs().max())
+        assert rel_t < 5e-3, f"MoE block on the decode twins differs from the per-pair computation by {rel_t}"
+        us = timed()
+    del stacks
     torch.cuda.empty_cache()
     if verbose:
-        print(f"Mixtral-8x7B-shape MoE MLP, bs={T}, top-{topk}, {hit} experts hit: {us:.1f} us per block "
+        print(f"Mixtral-8x7B-shape MoE MLP, bs={T}, top-{topk}, {hit} experts hit: {us:.1f} us per block [{kern}] "
               f"({by / 1e6:.0f} MB of expert weights streamed -> {by / us / 1e3:.0f} GB/s, {by / us / 80e3:.1f}% of 8 TB/s); "
-              f"hipGraph-captured, no host reads; output within {rel:.1e} of the per-pair computation")
-    return {"us_per_block": us, "bytes": by, "experts_hit": hit,
-            "checked_against": f"per-(token, expert) awq_gemm_forward calls, max rel diff {rel:.1e}"}
+              f"GEMM-layout grouped kernel {us_gemm:.1f} us ({by / us_gemm / 80e3:.1f}%); hipGraph-captured, no host reads; "
+              f"output within {rel:.1e} (GEMM layout) / {rel_t if rel_t is None else format(rel_t, '.1e')} (twins) of the per-pair computation")
+    return {"us_per_block": us, "kernel": kern, "gemm_layout_grouped_us": us_gemm, "bytes": by, "experts_hit": hit, "tokens": T,
+            "checked_against": f"per-(token, expert) awq_gemm_forward calls, max rel diff {rel:.1e} (GEMM-layout grouped kernel)"
+                               + (f", {rel_t:.1e} (row-streaming kernel on the GEMV-layout twins)" if rel_t is not None else "")}
 
 
 def run_prefill(T=512, dev=None, verbose=True, reps=5):
@@ -215,6 +234,14 @@ def run_ep(world, dev=None, layers=2, reps=20, verbose=True):
     return {"world": world, "per_rank": per_rank, "busiest_rank_us": worst, "sum_vs_unsharded_max_rel": rel}
 
 
+if __name__ == "__main__" and "--sweep" in sys.argv:
+    # where the row-streaming path hands over to the GEMM-layout grouped kernel (modules/fused/moe.py::ROWS_MAX_PAIRS)
+    from autoawq_amd.modules.fused import moe as _m
+
+    _m.ROWS_MAX_PAIRS = 1 << 30
+    for t_ in (1, 2, 4, 8, 12, 16, 24, 32):
+        run(T=t_, layers=2 if t_ <= 8 else 1, reps=10)
+    sys.exit(0)
 if __name__ == "__main__" and "--prefill" in sys.argv:
     run_prefill()
     sys.exit(0)
