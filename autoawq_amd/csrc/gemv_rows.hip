@@ -786,12 +786,14 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     };
     partition(bpc);
     if (fx & FX_GROUPED) {
-        // parts per matrix: the pairs multiply the blocks in flight, and a wave should stream ~100 KB behind its prologue (x into
-        // registers: 28 KB per block at K = 14336) -- 512 blocks in all, between 64 and 256 parts, a multiple of 8 (dense XCD map).
-        // Mixtral w2 (14336 -> 4096), 8 pairs: 38.5 us at 64 parts, 45 at 256, 75 at 1024; w1|w3 level from 64 to 512
-        // (profiles/r06_moe_rows.txt).  fxa->parts > 0 forces a count.
-        int want = fxa->parts > 0 ? fxa->parts : (512 / fxa->num_pairs + 7) / 8 * 8;
-        if (fxa->parts <= 0) want = want < 64 ? 64 : (want > 256 ? 256 : want);
+        // parts per matrix: the pairs multiply the blocks in flight -- as many blocks as the chip holds at once (the kernel's
+        // register count leaves room for 4 / 3 / 2 blocks per CU at SL <= 2 / <= 4 / above), between 64 and 512 parts, a multiple
+        // of 8 (dense XCD map); fewer, longer blocks amortise the prologue (x into registers: 28 KB per block at K = 14336).
+        // Mixtral bs = 4 (8 pairs), us per MoE block by (parts w1|w3, parts w2): (64, 64) 125.8, (128, 64) 108.3, (256, 64) 109.6,
+        // (512, 64) 110.1, (256, 32) 115.6, (256, 96) 116.3 (profiles/r06_moe_rows.txt).  fxa->parts > 0 forces a count.
+        const int occ = SL <= 2 ? 4 : (SL <= 4 ? 3 : 2);
+        int want = fxa->parts > 0 ? fxa->parts : (256 * occ / fxa->num_pairs + 7) / 8 * 8;
+        if (fxa->parts <= 0) want = want < 64 ? 64 : (want > 512 ? 512 : want);
         blocks = want;
         const int max_blocks = (su_units + p.rg - 1) / p.rg;
         if (blocks > max_blocks) blocks = max_blocks;
