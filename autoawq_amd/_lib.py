@@ -74,6 +74,8 @@ SIGNATURES = {
     "awq_grouped_gemm_forward": (c_int, [c_void_p] * 9 + [c_int64] * 8 + [c_void_p, c_size_t, c_void_p]),
     "awq_grouped_gemm_forward_ex": (c_int, [c_void_p] * 9 + [c_int64] * 8 + [c_void_p, c_size_t, c_uint32, c_void_p]),
     "awq_grouped_gemm_prefill": (c_int, [c_void_p] * 6 + [c_int64] * 5 + [c_uint32, c_void_p]),
+    "awq_grouped_gemm_prefill_ex": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_uint32, c_void_p]),
+    "awq_moe_sort_pairs": (c_int, [c_void_p] * 3 + [c_int64, c_int64, c_void_p]),
     "awq_gemv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                  c_int64, c_uint32, c_void_p]),
     "awq_gemv_auto_kernel": (c_int, [c_int64, c_int64, c_int64, c_int64]),

@@ -130,7 +130,10 @@ int awq_launch_gemm_regb_fz(const uint16_t* x, const int32_t* qweight_kn, const 
                             int M, int K, int N, int g, int bm, hipStream_t st);
 // MoE prefill: the same kernel over a token list sorted by expert (device-side row offsets), GEMM-layout expert stacks
 int awq_launch_gemm_regb_grouped(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
-                                 uint16_t* y, const int32_t* seg, int P, int E, int K, int N, int g, int bm, hipStream_t st);
+                                 uint16_t* y, const int32_t* seg, int P, int E, int K, int N, int g, int bm, hipStream_t st,
+                                 const int32_t* row_map = nullptr, int x_div = 1, const float* pair_w = nullptr, int gather = 0,
+                                 int scatter = 0);
+int awq_launch_moe_sort(const int* ids, int P, int E, int* order, int* seg, hipStream_t st);
 int awq_launch_dequant_nk(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out, int K,
                           int N, int g, int ZW, hipStream_t st);
 // Grouped (MoE) GEMM over stacked expert tensors (awq/modules/fused/moe.py:60-89), M = 16-row token blocks.

@@ -367,6 +367,34 @@ int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweight, const ui
                                         (int)group_size, AWQ_GEMM_FLAG_NLOG(flags) == 2 ? 256 : 0, static_cast<hipStream_t>(stream));
 }
 
+int awq_moe_sort_pairs(const int32_t* topk_ids, int32_t* order, int32_t* seg_offsets, int64_t num_pairs, int64_t num_experts,
+                       void* stream) {
+    if (num_pairs < 0 || num_pairs > (1 << 24) || num_experts < 1) return AWQ_ERR_BAD_SHAPE;
+    if (!seg_offsets || (num_pairs && (!topk_ids || !order))) return AWQ_ERR_NULL;
+    if (num_experts > 64) return AWQ_ERR_UNSUPPORTED;
+    if (num_pairs == 0) return hipMemsetAsync(seg_offsets, 0, (size_t)(num_experts + 1) * 4, static_cast<hipStream_t>(stream)) == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+    return awq_launch_moe_sort(topk_ids, (int)num_pairs, (int)num_experts, order, seg_offsets, static_cast<hipStream_t>(stream));
+}
+
+int awq_grouped_gemm_prefill_ex(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                                uint16_t* y, const int32_t* seg_offsets, const int32_t* row_map, const float* pair_weights,
+                                int64_t P, int64_t x_div, int64_t num_experts, int64_t K, int64_t N, int64_t group_size,
+                                uint32_t flags, void* stream) {
+    int rc = check_gemm_layout(K, N, group_size);
+    if (rc) return rc;
+    if (P < 0 || P > INT32_MAX || num_experts < 1 || num_experts > 4096 || x_div < 1) return AWQ_ERR_BAD_SHAPE;
+    if (flags & ~(0xF0u | AWQ_GROUPED_PREFILL_GATHER_X | AWQ_GROUPED_PREFILL_SCATTER_Y)) return AWQ_ERR_BAD_SHAPE;
+    if (P == 0 || N == 0) return AWQ_OK;
+    if (!x || !qweight || !scales || !qzeros || !y || !seg_offsets) return AWQ_ERR_NULL;
+    const bool gather = flags & AWQ_GROUPED_PREFILL_GATHER_X, scatter = flags & AWQ_GROUPED_PREFILL_SCATTER_Y;
+    if ((gather || scatter || pair_weights) && !row_map) return AWQ_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(scales) || !aligned16(qzeros) || !aligned16(y)) return AWQ_ERR_BAD_ALIGNMENT;
+    g_last_kernel = "gemm_regb_grouped";
+    return awq_launch_gemm_regb_grouped(x, qweight, scales, qzeros, y, seg_offsets, (int)P, (int)num_experts, (int)K, (int)N,
+                                        (int)group_size, AWQ_GEMM_FLAG_NLOG(flags) == 2 ? 256 : 0, static_cast<hipStream_t>(stream), row_map,
+                                        (int)x_div, pair_weights, gather ? 1 : 0, scatter ? 1 : 0);
+}
+
 /* ---- GEMV layout ------------------------------------------------------------------------- */
 
 // Which kernel awq_gemv_forward's AUTO dispatch takes (host only, no launch): the row-streaming kernel at batches 1 and 2, and at

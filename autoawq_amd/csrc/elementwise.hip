@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restr
     // run-time indexed private array -- scratch memory: 10 us for four tokens).  The arithmetic keeps its order: the softmax
     // denominator is summed over e = 0 .. E - 1 in sequence, the k selections take the first maximum.
     const int lane = tid & 63, wv = tid >> 6;
-    for (int t = wv; t < T; t += 4) {
+    // (routing only: a grid of ceil(T / 4) blocks, one token per wave; with the alignment pass: ONE block walks all tokens)
+    for (int t = 4 * blockIdx.x + wv; t < T; t += 4 * gridDim.x) {
         const float lg = lane < E ? logits[(int64_t)t * E + lane] : -INFINITY;
         float mx = lg;
 #pragma unroll
@@ -132,8 +133,72 @@ int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int*
     if (T < 1 || E < 1 || E > ROUTE_MAX_E || k < 1 || k > ROUTE_MAX_K || k > E || block < 0) return AWQ_ERR_UNSUPPORTED;
     if (first_expert < 0 || num_local < 1 || first_expert + num_local > E) return AWQ_ERR_BAD_SHAPE;
     const int P = T * k;
-    hipLaunchKernelGGL(awq_moe_route_kernel, dim3(1), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,
+    hipLaunchKernelGGL(awq_moe_route_kernel, dim3(block == 0 ? (unsigned)((T + 3) / 4) : 1u), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,
                        num_post_pad, T, E, k, renorm, block, P + num_local * (block - 1), P + num_local, first_expert, num_local);
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
+
+// ---- MoE prefill: the (token, expert) pairs sorted by expert as an INDEX LIST, in one launch (round 6).
+//
+// Replaces the torch glue of the prefill-sized path of apply_moe_weights (awq/modules/fused/moe.py:45-91 at token counts where an
+// expert sees GEMM-sized batches): argsort(stable) + scatter_add + cumsum + index_select.  order [P] = the pair indices grouped by
+// expert, pair order kept inside an expert (a stable counting sort: identical to torch.argsort(topk_ids.flatten(), stable=True));
+// seg [E + 1] = the row range of each expert.  Pairs whose id is outside [0, E) are not placed (seg[E] < P then).
+// One block of 1024 threads walks the pairs in chunks of 1024: a histogram pass (LDS atomics), then per chunk the rank of a pair
+// inside its expert = pairs of that expert in earlier waves of the chunk + earlier lanes of its wave (ballots).  E <= 64.
+namespace {
+__global__ __launch_bounds__(1024) void awq_moe_sort_kernel(const int* __restrict__ ids, int P, int E, int* __restrict__ order,
+                                                            int* __restrict__ seg) {
+    __shared__ int cnt[ROUTE_MAX_E], cursor[ROUTE_MAX_E], wcnt[16][ROUTE_MAX_E];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < ROUTE_MAX_E) cnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < P; i += 1024) {
+        const int e = ids[i];
+        if ((unsigned)e < (unsigned)E) atomicAdd(&cnt[e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int e = 0; e < E; ++e) {
+            cursor[e] = pos;
+            seg[e] = pos;
+            pos += cnt[e];
+        }
+        seg[E] = pos;
+    }
+    __syncthreads();
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int c0 = 0; c0 < P; c0 += 1024) {
+        const int i = c0 + tid;
+        const int e = i < P ? ids[i] : -1;
+        const bool valid = (unsigned)e < (unsigned)E;
+        int rank = 0;
+        for (int x = 0; x < E; ++x) {
+            const unsigned long long m = __ballot(valid && e == x);
+            if (lane == 0) wcnt[wave][x] = __popcll(m);
+            if (valid && e == x) rank = __popcll(m & lt);
+        }
+        __syncthreads();
+        if (valid) {
+            int off = cursor[e];
+            for (int w = 0; w < wave; ++w) off += wcnt[w][e];
+            order[off + rank] = i;
+        }
+        __syncthreads();
+        if (tid < E) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wcnt[w][tid];
+            cursor[tid] += tot;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+int awq_launch_moe_sort(const int* ids, int P, int E, int* order, int* seg, hipStream_t st) {
+    if (P < 1 || E < 1 || E > ROUTE_MAX_E) return AWQ_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(awq_moe_sort_kernel, dim3(1), dim3(1024), 0, st, ids, P, E, order, seg);
+    return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
+}

@@ -70,6 +70,11 @@ struct RegbParams {
     const int* seg;   // [E + 1] row offsets on the DEVICE (nothing about the routing is read back to the host)
     int E;
     long long w_stride, z_stride, s_stride;  // bytes between two experts' qweight / qzeros / scales
+    // GROUPED, round 6: the sort stays an index list -- no gathered copy of x, no scatter pass over y
+    const int* row_map;     // [P] pair index of sorted row r (null: rows of x / y are the sorted rows themselves)
+    const float* pair_w;    // [pairs] routing weights by PAIR index: y row := fp16(acc * pair_w[pair]) (null: none)
+    uint32_t x_div_magic;   // GATHER: x row of sorted row r = row_map[r] / x_div ((v * magic) >> 32; 0: x_div == 1)
+    int gather, scatter;    // gather: x rows through row_map; scatter: y rows to row_map[r]
 };
 
 constexpr int BK = 64, NBUF = 4, BN = 256;
@@ -271,7 +276,13 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         const int q = PIECES * wave + u;
         const int row = 8 * q + (lane >> 3), slot = lane & 7;
         const int kc = slot ^ ((row >> 1) & 7);
-        const int grow = min(m0 + row, m_hi - 1);
+        int grow = min(m0 + row, m_hi - 1);
+        if constexpr (GROUPED) {
+            if (p.gather) {  // the sorted row's source row: one 4-byte load per lane and piece, once per block
+                const int pr = p.row_map[grow];
+                grow = p.x_div_magic ? (int)__umulhi((uint32_t)pr, p.x_div_magic) : pr;
+            }
+        }
         a_voff[u] = (uint32_t)(((int64_t)grow * p.K + 8 * kc) * 2);
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic segment
@@ -467,18 +478,55 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
 #pragma unroll
         for (int c = 0; c < 4; ++c) b4[c] = (float)bv[c];
     }
+    if constexpr (GROUPED) {
+        // with a row map a lane's output rows and their routing weights are requested as batches of independent loads ahead of
+        // the stores, sixteen rows at a time (one dependent chain per row -- map, weight, store -- measured +46 us on Mixtral's
+        // w2 launch; all 32 rows at once spilled)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int h = 0; h < 2; ++h) {
+            int orow[4][4];
+            float wr[4][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = m0 + wm * 128 + 16 * i + 4 * kb + e;
-            if (row < m_hi) {
-                half4_t o;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = (half_t)(acc[i][c][e] + b4[c]);
-                *reinterpret_cast<half4_t*>(p.y + (int64_t)((DBG & 16) ? (row & 127) : row) * p.N + col) = o;
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m0 + wm * 128 + 16 * (4 * h + i) + 4 * kb + e;
+                    orow[i][e] = (p.scatter || p.pair_w) ? p.row_map[min(row, m_hi - 1)] : row;
+                    wr[i][e] = 1.f;
+                }
+            if (p.pair_w) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wr[i][e] = p.pair_w[orow[i][e]];  // mul_routed_weight (moe.py:84-88): fp32 product, one rounding
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m0 + wm * 128 + 16 * (4 * h + i) + 4 * kb + e;
+                    if (row < m_hi) {
+                        half4_t o;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = (half_t)(acc[4 * h + i][c][e] * wr[i][e]);
+                        *reinterpret_cast<half4_t*>(p.y + (int64_t)(p.scatter ? orow[i][e] : row) * p.N + col) = o;
+                    }
+                }
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + wm * 128 + 16 * i + 4 * kb + e;
+                if (row < m_hi) {
+                    half4_t o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = (half_t)(acc[i][c][e] + b4[c]);
+                    *reinterpret_cast<half4_t*>(p.y + (int64_t)((DBG & 16) ? (row & 127) : row) * p.N + col) = o;
+                }
+            }
+    }
 }
 
 }  // namespace
@@ -503,6 +551,7 @@ int awq_launch_gemm_regb(const AwqGemmArgs& a, int bm) {
     p.M = a.M; p.K = a.K; p.N = a.N; p.g = a.g;
     p.KW = p.ZW = p.SW = 0;
     p.seg = nullptr; p.E = 0; p.w_stride = p.z_stride = p.s_stride = 0;
+    p.row_map = nullptr; p.pair_w = nullptr; p.x_div_magic = 0; p.gather = p.scatter = 0;
     p.tiles_m = (a.M + bm - 1) / bm;
     p.tiles_n = (a.N + BN - 1) / BN;
     p.pm = PM; p.pn = PN;
@@ -564,6 +613,7 @@ int awq_launch_gemm_regb_fz(const uint16_t* x, const int32_t* qweight_kn, const 
     p.M = M; p.K = K; p.N = N; p.g = g;
     p.KW = p.ZW = p.SW = 0;
     p.seg = nullptr; p.E = 0; p.w_stride = p.z_stride = p.s_stride = 0;
+    p.row_map = nullptr; p.pair_w = nullptr; p.x_div_magic = 0; p.gather = p.scatter = 0;
     p.tiles_m = (M + bm - 1) / bm;
     p.tiles_n = (N + BN - 1) / BN;
     p.pm = PM; p.pn = PN;
@@ -603,6 +653,7 @@ int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uin
     p.M = M; p.K = K; p.N = N; p.g = g;
     p.KW = K / 8; p.ZW = ZW; p.SW = 8 * ZW;
     p.seg = nullptr; p.E = 0; p.w_stride = p.z_stride = p.s_stride = 0;
+    p.row_map = nullptr; p.pair_w = nullptr; p.x_div_magic = 0; p.gather = p.scatter = 0;
     p.tiles_m = (M + bm - 1) / bm;
     p.tiles_n = (N + BN - 1) / BN;
     p.pm = PM; p.pn = PN;
@@ -622,9 +673,12 @@ int awq_launch_gemm_regb_nk(const uint16_t* x, const int32_t* qweight, const uin
 
 // ---- the GROUPED form (MoE prefill, GEMM-layout expert stacks): x / y rows sorted by expert, seg [E + 1] on the device.
 // max_tiles: M tiles the launch provides = ceil(P / bm) + E covers every split of P rows over E experts.
+// row_map / x_div / pair_w / gather / scatter: see RegbParams (all optional; without row_map the rows of x and y are the sorted rows)
 int awq_launch_gemm_regb_grouped(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
-                                 uint16_t* y, const int32_t* seg, int P, int E, int K, int N, int g, int bm, hipStream_t st) {
+                                 uint16_t* y, const int32_t* seg, int P, int E, int K, int N, int g, int bm, hipStream_t st,
+                                 const int32_t* row_map, int x_div, const float* pair_w, int gather, int scatter) {
     if (!awq_gemm_regb_supports(P, K, N, g) || E < 1 || !seg) return AWQ_ERR_UNSUPPORTED;
+    if ((gather || scatter || pair_w) && !row_map) return AWQ_ERR_NULL;
     if (bm == 0) bm = 128;
     if (bm != 128 && bm != 256) return AWQ_ERR_UNSUPPORTED;
     RegbParams p;
@@ -637,6 +691,8 @@ int awq_launch_gemm_regb_grouped(const uint16_t* x, const int32_t* qweight, cons
     p.M = P; p.K = K; p.N = N; p.g = g;
     p.KW = p.ZW = p.SW = 0;
     p.seg = seg; p.E = E;
+    p.row_map = row_map; p.pair_w = pair_w; p.gather = gather; p.scatter = scatter; p.x_div_magic = 0;
+    if (gather && x_div > 1 && !awq_magic_u32((uint32_t)x_div, (uint32_t)P + 1u, &p.x_div_magic)) return AWQ_ERR_UNSUPPORTED;
     p.w_stride = (long long)K * (N / 8) * 4;
     p.z_stride = (long long)(K / g) * (N / 8) * 4;
     p.s_stride = (long long)(K / g) * N * 2;

@@ -71,6 +71,7 @@ class FusedSparseMoeBlock(torch.nn.Module):
 # From this many (token, expert) pairs an expert sees GEMM-sized batches: one fused GEMM per expert.  Mixtral shape, top-2
 # (tools/dbg_moe_sizes.py): 256 pairs 755 us (blocks) vs 812 us (per expert), 512 pairs 1265 vs 1003 us.
 PREFILL_MIN_PAIRS = 384
+FUSED_PREFILL_GLUE = True  # round 6: routing, sort, gather and scatter inside the launches (False: the torch glue of rounds 4-5)
 
 
 def _apply_moe_prefill(w1, w2, x, gating_output, topk, renormalize):
@@ -82,6 +83,20 @@ def _apply_moe_prefill(w1, w2, x, gating_output, topk, renormalize):
     projection: 16 launches of ~112 blocks each for Mixtral, and no hipGraph capture)."""
     T, H = x.shape
     E = w1.qweight.shape[0]
+    if FUSED_PREFILL_GLUE and E <= 64 and topk <= 8:
+        # round 6: the sort stays an index list -- routing (one launch, a wave per token), a counting sort of the pairs (one
+        # launch), w1|w3 reading the TOKENS' rows through the list, silu * mul, w2 writing each pair's row in pair order with
+        # its routing weight folded into the one rounding (moe.py:84-88), the top-k sum: 6 launches for ~22
+        topk_weights, topk_ids = ops.moe_route(gating_output, topk, renormalize, 0)[:2]
+        order, seg = ops.moe_sort_pairs(topk_ids, E)
+        try:
+            gate_up = ops.grouped_gemm_prefill_ex(x, w1.qweight, w1.scales, w1.qzeros, seg, order, x_div=topk, gather=True)
+            out = ops.grouped_gemm_prefill_ex(ops.silu_and_mul(gate_up), w2.qweight, w2.scales, w2.qzeros, seg, order, scatter=True,
+                                              pair_weights=topk_weights)
+            return out.view(T, topk, H).sum(dim=1)
+        except ops._lib.AwqHipError as e:  # shapes the register-decoded kernel does not take: the older path below
+            if getattr(e, "code", 0) != -3:
+                raise
     topk_weights, topk_ids = fused_topk(gating_output, topk, renormalize)
     flat_e = topk_ids.reshape(-1).long()
     order = torch.argsort(flat_e, stable=True)

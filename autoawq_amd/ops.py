@@ -235,6 +235,53 @@ def grouped_gemm_prefill(x_sorted, qweight, scales, qzeros, seg_offsets, flags=0
     return y
 
 
+GROUPED_PREFILL_GATHER_X, GROUPED_PREFILL_SCATTER_Y = 1 << 19, 1 << 20
+
+
+def moe_sort_pairs(topk_ids, num_experts):
+    """(order [P] int32, seg_offsets [E + 1] int32): the pairs of topk_ids [T, topk] grouped by expert as an index list, one
+    launch (awq_moe_sort_pairs) == torch.argsort(topk_ids.flatten(), stable=True) + the experts' row ranges."""
+    _require_gpu(topk_ids)
+    ids = topk_ids.contiguous().view(-1)
+    if ids.dtype != torch.int32:
+        raise _lib.AwqHipError("moe_sort_pairs expects int32 topk_ids")
+    order = torch.empty_like(ids)
+    seg = torch.empty((num_experts + 1,), dtype=torch.int32, device=ids.device)
+    with torch.cuda.device(ids.device):
+        _lib.check(_lib.lib().awq_moe_sort_pairs(_ptr(ids), _ptr(order), _ptr(seg), ids.numel(), num_experts, _stream()),
+                   "awq_moe_sort_pairs")
+    return order, seg
+
+
+def grouped_gemm_prefill_ex(x, qweight, scales, qzeros, seg_offsets, row_map, x_div=1, gather=False, scatter=False,
+                            pair_weights=None, flags=0, zero_init=False):
+    """awq_grouped_gemm_prefill_ex: the grouped prefill GEMM with the sort kept as an index list.  gather: x [T, K] holds the
+    tokens, sorted row r reads row row_map[r] / x_div; else x [P, K] is sorted.  scatter: y row row_map[r] (pair order) instead
+    of r; pair_weights [P] fp32 by pair index multiply the fp32 product before its one rounding."""
+    _require_gpu(x, qweight, scales, qzeros, seg_offsets, row_map, pair_weights)
+    if x.dtype != torch.float16 or seg_offsets.dtype != torch.int32 or row_map.dtype != torch.int32:
+        raise _lib.AwqHipError("grouped_gemm_prefill_ex expects fp16 activations and int32 offsets / row map")
+    x, qweight, scales, qzeros = x.contiguous(), qweight.contiguous(), scales.contiguous(), qzeros.contiguous()
+    P, K = row_map.numel(), x.shape[1]
+    E, N, G = qweight.shape[0], qweight.shape[2] * 8, qzeros.shape[1]
+    if qweight.shape[1] != K or scales.shape != (E, G, N) or qzeros.shape != (E, G, N // 8) or seg_offsets.numel() != E + 1 or K % G:
+        raise _lib.AwqHipError(f"grouped_gemm_prefill_ex: shape mismatch x{tuple(x.shape)} qweight{tuple(qweight.shape)} "
+                               f"scales{tuple(scales.shape)} qzeros{tuple(qzeros.shape)} seg{tuple(seg_offsets.shape)}")
+    if (gather and x.shape[0] * x_div < P) or (not gather and x.shape[0] != P):
+        raise _lib.AwqHipError(f"grouped_gemm_prefill_ex: x{tuple(x.shape)} does not cover {P} pairs (x_div {x_div})")
+    w = pair_weights.contiguous().float().view(-1) if pair_weights is not None else None
+    if w is not None and w.numel() != P:
+        raise _lib.AwqHipError("grouped_gemm_prefill_ex: one routing weight per pair")
+    y = (torch.zeros if zero_init else torch.empty)((P, N), dtype=torch.float16, device=x.device)
+    f = flags | (GROUPED_PREFILL_GATHER_X if gather else 0) | (GROUPED_PREFILL_SCATTER_Y if scatter else 0)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().awq_grouped_gemm_prefill_ex(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y),
+                                                    _ptr(seg_offsets.contiguous()), _ptr(row_map.contiguous()), _ptr(w), P, x_div, E, K, N,
+                                                    K // G, f, _stream())
+    _lib.check(rc, "awq_grouped_gemm_prefill_ex")
+    return y
+
+
 def gemv_forward(x2d, qweight, scales, qzeros, group_size, flags=0):
     """GEMV layout (qweight [N, K/8], qzeros [N, ZW], scales [N, 8*ZW]): y [M, N] fp16 = x2d @ W^T
     (awq_gemv_forward).  M is processed in chunks that fit the kernel (<= 16 rows and the LDS)."""

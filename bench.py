@@ -473,7 +473,9 @@ def leg_moe_prefill(dev):
     import bench_moe
 
     r = bench_moe.run_prefill(dev=dev, verbose=False)
-    r["what"] = "Mixtral-8x7B-shape fused MoE MLP at 512 tokens (1024 pairs): ONE grouped launch of the register-decoded MFMA GEMM per projection, row tiles dealt over the experts from device-side offsets (awq_grouped_gemm_prefill, modules/fused/moe.py)"
+    r["what"] = ("Mixtral-8x7B-shape fused MoE MLP at 512 tokens (1024 pairs): routing (one launch), a counting sort of the pairs (one launch), ONE "
+                 "grouped launch of the register-decoded MFMA GEMM per projection with the sort kept as an index list -- w1|w3 reads the tokens' rows "
+                 "through it, w2 writes pair rows with the routing weight in its one rounding (awq_grouped_gemm_prefill_ex, modules/fused/moe.py)")
     return r
 
 

@@ -172,6 +172,25 @@ AWQ_EXPORT int awq_grouped_gemm_prefill(const uint16_t* x, const int32_t* qweigh
                                         uint16_t* y, const int32_t* seg_offsets, int64_t P, int64_t num_experts, int64_t K,
                                         int64_t N, int64_t group_size, uint32_t flags, void* stream);
 
+/* The same launch with the sort kept as an INDEX LIST (round 6: no gathered copy of x, no scatter pass over y, one rounding):
+ *   row_map [P] int32 on the device = pair index (token * topk + slot) of sorted row r, as awq_moe_sort_pairs writes it;
+ *   AWQ_GROUPED_PREFILL_GATHER_X   x is NOT sorted: sorted row r reads x row row_map[r] / x_div (x_div = topk: x = the tokens);
+ *   AWQ_GROUPED_PREFILL_SCATTER_Y  sorted row r is written to y row row_map[r] (y in pair order [T * topk, N]);
+ *   pair_weights != NULL           y row = fp16(fp32 product * pair_weights[row_map[r]]) (mul_routed_weight, moe.py:84-88).
+ * Rows of y that no sorted row maps to (pairs of foreign experts in an expert-parallel shard) are not written. */
+#define AWQ_GROUPED_PREFILL_GATHER_X (1u << 19)
+#define AWQ_GROUPED_PREFILL_SCATTER_Y (1u << 20)
+AWQ_EXPORT int awq_grouped_gemm_prefill_ex(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                                           uint16_t* y, const int32_t* seg_offsets, const int32_t* row_map, const float* pair_weights,
+                                           int64_t P, int64_t x_div, int64_t num_experts, int64_t K, int64_t N, int64_t group_size,
+                                           uint32_t flags, void* stream);
+/* The (token, expert) pairs sorted by expert as an index list, one launch: order [num_pairs] = pair indices grouped by expert,
+ * pair order kept inside an expert (== torch.argsort(topk_ids.flatten(), stable=True)), seg_offsets [E + 1] = each expert's row
+ * range; ids outside [0, E) are not placed.  Replaces the argsort / scatter_add / cumsum glue of the prefill-sized path of
+ * apply_moe_weights (moe.py:45-91).  E <= 64. */
+AWQ_EXPORT int awq_moe_sort_pairs(const int32_t* topk_ids, int32_t* order, int32_t* seg_offsets, int64_t num_pairs,
+                                  int64_t num_experts, void* stream);
+
 /* ---- GEMV layout: qweight [N, K/8] i32 (ordinal nibbles), qzeros [N, ZW] i32, scales [N, 8*ZW] f16
  *      (awq/modules/linear/gemv.py:45-69; ZW = calculate_zeros_width, gemv.py:12-24) -------------- */
 

@@ -196,3 +196,94 @@ def test_moe_block_on_decode_twins_vs_oracle_and_vs_the_gemm_layout_path(ops, or
         assert ops.last_kernel() == "gemv_mfma_grouped"
     finally:
         moe.ROWS_MAX_PAIRS = saved
+
+
+# ---------------------------------------------------------------- prefill-sized token counts: the sort as an index list (round 6)
+
+@pytest.mark.parametrize("P,E", [(5, 8), (1024, 8), (3000, 8), (2049, 64), (64, 3)])
+def test_moe_sort_pairs_equals_stable_argsort(ops, P, E):
+    gen = torch.Generator().manual_seed(P + E)
+    ids = torch.randint(0, E, (P,), generator=gen).int()
+    if P > 100:
+        ids[::37] = -1      # pairs of foreign experts (expert-parallel shards) are not placed
+        ids[5::91] = E + 3
+    order, seg = ops.moe_sort_pairs(ids.cuda().view(-1, 1), E)
+    valid = (ids >= 0) & (ids < E)
+    key = torch.where(valid, ids, torch.full_like(ids, E)).long()
+    want = torch.argsort(key, stable=True)[: int(valid.sum())].int()
+    counts = torch.bincount(ids[valid].long(), minlength=E)
+    wseg = torch.zeros(E + 1, dtype=torch.int32)
+    wseg[1:] = torch.cumsum(counts, 0).int()
+    assert torch.equal(seg.cpu(), wseg)
+    assert torch.equal(order.cpu()[: int(valid.sum())], want)
+
+
+def test_moe_route_routing_only_many_tokens(ops):
+    T, E, k = 1537, 8, 2
+    logits = torch.randn((T, E), generator=torch.Generator().manual_seed(3)) * 2
+    w, ids, a, b, c = ops.moe_route(logits.cuda(), k, True, 0)
+    assert a is None and b is None and c is None
+    tw, ti = ops.fused_topk(logits.cuda(), k, True)
+    assert torch.equal(ids, ti) and torch.allclose(w, tw, rtol=1e-5, atol=1e-7)
+
+
+def test_grouped_prefill_gather_scatter_and_weights(ops):
+    """awq_grouped_gemm_prefill_ex against awq_grouped_gemm_prefill on explicitly gathered / scattered tensors: the same launch,
+    the sort kept as an index list -- bit for bit; routing weights within one fp16 rounding of fp16(product) * w."""
+    T, E, topk, K, N, g = 300, 8, 2, 512, 768, 128
+    gen = torch.Generator().manual_seed(17)
+    qw = torch.randint(MIN_INT32, MAX_INT32, (E, K, N // 8), dtype=torch.int32, generator=gen).cuda()
+    qz = torch.randint(MIN_INT32, MAX_INT32, (E, K // g, N // 8), dtype=torch.int32, generator=gen).cuda()
+    sc = (torch.rand((E, K // g, N), generator=gen) * 0.02 + 0.005).half().cuda()
+    x = torch.randn((T, K), generator=gen).half().cuda()
+    ids = torch.stack([torch.randperm(E, generator=gen)[:topk] for _ in range(T)]).int()
+    ids[:40, 0] = 5  # one crowded expert (several row tiles), and expert 6 emptied
+    ids[ids == 6] = 7
+    for t in range(T):
+        if ids[t, 0] == ids[t, 1]:
+            ids[t, 1] = (int(ids[t, 0]) + 1) % 6
+    ids = ids.cuda()
+    w = (torch.rand((T, topk), generator=gen) + 0.25).float().cuda()
+    order, seg = ops.moe_sort_pairs(ids, E)
+    P = T * topk
+    xs = x.index_select(0, (order // topk).long())
+    base = ops.grouped_gemm_prefill(xs, qw, sc, qz, seg)
+    got = ops.grouped_gemm_prefill_ex(x, qw, sc, qz, seg, order, x_div=topk, gather=True)
+    assert ops.last_kernel() == "gemm_regb_grouped" and torch.equal(got, base)
+    sorted_in = ops.grouped_gemm_prefill_ex(xs, qw, sc, qz, seg, order)
+    assert torch.equal(sorted_in, base)
+    scat = ops.grouped_gemm_prefill_ex(xs, qw, sc, qz, seg, order, scatter=True)
+    want = torch.empty_like(base)
+    want.index_copy_(0, order.long(), base)
+    assert torch.equal(scat, want)
+    sw = ops.grouped_gemm_prefill_ex(xs, qw, sc, qz, seg, order, scatter=True, pair_weights=w)
+    ref = want.float() * w.view(-1)[:, None]
+    assert ((sw.float() - ref).abs() <= 2.0 ** -10 * ref.abs() + 2.0 ** -24).all()
+    ones = ops.grouped_gemm_prefill_ex(xs, qw, sc, qz, seg, order, scatter=True, pair_weights=torch.ones_like(w))
+    assert torch.equal(ones, want)
+
+
+def test_moe_prefill_fused_glue_matches_the_torch_glue(ops):
+    from autoawq_amd.modules.fused import moe
+
+    T, E, H, I, g, topk = 512, 8, 512, 768, 128, 2
+    w1, w2 = gemm_stacks(E, H, I, g, seed=41)
+    a, b = Stack(), Stack()
+    for dst, src in ((a, w1), (b, w2)):
+        dst.qweight, dst.qzeros, dst.scales = src.qweight.cuda(), src.qzeros.cuda(), src.scales.cuda()
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn((T, H), generator=gen).half().cuda()
+    logits = torch.randn((T, E), generator=gen).cuda()
+    saved = moe.FUSED_PREFILL_GLUE
+    try:
+        moe.FUSED_PREFILL_GLUE = True
+        new = moe.apply_moe_weights(a, b, x, logits, topk, True)
+        moe.FUSED_PREFILL_GLUE = False
+        old = moe.apply_moe_weights(a, b, x, logits, topk, True)
+    finally:
+        moe.FUSED_PREFILL_GLUE = saved
+    # the same launches on the same rows; the routing weight now multiplies the fp32 product (one rounding) instead of its fp16
+    d = (new.float() - old.float()).abs()
+    # (each of a token's topk rows may move by one fp16 ulp of ITS magnitude before the sum; the strong checks are the bitwise
+    # kernel tests above and the oracle test of the module path)
+    assert float(d.max()) <= 4e-3 * float(old.float().abs().max()), float(d.max())
