@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restr
                                                            int* __restrict__ topk_ids, int* __restrict__ sorted_ids,
                                                            int* __restrict__ expert_ids, int* __restrict__ num_post_pad,
                                                            int T, int E, int k, int renorm, int block, int cap_sorted,
-                                                           int cap_blocks, int e0, int nl) {
+                                                           int cap_blocks, int e0, int nl, int routed) {
     __shared__ int counts[ROUTE_MAX_E], pad_start[ROUTE_MAX_E + 1];
     const int tid = threadIdx.x;
     const int P = T * k;
@@ -62,8 +62,15 @@ __global__ __launch_bounds__(256) void awq_moe_route_kernel(const float* __restr
     // run-time indexed private array -- scratch memory: 10 us for four tokens).  The arithmetic keeps its order: the softmax
     // denominator is summed over e = 0 .. E - 1 in sequence, the k selections take the first maximum.
     const int lane = tid & 63, wv = tid >> 6;
-    // (routing only: a grid of ceil(T / 4) blocks, one token per wave; with the alignment pass: ONE block walks all tokens)
-    for (int t = 4 * blockIdx.x + wv; t < T; t += 4 * gridDim.x) {
+    // (routing: a grid of ceil(T / 4) blocks, one token per wave.  With the alignment pass ONE block does both for up to 8 tokens;
+    // beyond, the launcher runs the routing as its own grid first and this block only counts the ids it wrote: routed < 0)
+    if (routed < 0) {
+        for (int i = tid; i < P; i += 256) {
+            const int e = topk_ids[i];
+            if (e >= e0 && e < e0 + nl) atomicAdd(&counts[e - e0], 1);
+        }
+    }
+    for (int t = 4 * blockIdx.x + wv; t < T && routed >= 0; t += 4 * gridDim.x) {
         const float lg = lane < E ? logits[(int64_t)t * E + lane] : -INFINITY;
         float mx = lg;
 #pragma unroll
@@ -133,8 +140,17 @@ int awq_launch_moe_route(const float* logits, float* topk_w, int* topk_ids, int*
     if (T < 1 || E < 1 || E > ROUTE_MAX_E || k < 1 || k > ROUTE_MAX_K || k > E || block < 0) return AWQ_ERR_UNSUPPORTED;
     if (first_expert < 0 || num_local < 1 || first_expert + num_local > E) return AWQ_ERR_BAD_SHAPE;
     const int P = T * k;
-    hipLaunchKernelGGL(awq_moe_route_kernel, dim3(block == 0 ? (unsigned)((T + 3) / 4) : 1u), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,
-                       num_post_pad, T, E, k, renorm, block, P + num_local * (block - 1), P + num_local, first_expert, num_local);
+    const int cap_sorted = P + num_local * (block - 1), cap_blocks = P + num_local;
+    if (block == 0 || T > 8) {  // the routing as a grid of its own (a wave per token), then -- if asked for -- one block aligns
+        hipLaunchKernelGGL(awq_moe_route_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,
+                           num_post_pad, T, E, k, renorm, 0, 0, 0, first_expert, num_local, 0);
+        if (block > 0)
+            hipLaunchKernelGGL(awq_moe_route_kernel, dim3(1), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,
+                               num_post_pad, T, E, k, renorm, block, cap_sorted, cap_blocks, first_expert, num_local, -1);
+    } else {
+        hipLaunchKernelGGL(awq_moe_route_kernel, dim3(1), dim3(256), 0, st, logits, topk_w, topk_ids, sorted_ids, expert_ids,
+                           num_post_pad, T, E, k, renorm, block, cap_sorted, cap_blocks, first_expert, num_local, 0);
+    }
     return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }
 
