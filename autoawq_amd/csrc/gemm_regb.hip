@@ -486,20 +486,32 @@ __global__ __launch_bounds__(WGM * 256, 2) void awq_gemm_regb_kernel(RegbParams 
         for (int h = 0; h < 2; ++h) {
             int orow[4][4];
             float wr[4][4];
+            // (ONE uniform branch per batch, not one per element: written as whole-batch alternatives so that hipcc keeps it that way)
+            if (p.scatter || p.pair_w) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = m0 + wm * 128 + 16 * (4 * h + i) + 4 * kb + e;
-                    orow[i][e] = (p.scatter || p.pair_w) ? p.row_map[min(row, m_hi - 1)] : row;
-                    wr[i][e] = 1.f;
-                }
+                    for (int e = 0; e < 4; ++e) orow[i][e] = p.row_map[min(m0 + wm * 128 + 16 * (4 * h + i) + 4 * kb + e, m_hi - 1)];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) orow[i][e] = m0 + wm * 128 + 16 * (4 * h + i) + 4 * kb + e;
+            }
             if (p.pair_w) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) wr[i][e] = p.pair_w[orow[i][e]];  // mul_routed_weight (moe.py:84-88): fp32 product, one rounding
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wr[i][e] = 1.f;
             }
+            // every load of the batch has landed before the first (conditional) store: nothing with a destination register is in
+            // the vector-memory queue across the 16 store branches (tools/isa_audit.py walks both sides of each with its queue state)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll

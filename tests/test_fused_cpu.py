@@ -184,3 +184,30 @@ def test_derived_weight_caches_follow_in_place_loads():
     assert not torch.equal(pq, p0)
     mlp.gate_proj_scales.mul_(2)                                        # any in-place write, not only load_state_dict
     assert torch.equal(mlp.gate_up_pairs()[1][0::2], mlp.gate_proj_scales)
+
+
+def test_gemm_stack_to_gemv_twin_holds_the_same_weights(oracle):
+    """utils/convert.py::gemm_stack_to_gemv (the MoE decode twins of round 6, built from the stacked GEMM-layout experts of
+    awq/models/mixtral.py:130-158): an integer repack -- every expert's dequantised rows equal the GEMM-layout expert's
+    dequantised columns bit for bit (both through the oracle), w1|w3 with its halves interleaved as (gate_j, up_j) row pairs."""
+    import numpy as np
+    import torch
+
+    from autoawq_amd.utils.convert import gemm_stack_to_gemv
+
+    E, K, N, g = 3, 256, 192, 128
+    gen = torch.Generator().manual_seed(4)
+    lim = 2 ** 31 - 1
+    qw = torch.randint(-lim - 1, lim, (E, K, N // 8), dtype=torch.int32, generator=gen)
+    qz = torch.randint(-lim - 1, lim, (E, K // g, N // 8), dtype=torch.int32, generator=gen)
+    sc = (torch.rand((E, K // g, N), generator=gen) * 0.02 + 0.005).half()
+    plain = gemm_stack_to_gemv(qw, qz, sc)
+    pairs = gemm_stack_to_gemv(qw, qz, sc, interleave_halves=True)
+    assert plain.qweight.shape == (E, N, K // 8) and plain.group_size == g and pairs.pairs and not plain.pairs
+    for e in range(E):
+        W = oracle.dequant_gemm(qw[e].numpy(), qz[e].numpy(), sc[e].numpy(), g)                                   # [K, N]
+        Wt = oracle.dequant_gemv(plain.qweight[e].numpy(), plain.qzeros[e].numpy(), plain.scales[e].numpy(), g)    # [K, N]
+        assert np.array_equal(np.asarray(Wt).view(np.uint16), np.asarray(W).view(np.uint16))
+        Wp = oracle.dequant_gemv(pairs.qweight[e].numpy(), pairs.qzeros[e].numpy(), pairs.scales[e].numpy(), g)
+        want = np.stack([W[:, : N // 2], W[:, N // 2:]], axis=2).reshape(K, N)
+        assert np.array_equal(np.asarray(Wp).view(np.uint16), np.ascontiguousarray(want).view(np.uint16))
