@@ -13,6 +13,6 @@ if [ "$2" == "full" ]; then
   (time AWQ_FULL_MATRIX=1 python -m pytest tests/ -q -m gpu) > $O/r06_pytest_gpu_full_matrix.log 2>&1; echo "pytest full rc=$?" >> $O/fingerprint.txt
 fi
 bash tools/prof_r06.sh $HEAD > $O/r06_prof.log 2>&1
-cp gpurun_out/r06_bench_kernel_trace_stats.txt gpurun_out/r06_pmc_fetch_size.txt gpurun_out/r06_pmc_gemm_bs.txt gpurun_out/r06_pmc_mfma_prefill.txt $O/ 2>/dev/null
+cp gpurun_out/r06_bench_kernel_trace_stats.txt gpurun_out/r06_pmc_fetch_size.txt gpurun_out/r06_pmc_gemm_bs.txt gpurun_out/r06_pmc_mfma_prefill.txt gpurun_out/r06_pmc_moe.txt $O/ 2>/dev/null
 python bench.py > $O/r06_bench_n1_final.json 2> $O/r06_bench_n1_final.err; echo "bench rc=$?" >> $O/fingerprint.txt
 cat $O/fingerprint.txt; tail -3 $O/r06_pytest_gpu_default.log; tail -3 $O/r06_pytest_gpu_full_matrix.log 2>/dev/null; cut -c1-300 $O/r06_bench_n1_final.json

@@ -1,11 +1,23 @@
+#!/bin/bash
+# MoE decode on GEMV-layout expert twins (round 6): the measurements behind profiles/r06_moe_rows.txt, on a GPU box:
+#   the tests of the path, the bs = 4 block (twins vs GEMM-layout stacks), the parts-per-matrix sweep on the bench's routing,
+#   the token sweep with the hand-over lifted, the prefill block, the dense small-batch probe.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r06c
+O=gpurun_out/moe_rows
 mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_moe_rows.py tests/test_gpu_parity.py tests/test_mixtral.py tests/test_gpu_ep.py tests/test_gpu_shims.py tests/test_gpu_baseline_configs.py tests/test_gpu_route_a_replay.py -x -q -m gpu -k "moe or grouped or mixtral or ep or route or Mixtral or regb" 2>&1 | tail -12 > $O/moe_prefill_tests.txt
-cat $O/moe_prefill_tests.txt
-rm -rf /tmp/prof_moe
-rocprofv3 --kernel-trace --stats -d /tmp/prof_moe -o moe -- python tools/bench_moe.py --prefill > $O/moe_prefill_prof.log 2>&1
-DB=$(find /tmp/prof_moe -name "*.db" | head -1)
-python tools/rocpd_summary.py $DB > $O/moe_prefill_fused_kernel_stats.txt 2>&1
-grep Mixtral $O/moe_prefill_prof.log; grep -i "awq\|calls" $O/moe_prefill_fused_kernel_stats.txt | cut -c1-180 | head -24
+timeout 1500 python -m pytest tests/test_gpu_moe_rows.py -x -q -m gpu 2>&1 | tail -5 | tee $O/tests.txt
+python tools/bench_moe.py 2>&1 | grep -v amdgpu.ids | tee $O/bench.txt
+timeout 900 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee $O/parts.txt
+import sys
+sys.path.insert(0, "tools"); sys.path.insert(0, ".")
+import bench_moe
+from autoawq_amd.modules.fused import moe
+for p1, p2 in ((64, 64), (128, 64), (256, 64), (512, 64), (256, 32), (256, 96), (0, 0)):
+    moe.ROWS_PARTS = (p1, p2)
+    print("parts", (p1, p2), end=": ")
+    bench_moe.run()
+PY
+python tools/bench_moe.py --sweep 2>&1 | grep -v amdgpu.ids | tee $O/sweep.txt
+python tools/bench_moe.py --prefill 2>&1 | grep -v amdgpu.ids | tee $O/prefill.txt
+python tools/probe_pairs_dense.py 2>&1 | grep -v amdgpu.ids | tee $O/pairs_dense.txt

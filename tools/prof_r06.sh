@@ -29,5 +29,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_bs_f -o 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_bs_w -o bs -- python tools/pmc_gemm_bs.py run > $O/r06_pmc_bs_w.log 2>&1
 { echo "# git head $HEAD; kernel source fingerprint: $FP"; echo "# rocprofv3 --pmc FETCH_SIZE (and, own pass, WRITE_SIZE) --kernel-trace -- python tools/pmc_gemm_bs.py run   (tools/prof_r06.sh): bench.py's gemm_bs legs, 4096 x 11008 g128, 28 distinct matrices"; grep "kernel" $O/r06_pmc_bs_f.log | sed 's/^/# /'; python tools/pmc_gemm_bs.py summarize $O/pmc_bs_f $O/pmc_bs_w $O/pmc_probe_r06; } > $O/r06_pmc_gemm_bs.txt 2>&1
 bash tools/pmc_mfma_r06.sh "$HEAD" "$FP" > $O/r06_pmc_mfma_prefill.txt 2>&1
+rm -rf $O/pmc_moe
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_moe -o moe -- python tools/bench_moe.py > $O/r06_pmc_moe.log 2>&1
+{ echo "# git head $HEAD; kernel source fingerprint: $FP"; echo "# rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/bench_moe.py   (own pass; tools/prof_r06.sh): the MoE decode block on the GEMV-layout twins (awq_gemv_rows_kernel, grouped form) and on the GEMM-layout stacks (awq_gemv_mfma_kernel, grouped)"; grep Mixtral $O/r06_pmc_moe.log | cut -c1-400; python tools/pmc_moe.py $O/pmc_moe; } > $O/r06_pmc_moe.txt 2>&1
+rm -rf $O/pmc_moe
 rm -rf $O/pmc_r06 $O/pmc_probe_r06 $O/pmc_bs_f $O/pmc_bs_w $O/bin
+cat $O/r06_pmc_moe.txt
 tail -12 $O/r06_bench_kernel_trace_stats.txt 2>/dev/null; tail -8 $O/r06_pmc_fetch_size.txt; cat $O/r06_pmc_gemm_bs.txt; tail -20 $O/r06_pmc_mfma_prefill.txt
