@@ -97,7 +97,7 @@ def test_regb_prefill_kernel_directly_at_config3_shape(ops, oracle, K, N, bm):
 @pytest.mark.parametrize("K,N,M", [(4096, 11008, 16384), (11008, 4096, 2048), (4096, 12288, 130), (4096, 4096, 97), (1024, 200, 300),
                                    (512, 64, 70), (3584, 8192, 257), (8192, 1280, 128)])
 @pytest.mark.parametrize("bm", [1, 2])
-def test_gemvfast_layout_prefill_route_vs_oracle(ops, oracle, K, N, M, bm):
+def test_gemvfast_layout_prefill_route_vs_oracle_unpinned_in_the_reference(ops, oracle, K, N, M, bm):
     """Round 6: the prefill route of WQLinear_GEMVFast (the reference runs awq_v2_ext.gemm_forward_cuda_prefill there,
     awq/modules/linear/gemv_fast.py:203-206) as TWO hand-written launches -- csrc/repack.hip (GEMVFast words -> GEMM-layout words,
     bit-exact against utils/convert.py's torch unpack) + csrc/gemm_regb.hip in its FZ form (W = fp16(w s + qzeros), this format's own
@@ -366,7 +366,7 @@ def _rand_gemm_module(K, N, g, gen):
     return m
 
 
-def test_mixtral_shape_moe_block_built_with_fuse_linears_vs_oracle(ops, oracle):
+def test_mixtral_shape_moe_block_built_with_fuse_linears_vs_oracle_unpinned_in_the_reference(ops, oracle):
     """BASELINE config 5 at its real shape: E = 8, top-2, hidden 4096, intermediate 14336, 4 tokens.
     The expert stacks are built exactly like awq/models/mixtral.py:131-151 does (fuse_linears([w1, w3]) per
     expert on N, then fuse_linears(..., dim=0, operation=torch.stack) over the experts, the same for w2);

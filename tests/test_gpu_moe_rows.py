@@ -45,7 +45,7 @@ SHAPES = [(256, 512), (512, 250), (1024, 96), (4096, 1024), (6144, 256), (8192, 
 
 @pytest.mark.parametrize("K,N", SHAPES)
 @pytest.mark.parametrize("T,topk", [(1, 2), (4, 2), (5, 3), (8, 1)])
-def test_grouped_rows_kernel_vs_oracle_and_vs_per_pair_launches(ops, oracle, K, N, T, topk):
+def test_grouped_rows_kernel_vs_oracle_and_vs_per_pair_launches_unpinned_in_the_reference(ops, oracle, K, N, T, topk):
     E, g = 8, 128
     qw, qz, sc = gemv_stack(E, K, N, g, seed=K + N + T)
     gen = torch.Generator().manual_seed(T * 31 + topk)
@@ -153,7 +153,7 @@ def test_gemm_stack_to_gemv_is_the_same_weights(ops, oracle):
 
 
 @pytest.mark.parametrize("T", [1, 4, 6])
-def test_moe_block_on_decode_twins_vs_oracle_and_vs_the_gemm_layout_path(ops, oracle, T):
+def test_moe_block_on_decode_twins_vs_oracle_and_vs_the_gemm_layout_path_unpinned_in_the_reference(ops, oracle, T):
     from autoawq_amd.modules.fused import moe
 
     E, H, I, g, topk = 8, 512, 768, 128, 2

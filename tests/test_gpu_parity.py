@@ -889,7 +889,7 @@ def stacked_experts(E, K, N, g, seed):
 
 @pytest.mark.parametrize("rows", [8, 16])
 @pytest.mark.parametrize("T,E,topk,K,N", [(4, 8, 2, 256, 512), (1, 8, 2, 512, 256), (19, 4, 2, 256, 1024), (40, 8, 2, 128, 256)])
-def test_grouped_gemm_vs_oracle(ops, oracle, T, E, topk, K, N, rows):
+def test_grouped_gemm_vs_oracle_unpinned_in_the_reference(ops, oracle, T, E, topk, K, N, rows):
     """grouped_gemm_forward (moe.py:60-89): every (token, slot) pair against its own expert."""
     g = 128
     qw, qz, sc = stacked_experts(E, K, N, g, seed=T + E + K)
@@ -916,7 +916,7 @@ def test_grouped_gemm_vs_oracle(ops, oracle, T, E, topk, K, N, rows):
     assert ops.workspace_is_clean(y.device)
 
 
-def test_moe_block_vs_oracle(ops, oracle):
+def test_moe_block_vs_oracle_unpinned_in_the_reference(ops, oracle):
     """FusedSparseMoeBlock / apply_moe_weights (moe.py:12-91) on a Mixtral-shaped toy: E=8, top-2."""
     from autoawq_amd.modules.fused.moe import FusedSparseMoeBlock
 
@@ -975,7 +975,7 @@ def test_moe_activation_folded_into_w2_is_bit_identical(ops, T):
     assert torch.equal(a, b)
 
 
-def test_moe_prefill_path_vs_oracle_and_vs_the_block_path(ops, oracle):
+def test_moe_prefill_path_vs_oracle_and_vs_the_block_path_unpinned_in_the_reference(ops, oracle):
     """T = 512 tokens, top-2 of 8 experts (1024 pairs, ~128 rows per expert): apply_moe_weights sorts the pairs by expert on the
     device and runs ONE grouped launch of the register-decoded MFMA GEMM per projection (awq_grouped_gemm_prefill,
     modules/fused/moe.py::_apply_moe_prefill; round 3: one GEMM per expert and a host read-back).  Against the CPU oracle on a
@@ -1134,7 +1134,7 @@ def test_gemvfast_layout_golden(ops, oracle, name):
 
 @pytest.mark.parametrize("K,N,g", [(4096, 4096, 128), (11008, 4096, 128), (1024, 80, 64), (512, 48, 32), (2048, 208, 2048)])
 @pytest.mark.parametrize("M", [1, 3, 8, 16, 20])
-def test_gemvfast_layout_vs_oracle(ops, oracle, K, N, g, M):
+def test_gemvfast_layout_vs_oracle_unpinned_in_the_reference(ops, oracle, K, N, g, M):
     qw, sc, qz, x = gemvfast_case(K, N, g, M, seed=K + N + M)
     W = oracle.dequant_gemvfast(qw.numpy(), sc.numpy(), qz.numpy(), g)
     Wt = ops.dequantize_weights_gemv_fast(qw.cuda(), sc.cuda(), qz.cuda(), g)
@@ -1155,7 +1155,7 @@ def test_gemvfast_layout_vs_oracle(ops, oracle, K, N, g, M):
 
 
 @pytest.mark.parametrize("K,N", [(4096, 11008), (4096, 4096), (11008, 4096), (8192, 1280), (1024, 8192), (256, 16), (4224, 208)])
-def test_gemvfast_batch_kernel_vs_oracle(ops, oracle, K, N):
+def test_gemvfast_batch_kernel_vs_oracle_unpinned_in_the_reference(ops, oracle, K, N):
     """csrc/gemv_batch.hip in its GEMVFast form (round 5: the batched kernel on qweight int16 [N/4, K], scales / qzeros fp16 [GP, N]; the
     reference runs awq_v2_ext.gemm_forward_cuda_prefill there, gemv_fast.py:203-206): 7B and 70B-shard shapes, one and several passes
     over K, few tiles, every ring form, batches 1 .. 128 (round 6: one launch, 33 .. 128 rows as two / four row parts of a block); against the oracle's W = fp16(w s + qzeros) and fp32 product;
