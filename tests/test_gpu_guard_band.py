@@ -25,6 +25,8 @@ SUBSET = ("test_gemv_rows_kernel_vs_oracle or test_gemv_rows_block_fusions or co
 COMPACT = ("(test_gemv_rows_kernel_vs_oracle and (4096-4096-128 or 11008-4096-128 or 4096-4099 or 384-7 or 1280-10 or 2048-200 or 256-16)) or "
            "(test_gemv_batch_kernel_vs_oracle and (4096-11008 or 11008-4096 or 2048-4099 or 16512-72 or 256-16 or 1024-200)) or "
            "(test_gemvfast_layout_prefill_route_vs_oracle and (1-1024-200 or 1-512-64 or 1-4096-4096)) or "  # round 6: the FZ form + its repack, ragged N
+           "(test_grouped_rows_kernel_vs_oracle and (5-3-512-250 or 4-2-14336-256 or 1-2-1024-96)) or test_grouped_prefill_gather_scatter or "  # round 6: MoE decode twins,
+           "test_moe_sort_pairs or test_moe_route_routing_only or "                                                                                # the index-list prefill
            "test_gemv_batch_refuses or repack or prefill_attention or test_decode_attention_vs_oracle or unpack or "
            "test_dequant_golden or test_gemm_golden or test_moe_block_vs_oracle or rmsnorm or rope_kv or test_gemvfast_layout_golden")
 
