@@ -80,7 +80,7 @@ SIGNATURES = {
                                  c_int64, c_uint32, c_void_p]),
     "awq_gemv_auto_kernel": (c_int, [c_int64, c_int64, c_int64, c_int64]),
     "awq_gemv_forward_ex": (c_int, [ctypes.POINTER(AwqGemvEx)]),
-    "awq_grouped_gemv_forward": (c_int, [c_void_p] * 7 + [c_int64] * 7 + [c_uint32, c_int64, c_void_p]),
+    "awq_grouped_gemv_forward": (c_int, [c_void_p] * 7 + [c_int64] * 8 + [c_uint32, c_int64, c_void_p]),
     "awq_gemv_lds_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "awq_dequantize_weights_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                             c_int64, c_void_p]),

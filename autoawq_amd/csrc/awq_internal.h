@@ -101,6 +101,7 @@ struct AwqRowsFx {  // decoder-block prologue / epilogue of the row-streaming ke
     const int32_t* pair_expert = nullptr;  // [num_pairs] on the device; a value outside [0, num_experts) skips the pair
     const float* pair_scale = nullptr;     // [num_pairs] routing weights folded into the epilogue, or null
     int num_pairs = 0, num_experts = 0, x_div = 1;
+    int first_expert = 0;                  // pair_expert holds global ids; the stack holds experts [first_expert, first_expert + num_experts)
     int parts = 0;                         // blocks one expert matrix is dealt over (0 = auto)
 };
 int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,

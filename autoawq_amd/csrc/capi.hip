@@ -500,9 +500,10 @@ int awq_gemv_forward_ex(const AwqGemvEx* e) {
 
 int awq_grouped_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                              uint16_t* y, const int32_t* pair_experts, const float* pair_weights, int64_t num_pairs,
-                             int64_t x_div, int64_t num_experts, int64_t K, int64_t N, int64_t group_size,
+                             int64_t x_div, int64_t num_experts, int64_t first_expert, int64_t K, int64_t N, int64_t group_size,
                              int64_t zeros_width, uint32_t flags, int64_t parts, void* stream) {
     const int64_t g = group_size, ZW = zeros_width;
+    if (first_expert < 0 || first_expert > INT32_MAX) return AWQ_ERR_BAD_SHAPE;
     if (K <= 0 || N < 0 || g <= 0 || K % g || K % 8 || ZW <= 0 || ZW * 8 < K / g) return AWQ_ERR_BAD_SHAPE;
     if (num_pairs < 0 || num_experts < 1 || x_div < 1 || parts < 0 || K > INT32_MAX || N > INT32_MAX || num_experts > INT32_MAX ||
         (flags & ~AWQ_GEMV_EX_SILU_PAIRS))
@@ -521,6 +522,7 @@ int awq_grouped_gemv_forward(const uint16_t* x, const int32_t* qweight, const ui
     fx.pair_scale = pair_weights;
     fx.num_pairs = (int)num_pairs;
     fx.num_experts = (int)num_experts;
+    fx.first_expert = (int)first_expert;
     fx.x_div = (int)x_div;
     fx.parts = (int)parts;
     g_last_kernel = "gemv_rows_grouped";

@@ -91,6 +91,7 @@ struct RowsParams {
     const int* pair_expert;     // [pairs] expert of pair i (topk_ids flattened); outside [0, E): the pair's rows are not written
     const float* pair_scale;    // FX_SCALE: y := fp16(W x * pair_scale[i]) (fp32 product, one rounding)
     int E, parts;               // parts = blocks one matrix is dealt over
+    int e_first;                // expert-parallel shards: pair_expert holds GLOBAL ids, this stack holds experts [e_first, e_first + E)
     uint32_t x_div_magic;       // x row of pair i = i / x_div = (i * magic) >> 32; 0: x_div == 1
     int y_pitch, y_rows;        // halfs between the y rows of two pairs; number of pairs (grid.x = 8 * y_rows)
     long long w_stride, z_stride, s_stride;  // bytes between two experts' qweight / qzeros / scales
@@ -109,6 +110,22 @@ AWQ_DEV float dpp_mov(float v) {
 AWQ_DEV float dot2(uint32_t a, uint32_t b, float c) { return __builtin_amdgcn_fdot2(u2h2(a), u2h2(b), c, false); }
 AWQ_DEV float4_t mfma4(u32x2 a, u32x2 b, float4_t c) {
     return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, a), __builtin_bit_cast(half4_t, b), c, 0, 0, 0);
+}
+
+// FX_NORM: one fp16 pair through the norm, fp16(fp32(fp32(x) * inv) * fp32(w)) -- the arithmetic of awq_rmsnorm_kernel, in four
+// mixed-precision FMAs (v_fma_mix reads the fp16 halves directly and rounds like the separate multiplies: the addend is -0.0, so
+// signed zeros survive) instead of four converts, four multiplies and a packing convert.
+AWQ_DEV uint32_t norm_pair(uint32_t x2, uint32_t w2, float inv) {
+    float t0, t1;
+    uint32_t r;
+    const float nz = -0.0f;  // (the addend: x * y + (-0.0) == x * y for every x * y, signed zeros included)
+    asm("v_fma_mix_f32 %0, %2, %3, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %2, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(t0), "=&v"(t1) : "v"(x2), "v"(inv), "v"(nz));
+    asm("v_fma_mixlo_f16 %0, %1, %3, %4 op_sel_hi:[0,1,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,1,0]"
+        : "=&v"(r) : "v"(t0), "v"(t1), "v"(w2), "v"(nz));
+    return r;
 }
 
 // One round's request: four weight units, non-temporal.  The SGPR base is the tensor pointer itself (a kernel argument,
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
         const int pr = blockIdx.x >> 3;
         part = 8 * blockIdx.y + (blockIdx.x & 7);
         if (part >= p.parts) return;
-        const int e = p.pair_expert[pr];  // (scalar load: uniform index)
+        const int e = p.pair_expert[pr] - p.e_first;  // (scalar load: uniform index)
         if ((unsigned)e >= (unsigned)p.E) return;
         qw_base = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.qweight) + (long long)e * p.w_stride);
         qz_base = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.qzeros) + (long long)e * p.z_stride);
@@ -376,7 +393,24 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
     float inv = 1.f;
     const u32x2 sum_rows = {(lane & 3) == 0 ? 0x3C003C00u : ((lane & 3) == 1 ? 0x64006400u : 0u),
                             (lane & 3) == 0 ? 0x3C003C00u : ((lane & 3) == 1 ? 0x54005400u : 0u)};
-    if constexpr (FX & FX_NORM) {  // the row statistic: a wave covers the whole row (wk == 1), inactive lanes add nothing
+    constexpr int SB = SL <= 3 ? SL : (SL == 8 ? 1 : 2);  // slots per LDS -> register batch: 16 SB registers in flight (SL = 8 has none to spare)
+    // FX_NORM with the whole row in ONE batch (SL <= 3: K <= 6144): the row statistic is taken from the batch's own registers, and
+    // the norm weights are read in the same batch -- no second pass over x in LDS (round 6: 7.38 -> 7.05 us on qkv with the DPP sum
+    // and the mixed-precision FMAs, profiles/r06_fx_overhead.txt)
+    constexpr bool NORM_INLINE = (FX & FX_NORM) && SB == SL;
+    auto wave_sum = [&](float ss) __attribute__((always_inline)) {
+        // without the LDS crossbar (six dependent ds_bpermute round trips on the launch's critical path): DPP inside the 16-lane
+        // rows, then the four row sums through scalar registers
+        ss += dpp_mov<0xB1>(ss);   // quad_perm [1,0,3,2]
+        ss += dpp_mov<0x4E>(ss);   // quad_perm [2,3,0,1]
+        ss += dpp_mov<0x124>(ss);  // row_ror:4
+        ss += dpp_mov<0x128>(ss);  // row_ror:8
+        const int si = __builtin_bit_cast(int, ss);
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(si, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(si, 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(si, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(si, 48));
+        return (r0 + r1) + (r2 + r3);
+    };
+    if constexpr ((FX & FX_NORM) && !NORM_INLINE) {  // the row statistic: a wave covers the whole row (wk == 1), inactive lanes add nothing
         float ss = 0.f;
 #pragma unroll
         for (int s = 0; s < SL; ++s)
@@ -388,8 +422,7 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                 for (int i = 0; i < 4; ++i) q = dot2(d[i], d[i], q);
                 ss += q;  // (a lane without a chunk reads the zero chunk)
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        ss = wave_sum(ss);
         inv = rsqrtf(ss / (float)p.K + p.norm_eps);
     }
 #pragma unroll
@@ -398,7 +431,6 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
         // The LDS reads are inline asm, a BATCH of slots at a time behind ONE wait (left to the compiler, the reads of a slot
         // went out two at a time with a wait after each pair: 0.48 us for 8 reads at K = 4096, 1.28 us at K = 11008, on the
         // critical path of the launch -- profiles/r03_gemv_rows_trace.txt); the C0 / SX sums run as four independent chains.
-        constexpr int SB = SL <= 3 ? SL : (SL == 8 ? 1 : 2);  // slots per batch: 16 SB registers in flight (SL = 8 has none to spare)
         static_assert(SL % SB == 0, "batches cover the slots");
 #pragma unroll
         for (int s0 = 0; s0 < SL; s0 += SB) {
@@ -411,10 +443,34 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
                     if constexpr (!(AWQ_ROWS_DBG & 2))
                         asm volatile("ds_read_b128 %0, %1" : "=&v"(dj[sb][j]) : "v"(lds0 + (uint32_t)(((m * 4 + j) * Cq + cidx[s0 + sb]) * 16)));
                 }
+            u32x4 wj[NORM_INLINE ? SB : 1][4];
+            if constexpr (NORM_INLINE) {
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(wj[sb][j]) : "v"(lds0 + (uint32_t)(((MM * 4 + j) * Cq + cidx[s0 + sb]) * 16)));
+            }
             if constexpr (!(AWQ_ROWS_DBG & 2)) {
 #pragma unroll
                 for (int sb = 0; sb < SB; ++sb)  // (LDS operations return in order: the first wait covers every read of the batch)
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dj[sb][0]), "+v"(dj[sb][1]), "+v"(dj[sb][2]), "+v"(dj[sb][3]));
+            }
+            if constexpr (NORM_INLINE) {
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wj[sb][0]), "+v"(wj[sb][1]), "+v"(wj[sb][2]), "+v"(wj[sb][3]));
+                float ss = 0.f;  // the row statistic, summed in the order of the separate pass (slot, piece, pair)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float q = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) q = dot2(dj[sb][j][i], dj[sb][j][i], q);
+                        ss += q;  // (a lane without a chunk read the zero chunk)
+                    }
+                inv = rsqrtf(wave_sum(ss) / (float)p.K + p.norm_eps);
             }
 #pragma unroll
             for (int sb = 0; sb < SB; ++sb) {
@@ -423,16 +479,13 @@ __global__ __launch_bounds__(512) void awq_gemv_rows_kernel(RowsParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     u32x4 d = dj[sb][j];
-                    if constexpr (FX & FX_NORM) {
+                    if constexpr (NORM_INLINE) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d[i] = norm_pair(d[i], wj[sb][j][i], inv);  // == awq_rmsnorm_kernel
+                    } else if constexpr (FX & FX_NORM) {
                         const u32x4 wv = *reinterpret_cast<const u32x4*>(smem + (size_t)(((MM * 4 + j) * Cq + cidx[s]) * 16));
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const half2_t a = u2h2(d[i]), gw = u2h2(wv[i]);
-                            half2_t o;
-                            o[0] = (half_t)((float)a[0] * inv * (float)gw[0]);  // == awq_rmsnorm_kernel
-                            o[1] = (half_t)((float)a[1] * inv * (float)gw[1]);
-                            d[i] = h22u(o);
-                        }
+                        for (int i = 0; i < 4; ++i) d[i] = norm_pair(d[i], wv[i], inv);  // == awq_rmsnorm_kernel
                     }
                     xp[m][s][4 * j + 0] = __builtin_amdgcn_perm(d[2], d[0], 0x05040100u);  // (x0, x4)  bias 1024
                     xp[m][s][4 * j + 1] = __builtin_amdgcn_perm(d[2], d[0], 0x07060302u);  // (x1, x5)  bias 64
@@ -815,12 +868,13 @@ int awq_launch_gemv_rows(const uint16_t* x, const int32_t* qweight, const uint16
     p.norm_eps = fxa ? fxa->norm_eps : 0.f;
     p.res = fxa ? reinterpret_cast<const half_t*>(fxa->res) : nullptr;
     p.pair_expert = nullptr; p.pair_scale = nullptr;
-    p.E = 0; p.parts = blocks; p.x_div_magic = 0; p.y_pitch = 0; p.y_rows = 0;
+    p.E = 0; p.parts = blocks; p.x_div_magic = 0; p.y_pitch = 0; p.y_rows = 0; p.e_first = 0;
     p.w_stride = p.z_stride = p.s_stride = 0;
     if (fx & FX_GROUPED) {
         p.pair_expert = fxa->pair_expert;
         p.pair_scale = fxa->pair_scale;
         p.E = fxa->num_experts;
+        p.e_first = fxa->first_expert;
         p.y_rows = fxa->num_pairs;
         p.y_pitch = (fx & FX_PAIRS) ? N / 2 : N;
         if (fxa->x_div > 1 && !awq_magic_u32((uint32_t)fxa->x_div, (uint32_t)fxa->num_pairs + 1u, &p.x_div_magic)) return AWQ_ERR_UNSUPPORTED;

@@ -69,6 +69,13 @@ def apply_moe_weights_local(w1, w2, x, gating_output, topk, renormalize, e0):
     """This rank's part of apply_moe_weights (awq/modules/fused/moe.py:45-91): [T, H] partial sums over the pairs
     routed to experts [e0, e0 + w1.qweight.shape[0]); the sum over ranks is the reference result."""
     num_local = w1.qweight.shape[0]
+    t1, t2 = getattr(w1, "decode_twin", None), getattr(w2, "decode_twin", None)
+    if t1 is not None and t2 is not None and x.shape[0] * topk <= _moe.ROWS_MAX_PAIRS and x.is_cuda:
+        # decode on GEMV-layout twins of the OWNED experts (ExpertShard.build_decode_twins): the router's global ids go to the
+        # launch as they are, pairs of foreign experts are skipped there and their rows stay zero
+        out = _moe._apply_moe_rows(t1, t2, x, gating_output, topk, renormalize, first_expert=e0)
+        if out is not None:
+            return out
     rows = _moe.DECODE_BLOCK_ROWS if x.shape[0] * topk <= _moe.DECODE_MAX_PAIRS else _moe.BLOCK_ROWS
     one_launch = gating_output.is_cuda and gating_output.shape[1] <= 64 and topk <= 8 and x.shape[0] <= 1024
     if one_launch:  # softmax + top-k over ALL experts (identical on every rank) + placement of the owned pairs, one kernel
@@ -107,6 +114,8 @@ class ExpertParallelSparseMoeBlock(nn.Module):
             raise ValueError(f"{world} ranks for {self.num_experts} experts: an expert is the indivisible unit here")
         self.e0, self.e1 = expert_bounds(self.num_experts, rank, world)
         self.ws, self.w2s = ExpertShard(ws, self.e0, self.e1), ExpertShard(w2s, self.e0, self.e1)
+        if getattr(ws, "decode_twin", None) is not None and self.ws.qweight.is_cuda:
+            _moe.build_decode_twins(self.ws, self.w2s)  # the unsharded block had decode twins: so does the shard (of ITS experts)
 
     def forward(self, hidden_states):
         batch_size, sequence_length, hidden_dim = hidden_states.shape

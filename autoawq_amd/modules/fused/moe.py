@@ -117,21 +117,25 @@ def _apply_moe_prefill(w1, w2, x, gating_output, topk, renormalize):
     return out.view(T, topk, H).sum(dim=1)
 
 
-def _apply_moe_rows(t1, t2, x, gating_output, topk, renormalize):
+def _apply_moe_rows(t1, t2, x, gating_output, topk, renormalize, first_expert=0):
     """Decode on the GEMV-layout twins: softmax / top-k, ONE launch of the row-streaming kernel for w1|w3 over all pairs with
     silu(gate) * up written by the launch itself, ONE for w2 with the routing weight in its epilogue, the top-k sum.  No
-    alignment pass (no blocks: every pair is a batch-1 call), nothing read back.  None: a shape the kernel does not take."""
+    alignment pass (no blocks: every pair is a batch-1 call), nothing read back.  None: a shape the kernel does not take.
+    first_expert (expert-parallel shards, autoawq_amd/ep.py): the twins hold experts [first_expert, first_expert + E) of the
+    router's global ids; the rows of the other pairs stay zero, i.e. the result is this rank's partial sum."""
     in_dtype = x.dtype
     xh = x.half() if in_dtype != torch.float16 else x
-    num_experts = t1.qweight.shape[0]
+    num_experts = gating_output.shape[1]
+    local = first_expert != 0 or t1.qweight.shape[0] != num_experts
     if num_experts <= 64 and topk <= 8 and x.shape[0] <= 1024:
         topk_weights, topk_ids = ops.moe_route(gating_output, topk, renormalize, 0)[:2]  # routing only: no alignment pass
     else:
         topk_weights, topk_ids = fused_topk(gating_output, topk, renormalize)
     try:
-        act = ops.grouped_gemv_forward(xh, t1.qweight, t1.scales, t1.qzeros, topk_ids, t1.group_size, silu_pairs=True, parts=ROWS_PARTS[0])
+        act = ops.grouped_gemv_forward(xh, t1.qweight, t1.scales, t1.qzeros, topk_ids, t1.group_size, silu_pairs=True, parts=ROWS_PARTS[0],
+                                       first_expert=first_expert, zero_init=local)
         out = ops.grouped_gemv_forward(act.view(-1, act.shape[-1]), t2.qweight, t2.scales, t2.qzeros, topk_ids, t2.group_size,
-                                       topk_weights=topk_weights, parts=ROWS_PARTS[1])
+                                       topk_weights=topk_weights, parts=ROWS_PARTS[1], first_expert=first_expert, zero_init=local)
     except ops._lib.AwqHipError as e:
         if getattr(e, "code", 0) != -3:
             raise

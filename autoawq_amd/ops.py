@@ -470,13 +470,14 @@ def grouped_gemm_forward(x, qweight, scales, qzeros, topk_weights, sorted_token_
 
 
 def grouped_gemv_forward(x, qweight, scales, qzeros, topk_ids, group_size, topk_weights=None, silu_pairs=False, parts=0,
-                         zero_init=False):
+                         zero_init=False, first_expert=0):
     """MoE decode on GEMV-layout expert stacks (awq_grouped_gemv_forward; the decode-sized calls of
     awq/modules/fused/moe.py:60-89): x [T, K] (every token feeds its topk pairs) or [T * topk, K] (one row per pair) fp16,
     qweight [E, N, K/8] i32, qzeros [E, N, ZW] i32, scales [E, N, 8 ZW] fp16, topk_ids [T, topk] i32 on the device.
     Returns [T, topk, N] (N / 2 with silu_pairs: rows (2 j, 2 j + 1) of every expert = (gate_j, up_j), silu(gate) * up
     written by the launch); topk_weights [T, topk] fp32 multiplies each pair's row before its one rounding.  One launch of
-    the row-streaming kernel for all pairs; pairs whose id is outside [0, E) are skipped (zero_init: their rows read as 0)."""
+    the row-streaming kernel for all pairs; the stack holds experts [first_expert, first_expert + E) of topk_ids' global ids
+    and pairs of other experts are skipped (expert-parallel shards; zero_init: their rows read as 0)."""
     _require_gpu(x, qweight, scales, qzeros, topk_ids, topk_weights)
     if x.dtype != torch.float16 or topk_ids.dtype != torch.int32:
         raise _lib.AwqHipError("grouped_gemv_forward expects fp16 activations and int32 topk_ids")
@@ -498,7 +499,7 @@ def grouped_gemv_forward(x, qweight, scales, qzeros, topk_ids, group_size, topk_
     y = (torch.zeros if zero_init else torch.empty)((T, topk, N // 2 if silu_pairs else N), dtype=torch.float16, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.lib().awq_grouped_gemv_forward(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(y), _ptr(topk_ids),
-                                                 _ptr(w), P, x_div, E, K, N, group_size, ZW,
+                                                 _ptr(w), P, x_div, E, first_expert, K, N, group_size, ZW,
                                                  GEMV_EX_SILU_PAIRS if silu_pairs else 0, parts, _stream())
     _lib.check(rc, "awq_grouped_gemv_forward")
     return y

@@ -410,8 +410,9 @@ AWQ_EXPORT int awq_gemv_forward_ex(const AwqGemvEx* args);
  * qweight [E, N, K/8] int32, qzeros [E, N, ZW] int32, scales [E, N, 8 ZW] fp16 -- and runs every (token, expert) pair as one
  * batch-1 call of the row-streaming kernel (csrc/gemv_rows.hip), all pairs in ONE launch:
  *   y[i] = x[i / x_div] @ W[pair_experts[i]]^T            i = 0 .. num_pairs - 1, pair i = token * topk + slot
- * pair_experts [num_pairs] int32 ON THE DEVICE (= topk_ids flattened; nothing is read back: capturable); an id outside
- * [0, num_experts) leaves row i of y untouched (expert-parallel shards).  x_div = topk for the w1|w3 call (x = the tokens),
+ * pair_experts [num_pairs] int32 ON THE DEVICE (= topk_ids flattened; nothing is read back: capturable); the stack holds the experts
+ * [first_expert, first_expert + num_experts) of those GLOBAL ids (first_expert = 0: all of them) and a pair of any other expert
+ * leaves row i of y untouched (expert-parallel shards: zero y first).  x_div = topk for the w1|w3 call (x = the tokens),
  * 1 for the w2 call (x = one row per pair).
  *   pair_weights != NULL              y[i] = fp16(fp32 product * pair_weights[i]) (mul_routed_weight, moe.py:84-88)
  *   AWQ_GEMV_EX_SILU_PAIRS (flags)    rows (2 j, 2 j + 1) of every expert are (gate_j, up_j); y [num_pairs, N / 2] =
@@ -421,8 +422,8 @@ AWQ_EXPORT int awq_gemv_forward_ex(const AwqGemvEx* args);
  * AWQ_ERR_UNSUPPORTED: K > 16384, group_size % 128, num_pairs > 8191 -- the caller keeps the GEMM-layout grouped kernel. */
 AWQ_EXPORT int awq_grouped_gemv_forward(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
                                         uint16_t* y, const int32_t* pair_experts, const float* pair_weights, int64_t num_pairs,
-                                        int64_t x_div, int64_t num_experts, int64_t K, int64_t N, int64_t group_size,
-                                        int64_t zeros_width, uint32_t flags, int64_t parts, void* stream);
+                                        int64_t x_div, int64_t num_experts, int64_t first_expert, int64_t K, int64_t N,
+                                        int64_t group_size, int64_t zeros_width, uint32_t flags, int64_t parts, void* stream);
 
 /* awq_rope_kv_append + awq_decode_attention in ONE launch for a decode step (S = 1, full rotary,
  * head_dim = 128): qkv [B, (n_heads + 2*n_kv_heads) * 128] is the fused projection's output; query

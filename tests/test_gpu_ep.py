@@ -79,3 +79,38 @@ def test_expert_parallel_rank_step_is_graph_capturable():
         want2 = ep.apply_moe_weights_local(a, b, x, logits, topk, True, 2)
         s.synchronize()
     assert torch.equal(got2, want2)
+
+
+@pytest.mark.parametrize("E,T,topk,world", [(8, 4, 2, 2), (8, 4, 2, 8), (8, 1, 2, 4), (6, 6, 2, 3)])
+def test_expert_parallel_ranks_on_decode_twins_sum_to_the_unsharded_block(E, T, topk, world):
+    """round 6: a shard with GEMV-layout twins of ITS experts runs the decode step through the grouped row-streaming launch
+    (the router's global ids, first_expert = the shard's first: pairs of foreign experts are skipped and stay zero); the ranks'
+    partial sums add up to the unsharded block on its twins and on its GEMM-layout stacks."""
+    from autoawq_amd import _lib, ep, ops
+    from autoawq_amd.modules.fused import moe as _moe
+
+    _lib.lib()
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(E * 10 + T)
+    H, I = 1024, 2816
+    w1, w2 = _stack(E, H, 2 * I, gen, dev), _stack(E, I, H, gen, dev)
+    x = torch.randn((T, H), device=dev, generator=gen).half()
+    logits = torch.randn((T, E), device=dev, generator=gen)
+    base = _moe.apply_moe_weights(w1, w2, x, logits, topk, True).float()
+    assert ops.last_kernel() == "gemv_mfma_grouped"
+    total = torch.zeros_like(base)
+    for r in range(world):
+        e0, e1 = ep.expert_bounds(E, r, world)
+        a, b = ep.ExpertShard(w1, e0, e1), ep.ExpertShard(w2, e0, e1)
+        _moe.build_decode_twins(a, b)
+        part = ep.apply_moe_weights_local(a, b, x, logits, topk, True, e0)
+        assert ops.last_kernel() == "gemv_rows_grouped"
+        assert bool(torch.isfinite(part).all())
+        total += part.float()
+    _moe.build_decode_twins(w1, w2)
+    full = _moe.apply_moe_weights(w1, w2, x, logits, topk, True).float()
+    assert ops.last_kernel() == "gemv_rows_grouped"
+    # the same pairs through the same kernel, summed per rank first: fp16 rounding of the partial sums only
+    for ref in (full, base):
+        err = (total - ref).abs()
+        assert bool((err <= 4e-3 * ref.abs() + 4e-3 * ref.abs().mean()).all()), float(err.max())
